@@ -1,0 +1,162 @@
+/*
+ * tsnet_abi.h -- C ABI of the MI355X-native TS-Net generator forward path.
+ *
+ * The reference (nihaomiao/WACV23_TSNet) has NO plugin / operator / FFI boundary: callers
+ * drive a Python object.  This header therefore defines the boundary
+ * a binding for that object would use; every entry point cites the reference interface it
+ * replaces.  Plain C: pointers and sizes only, no torch types.  All device pointers are
+ * contiguous fp32 buffers in the caller's HIP context; `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  Work is enqueued stream-ordered and asynchronously; the
+ * library never synchronises the device inside tsnet_forward*.
+ *
+ * Threading: one host thread per handle; handles are independent (one per GPU / process).
+ * Errors: 0 = ok, negative = failure; tsnet_last_error(h) returns a message owned by the handle
+ *         (tsnet_last_error(NULL) returns the message of the last failed tsnet_create).
+ */
+#ifndef TSNET_ABI_H
+#define TSNET_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSNET_ABI_VERSION 1
+#define TSNET_MAX_SOURCES 8
+
+enum {
+    TSNET_OK = 0,
+    TSNET_ERR_ARG = -1,     /* bad argument / shape / state */
+    TSNET_ERR_WEIGHT = -2,  /* unknown, missing or mis-shaped parameter */
+    TSNET_ERR_HIP = -3,     /* HIP runtime failure (message carries hipGetErrorString) */
+    TSNET_ERR_NOMEM = -4
+};
+
+typedef struct tsnet_engine* tsnet_handle;
+
+/* Constructor arguments of the reference model that shape the forward graph.
+ * Replaces: TSNet.__init__ (model/TSNet.py:204-228), pose extras (model/TSNet_pose.py:214-215,276-280). */
+typedef struct tsnet_cfg {
+    int label_nc;        /* L: label channels (2 face, 25 pose) */
+    int n_blocks;        /* decoder ResnetBlocks (0 quick-start, 4 demos) */
+    int n_downsampling;  /* must be 3 with ngf=64 (FuseNet width is 2*ngf*2^n_down, TSNet.py:227) */
+    int n_source;        /* K <= TSNET_MAX_SOURCES */
+    int ngf;             /* 64 in every reference caller */
+    int enc_blocks;      /* img_enc ResnetBlocks (Encoder default 9, TSNet.py:53) */
+    int addcoords;       /* Encoder.coord_conv on/off (TSNet.py:89-90) */
+    int pose_composite;  /* 1 = TSNet_pose use_mask epilogue (TSNet_pose.py:416-417); needs H=W=256 */
+    float pose_mean[3];  /* BGR mean of the pose model (TSNet_pose.py:215) */
+    int height, width;   /* input frame size (256x256 in the reference) */
+    int max_batch;       /* largest B a forward will be called with (workspace is sized once) */
+} tsnet_cfg;
+
+/* ---- lifecycle ---------------------------------------------------------------------------
+ * tsnet_create          <- TSNet(...) construction                       (model/TSNet.py:204-264)
+ * tsnet_load_weights    <- net.load_state_dict(ckpt['img_enc'|...])      (demo/demo_face.py:126-129)
+ *     `name` = "<net>.<state_dict key>", nets img_enc / lbl_enc / fuse_net / dec, e.g.
+ *     "img_enc.model.13.conv_block.1.weight" (OIHW fp32) or "dec.map_conv.bias".
+ *     `data` may be a host or a device pointer.  Unknown names -> TSNET_ERR_WEIGHT.
+ * tsnet_finalize        <- networks.init_net's net.cuda()                (model/networks.py:116)
+ *     checks that every parameter was loaded, re-packs weights into the kernels' K-major
+ *     layout in HBM and allocates the workspace arena.  No allocation happens after it.
+ */
+int tsnet_abi_version(void);
+int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out);
+int tsnet_load_weights(tsnet_handle h, const char* name, const float* data, const int64_t* shape, int rank);
+int tsnet_finalize(tsnet_handle h, void* stream);
+void tsnet_destroy(tsnet_handle h);
+const char* tsnet_last_error(tsnet_handle h);
+
+/* Number of parameters the configuration expects and their names/shapes, so a binding can
+ * validate a checkpoint before loading (key schema: SURVEY.md section 8-b). */
+int tsnet_num_params(tsnet_handle h);
+int tsnet_param_info(tsnet_handle h, int index, const char** name, int64_t shape_out[4], int* rank);
+
+/* Packed-weight buffer (device) for replication across GPUs: rank 0 finalizes from a checkpoint,
+ * other ranks finalize from zeros and receive this buffer by one RCCL broadcast
+ * (SURVEY.md section 8-e).  The reference is single-GPU only; there is no reference call site. */
+int tsnet_packed_weights(tsnet_handle h, void** dev_ptr, size_t* bytes);
+
+/* ---- forward -----------------------------------------------------------------------------
+ * tsnet_forward  <- TSNet.set_test_input(...) + TSNet.forward()  (model/TSNet.py:283-294, 309-407)
+ *   src_img[i]  (B,3,H,W)  source frames exactly as the reference caller passes them, i.e. BEFORE
+ *                          the /255 that set_test_input applies (TSNet.py:286)
+ *   src_lbl[i]  (B,L,H,W)  src_bbox[i] (B,H,W)    i < n_source
+ *   tar_lbl     (B,L,H,W)  tar_bbox    (B,H,W)
+ *   out_rgb     (B,3,H,W)  = self.rec_tar_img     (TSNet.py:407; pose composite TSNet_pose.py:416-417)
+ *   out_flow    NULL or (K,B,H/8,W/8,2) = self.warp_grid2d_list when return_flow (TSNet.py:369-370)
+ */
+int tsnet_forward(tsnet_handle h,
+                  const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox,
+                  const float* tar_lbl, const float* tar_bbox,
+                  float* out_rgb, float* out_flow, int B, void* stream);
+
+/* Clip mode (caller pattern demo/demo_face.py:185-192: the same K
+ * sources for every driving frame).  tsnet_set_sources runs img_enc once and caches its features;
+ * tsnet_forward_target then costs only lbl_enc + both branches + decoder and returns the same
+ * result as tsnet_forward on the same inputs. */
+int tsnet_set_sources(tsnet_handle h, const float* const* src_img, const float* const* src_lbl,
+                      const float* const* src_bbox, int B, void* stream);
+int tsnet_forward_target(tsnet_handle h, const float* tar_lbl, const float* tar_bbox,
+                         float* out_rgb, float* out_flow, int B, void* stream);
+
+/* Device copies of the stage tensors of the last forward, for stage-wise parity tests
+ * (NHWC fp32).  name: "src_fea" (K*B,h,w,c; n = i*B+b), "tar_fea" (B,h,w,c), "pg", "sg" (B,h,w,c),
+ * "dec_map" (B,h,w,c).  Returns the element count through *count. */
+int tsnet_stage_ptr(tsnet_handle h, const char* name, const float** dev_ptr, size_t* count);
+
+/* Algorithmic work of one forward at batch B (multiply-accumulates, SURVEY.md section 8-d closed form). */
+double tsnet_forward_macs(tsnet_handle h, int B);
+
+/* Per-kernel-class timing of the next forward(s): when enabled the engine brackets every launch
+ * class with hipEvents on the caller's stream (used by bench.py for the roofline object).
+ * tsnet_timing_read returns accumulated milliseconds and launch counts per class. */
+#define TSNET_TIMING_CLASSES 8
+enum { TSNET_T_CONV = 0, TSNET_T_STATS = 1, TSNET_T_ELEMWISE = 2, TSNET_T_FLOW = 3, TSNET_T_WARP = 4,
+       TSNET_T_PACK = 5, TSNET_T_UPSAMPLE = 6, TSNET_T_OTHER = 7 };
+int tsnet_timing_enable(tsnet_handle h, int on);
+int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64_t launches_out[TSNET_TIMING_CLASSES], int reset);
+
+/* ---- single operators (NHWC fp32 device tensors), exported for op-level parity tests ------
+ * These run the very kernels tsnet_forward uses.
+ *
+ * tsnet_op_conv2d <- nn.Conv2d (+ preceding nn.ReflectionPad2d / zero padding)  (TSNet.py:27,42,66,70,147,152)
+ *   x (N,H,W,Cin) ; w OIHW (Cout,Cin,k,k) host or device ; bias (Cout) or NULL ; y (N,Ho,Wo,Cout)
+ *   pad_mode 0 = zero, 1 = reflect.  in_alpha/in_beta (N*Cin) or NULL: the consumer-side
+ *   InstanceNorm+ReLU applied on load, x' = max(alpha*x + beta, 0) (zero padding pads x').
+ *   act: 0 none, 1 tanh.
+ * tsnet_op_instnorm_stats <- nn.InstanceNorm2d statistics (TSNet.py:53; eps 1e-5, biased variance):
+ *   alpha = 1/sqrt(var+eps), beta = -mean*alpha, each (N*C).
+ * tsnet_op_norm_act   : y = alpha*x+beta (relu optional) ; if resid != NULL y += resid  (ResnetBlock tail, TSNet.py:48)
+ * tsnet_op_upsample2x <- nn.Upsample(scale_factor=2, bilinear, align_corners=False) (TSNet.py:145), with the
+ *   producer's InstanceNorm+ReLU fused on load when alpha/beta != NULL.
+ * tsnet_op_flow       <- transformation branch up to the flow field (TSNet.py:319-323,339-365):
+ *   tar_fea (B,h,w,C), src_fea (B,h,w,C) un-normalised NHWC; bboxes (B,H,W); flow (B,h,w,2).
+ * tsnet_op_warp       <- F.grid_sample(bilinear, zeros, align_corners=False) (TSNet.py:366) on NHWC.
+ */
+int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin,
+                    const float* w_oihw, const float* bias, int Cout, int ksize, int stride, int pad, int pad_mode,
+                    const float* in_alpha, const float* in_beta, int in_relu, int act,
+                    float* y, void* stream);
+int tsnet_op_instnorm_stats(const float* x, int N, int HW, int C, float* alpha, float* beta, void* stream);
+int tsnet_op_norm_act(const float* x, const float* alpha, const float* beta, int relu, const float* resid,
+                      int N, int HW, int C, float* y, void* stream);
+int tsnet_op_upsample2x(const float* x, const float* alpha, const float* beta, int relu,
+                        int N, int H, int W, int C, float* y, void* stream);
+int tsnet_op_flow(const float* tar_fea, const float* src_fea, const float* tar_bbox, const float* src_bbox,
+                  int B, int h, int w, int C, int H, int W, float* flow, void* stream);
+int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, int C, float* out, void* stream);
+const char* tsnet_op_last_error(void);
+
+/* Host-side constant tables, exported so CPU tests can pin them against torch:
+ * tsnet_linspace <- torch.linspace(-1,1,n) as used by get_grid (TSNet.py:301-302);
+ * tsnet_coord_table <- Encoder.coord_conv channels (xx,yy,rr) at (H,W), layout (H,W,3) (TSNet.py:107-122). */
+void tsnet_linspace(int n, float* out);
+void tsnet_coord_table(int H, int W, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSNET_ABI_H */

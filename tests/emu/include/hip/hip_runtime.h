@@ -1,0 +1,80 @@
+// TEST INFRASTRUCTURE ONLY -- a minimal CPU emulation of the HIP programming model.
+//
+// The product is built by hipcc for gfx950 and never sees this header.  tests/emu compiles the
+// *unmodified* engine sources (wacv23_tsnet_amd/csrc/*.cpp, *.hpp) with a host compiler and this
+// directory first on the include path, which turns every kernel launch into a sequential loop over
+// workgroups whose threads run as cooperative fibers.  Wave-collective builtins (MFMA, shuffles)
+// and __syncthreads are rendezvous points between fibers, and the MFMA emulation follows the gfx950
+// fragment layout (cdna_hip_programming.md section 3), so an indexing or layout mistake in a kernel
+// shows up on the CPU, against the oracle, before any GPU time is spent.
+// It is slow (~1 GFLOP/s) and is used on tiny shapes only.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+typedef int hipError_t;
+typedef struct emu_stream* hipStream_t;
+typedef struct emu_event* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+namespace emu {
+struct Idx { unsigned x, y, z; };
+extern Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+extern unsigned char* g_dyn_smem;
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void syncthreads();
+float shfl_xor(float v, int mask);
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+f32x16_t mfma_32x32x2(float a, float b, f32x16_t c);
+}  // namespace emu
+
+#define threadIdx (emu::g_threadIdx)
+#define blockIdx (emu::g_blockIdx)
+#define blockDim (emu::g_blockDim)
+#define gridDim (emu::g_gridDim)
+
+// dynamic LDS: HIP's own HIP_DYNAMIC_SHARED macro (amd_device_functions.h) is what the kernels use
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<unsigned char*>(emu::g_dyn_smem);
+static inline void __syncthreads() { emu::syncthreads(); }
+static inline float __shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
+
+static inline const char* hipGetErrorString(hipError_t) { return "emu error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); return *p ? hipSuccess : 1; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })

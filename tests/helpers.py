@@ -1,0 +1,75 @@
+"""Shared helpers for the parity tests (CPU-emulation tier and GPU tier run the same cases)."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import tsnet_oracle as O
+from wacv23_tsnet_amd.engine import TSNetEngine
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return meta, z
+
+
+def make_engine(cfg: O.TSNetConfig, sd, H, W, max_batch, device, lib=None) -> TSNetEngine:
+    eng = TSNetEngine(label_nc=cfg.label_nc, n_blocks=cfg.n_blocks, n_downsampling=cfg.n_downsampling,
+                      n_source=cfg.n_source, ngf=cfg.ngf, enc_blocks=cfg.enc_blocks, addcoords=cfg.addcoords,
+                      pose_composite=bool(cfg.pose and cfg.use_mask), pose_mean=cfg.mean,
+                      height=H, width=W, max_batch=max_batch, lib=lib)
+    eng.load_state_dict({k: v.to(device) for k, v in sd.items()})
+    eng.finalize(device)
+    return eng
+
+
+def run_engine(eng: TSNetEngine, inputs, device, return_flow=True):
+    src_img, src_lbl, src_bbox, tar_lbl, tar_bbox = inputs
+    to = lambda t: t.to(device)
+    rec, flows = eng.forward([to(x) for x in src_img], [to(x) for x in src_lbl], [to(x) for x in src_bbox],
+                             to(tar_lbl), to(tar_bbox), return_flow=return_flow)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+    return rec.cpu(), ([f.cpu() for f in flows] if flows is not None else None)
+
+
+def nhwc_to_nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def stage_report(eng, ref_stages, K, B, device):
+    """max-abs deltas of the engine's stage tensors vs the oracle's."""
+    out = {}
+    src = nhwc_to_nchw(eng.stage("src_fea", device).cpu())
+    for i in range(K):
+        out[f"src_fea{i}"] = (src[i * B:(i + 1) * B] - ref_stages["src_fea"][i]).abs().max().item()
+    for k in ("tar_fea", "pg", "sg", "dec_map"):
+        out[k] = (nhwc_to_nchw(eng.stage(k, device).cpu()) - ref_stages[k]).abs().max().item()
+    return out
+
+
+_SD_CACHE = {}
+
+
+def cfg_from_meta(meta) -> O.TSNetConfig:
+    c = meta["cfg"]
+    return O.TSNetConfig(label_nc=c["label_nc"], n_blocks=c["n_blocks"], n_downsampling=c["n_downsampling"],
+                         n_source=c["n_source"], pose=c["pose"], use_mask=c["use_mask"])
+
+
+def golden_case(name):
+    """(meta, arrays, cfg, state_dict, inputs) of a committed golden, regenerated from the PRNG."""
+    meta, z = load_golden(name)
+    cfg = cfg_from_meta(meta)
+    key = (cfg.label_nc, cfg.n_blocks, meta["wseed"], meta["bias_std"])
+    if key not in _SD_CACHE:
+        _SD_CACHE.clear()          # 268 MB each: keep one
+        _SD_CACHE[key] = O.synth_state_dict(cfg, seed=meta["wseed"], bias_std=meta["bias_std"])
+    inputs = O.synth_inputs(cfg, meta["B"], meta["H"], meta["W"], seed=meta["iseed"], mask_mode=meta["mask_mode"])
+    return meta, z, cfg, _SD_CACHE[key], inputs

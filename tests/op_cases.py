@@ -1,0 +1,149 @@
+"""Operator-level parity cases, shared by the CPU-emulation tier (tests/test_emu_*.py) and the GPU
+tier (tests/test_gpu_ops.py).  Every case calls through the C ABI (tsnet_op_*) and compares with
+plain PyTorch CPU fp32 ops -- the same ATen ops the reference's modules resolve to."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from wacv23_tsnet_amd import prng
+
+
+def _rand(seed, name, shape, lo=-1.0, hi=1.0):
+    return prng.uniform01(seed, name, shape) * (hi - lo) + lo
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def conv_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, norm=False, act=0, bias=True, seed=0):
+    """nn.Conv2d (+ReflectionPad2d / zero pad, + consumer-side IN+ReLU) vs tsnet_op_conv2d. Returns max|d|."""
+    x = _rand(seed, "x", (N, Cin, H, W))
+    w = _rand(seed, "w", (Cout, Cin, k, k)) * (2.0 / (Cin * k * k) ** 0.5)
+    b = _rand(seed, "b", (Cout,)) if bias else None
+    xin, al, be = x, None, None
+    if norm:
+        al = _rand(seed, "al", (N, Cin), 0.5, 1.5)
+        be = _rand(seed, "be", (N, Cin), -0.3, 0.3)
+        xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
+    if reflect:
+        ref = F.conv2d(F.pad(xin, (pad,) * 4, mode="reflect"), w, b, stride=stride)
+    else:
+        ref = F.conv2d(xin, w, b, stride=stride, padding=pad)
+    if act:
+        ref = torch.tanh(ref)
+    Ho, Wo = ref.shape[2:]
+    xd = nhwc(x).to(dev)
+    y = torch.full((N, Ho, Wo, Cout), float("nan"), device=dev)
+    ald = al.contiguous().to(dev) if norm else None
+    bed = be.contiguous().to(dev) if norm else None
+    wd, bd = w.to(dev), (b.to(dev) if bias else None)
+    rc = lib.tsnet_op_conv2d(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), _p(bd), Cout, k, stride, pad, int(reflect),
+                             _p(ald), _p(bed), 1 if norm else 0, act, y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    return (nchw(y.cpu()) - ref).abs().max().item()
+
+
+def instnorm_case(lib, dev, N, H, W, C, relu, resid, seed=0, offset=0.0):
+    """InstanceNorm2d(eps=1e-5, biased var) [+ReLU] [+residual] vs stats + norm_act kernels."""
+    x = _rand(seed, "x", (N, C, H, W), -2, 2) + offset
+    ref = F.instance_norm(x, eps=1e-5)
+    if relu:
+        ref = F.relu(ref)
+    r = _rand(seed, "r", (N, C, H, W)) if resid else None
+    if resid:
+        ref = r + ref
+    xd = nhwc(x).to(dev)
+    al = torch.empty(N * C, device=dev)
+    be = torch.empty(N * C, device=dev)
+    rc = lib.tsnet_op_instnorm_stats(xd.data_ptr(), N, H * W, C, al.data_ptr(), be.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    y = torch.empty_like(xd)
+    rd = nhwc(r).to(dev) if resid else None
+    rc = lib.tsnet_op_norm_act(xd.data_ptr(), al.data_ptr(), be.data_ptr(), int(relu), _p(rd), N, H * W, C, y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    return (nchw(y.cpu()) - ref).abs().max().item()
+
+
+def upsample_case(lib, dev, N, H, W, C, norm, seed=0):
+    """nn.Upsample(x2, bilinear, align_corners=False) [after IN+ReLU] vs tsnet_op_upsample2x."""
+    x = _rand(seed, "x", (N, C, H, W), -2, 2)
+    xin, al, be = x, None, None
+    if norm:
+        al = _rand(seed, "al", (N, C), 0.5, 1.5)
+        be = _rand(seed, "be", (N, C), -0.3, 0.3)
+        xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
+    ref = F.interpolate(xin, scale_factor=2, mode="bilinear", align_corners=False)
+    xd = nhwc(x).to(dev)
+    y = torch.empty((N, 2 * H, 2 * W, C), device=dev)
+    ald = al.contiguous().to(dev) if norm else None
+    bed = be.contiguous().to(dev) if norm else None
+    rc = lib.tsnet_op_upsample2x(xd.data_ptr(), _p(ald), _p(bed), int(norm), N, H, W, C, y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    return (nchw(y.cpu()) - ref).abs().max().item()
+
+
+def flow_case(lib, dev, B, h, w, C, mask_mode="bernoulli", seed=0, spike=False):
+    """Transformation branch up to the flow (TSNet.py:319-365) + grid_sample (:366) vs the oracle's
+    transformation_branch.  spike=True plants one dominant source per target (forces online-softmax
+    rescales in every tile order).  Returns (max|d flow|, max|d warped|)."""
+    from oracle import tsnet_oracle as O
+    H, W = h * 8, w * 8
+    tar = F.relu(_rand(seed, "tar", (B, C, h, w), -1, 1))
+    src = _rand(seed, "src", (B, C, h, w), -1, 1) * 3
+    if spike:
+        P = h * w
+        perm = torch.arange(P - 1, -1, -1)
+        srcf = src.view(B, C, P)
+        tarf = tar.view(B, C, P)
+        srcf[:, :, perm] = srcf[:, :, perm] * 0.2 + 4.0 * tarf    # source perm[t] ~ aligned with target t
+    if mask_mode == "ones":
+        mt, ms = torch.ones(B, H, W), torch.ones(B, H, W)
+    elif mask_mode == "zeros":
+        mt, ms = torch.zeros(B, H, W), torch.zeros(B, H, W)
+    elif mask_mode == "soft":
+        mt, ms = prng.uniform01(seed, "mt", (B, H, W)), prng.uniform01(seed, "ms", (B, H, W))
+    else:
+        mt, ms = prng.bernoulli(seed, "mt", (B, H, W)), prng.bernoulli(seed, "ms", (B, H, W))
+    warped_ref, flow_ref = O.transformation_branch(tar, src, mt.unsqueeze(1), ms.unsqueeze(1))
+    tard, srcd = nhwc(tar).to(dev), nhwc(src).to(dev)
+    mtd, msd = mt.to(dev), ms.to(dev)
+    flow = torch.empty((B, h, w, 2), device=dev)
+    rc = lib.tsnet_op_flow(tard.data_ptr(), srcd.data_ptr(), mtd.data_ptr(), msd.data_ptr(), B, h, w, C, H, W, flow.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    warped = torch.empty((B, h, w, C), device=dev)
+    rc = lib.tsnet_op_warp(srcd.data_ptr(), flow.data_ptr(), B, h, w, C, warped.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    return (flow.cpu() - flow_ref).abs().max().item(), (nchw(warped.cpu()) - warped_ref).abs().max().item()
+
+
+def warp_case(lib, dev, B, h, w, C, seed=0):
+    """F.grid_sample(bilinear, zeros, align_corners=False) with flows that leave [-1,1] (zero padding
+    and border blending exercised) vs tsnet_op_warp."""
+    src = _rand(seed, "src", (B, C, h, w), -2, 2)
+    flow = _rand(seed, "flow", (B, h, w, 2), -1.3, 1.3)
+    ref = F.grid_sample(src, flow, align_corners=False)
+    srcd, fd = nhwc(src).to(dev), flow.to(dev)
+    out = torch.empty((B, h, w, C), device=dev)
+    rc = lib.tsnet_op_warp(srcd.data_ptr(), fd.data_ptr(), B, h, w, C, out.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    return (nchw(out.cpu()) - ref).abs().max().item()

@@ -1,0 +1,68 @@
+"""CPU tier: every HIP kernel of the hot path executed under the fiber emulator (tests/emu) through
+the C ABI and compared with PyTorch CPU ops.  This checks indexing / padding / MFMA fragment layout /
+reduction logic; numerics on real hardware are the GPU tier's job."""
+import pytest
+
+import op_cases as oc
+
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_conv_tiles(emu_lib, tile, monkeypatch):
+    # the tile override is read once per process: exercise it through a subprocess-free path by
+    # using shapes whose natural choice is that tile
+    shapes = {0: (1, 32, 32, 16, 256), 1: (1, 32, 32, 16, 64), 2: (2, 9, 7, 16, 40), 3: (1, 16, 16, 8, 3)}
+    N, H, W, Cin, Cout = shapes[tile]
+    assert oc.conv_case(emu_lib, "cpu", N, H, W, Cin, Cout, 3, 1, 1, True, norm=True) < TOL
+
+
+@pytest.mark.parametrize("k,stride,pad,reflect", [(7, 1, 3, True), (3, 2, 1, False), (3, 1, 1, True), (1, 1, 0, False)])
+@pytest.mark.parametrize("norm", [False, True])
+def test_conv_kinds(emu_lib, k, stride, pad, reflect, norm):
+    assert oc.conv_case(emu_lib, "cpu", 2, 12, 10, 8, 24, k, stride, pad, reflect, norm=norm) < TOL
+
+
+def test_conv_head_tanh(emu_lib):
+    assert oc.conv_case(emu_lib, "cpu", 1, 8, 8, 64, 3, 7, 1, 3, True, norm=True, act=1) < TOL
+
+
+def test_conv_ragged_m_and_no_bias(emu_lib):
+    assert oc.conv_case(emu_lib, "cpu", 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL
+
+
+@pytest.mark.parametrize("C,H,W", [(8, 6, 5), (64, 16, 16), (24, 9, 3), (1024, 2, 2)])
+@pytest.mark.parametrize("relu,resid", [(True, False), (False, True)])
+def test_instnorm(emu_lib, C, H, W, relu, resid):
+    assert oc.instnorm_case(emu_lib, "cpu", 2, H, W, C, relu, resid) < TOL
+
+
+def test_instnorm_large_mean(emu_lib):
+    # mean >> std: E[x^2]-mean^2 in fp32 would cancel; the fp64 partials must not
+    assert oc.instnorm_case(emu_lib, "cpu", 1, 16, 16, 8, False, False, offset=300.0) < 2e-3
+
+
+@pytest.mark.parametrize("norm", [False, True])
+def test_upsample(emu_lib, norm):
+    assert oc.upsample_case(emu_lib, "cpu", 2, 5, 7, 16, norm) < TOL
+
+
+@pytest.mark.parametrize("mask_mode", ["bernoulli", "ones", "zeros", "soft"])
+def test_flow_masks(emu_lib, mask_mode):
+    df, dw = oc.flow_case(emu_lib, "cpu", 2, 4, 6, 64, mask_mode)
+    assert df < 5e-5 and dw < 5e-4
+
+
+def test_flow_ragged_positions_and_spike(emu_lib):
+    # P = 7*9 = 63 (not a multiple of the 32-position tiles); spiky attention forces rescales
+    df, dw = oc.flow_case(emu_lib, "cpu", 1, 7, 9, 32, "bernoulli", spike=True)
+    assert df < 5e-5 and dw < 5e-4
+
+
+def test_flow_many_tiles(emu_lib):
+    df, dw = oc.flow_case(emu_lib, "cpu", 1, 16, 16, 16, "ones", spike=True)   # 8 source tiles: 2 per wave
+    assert df < 5e-5 and dw < 5e-4
+
+
+def test_warp_out_of_range(emu_lib):
+    assert oc.warp_case(emu_lib, "cpu", 2, 5, 6, 16) < TOL

@@ -1,0 +1,80 @@
+"""GPU tier: operator-level parity of the HIP kernels against PyTorch CPU fp32 ops, through the C ABI."""
+import pytest
+import torch
+
+import op_cases as oc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 3e-5     # fp32 reassociation noise on O(1) values
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available()
+    from wacv23_tsnet_amd import _lib
+    return _lib.load()       # raises if the HIP extension is missing: no fallback
+
+
+# shapes that select each of the four tile configurations on the real dispatch heuristic
+@pytest.mark.parametrize("shape", [(4, 32, 32, 64, 512), (4, 32, 32, 64, 128), (2, 9, 7, 16, 40), (1, 32, 32, 8, 3), (12, 32, 32, 512, 512)])
+def test_conv_tiles(lib, shape):
+    N, H, W, Cin, Cout = shape
+    assert oc.conv_case(lib, DEV, N, H, W, Cin, Cout, 3, 1, 1, True, norm=True) < TOL
+
+
+@pytest.mark.parametrize("k,stride,pad,reflect", [(7, 1, 3, True), (3, 2, 1, False), (3, 1, 1, True), (1, 1, 0, False)])
+@pytest.mark.parametrize("norm", [False, True])
+def test_conv_kinds(lib, k, stride, pad, reflect, norm):
+    assert oc.conv_case(lib, DEV, 2, 24, 20, 8, 24, k, stride, pad, reflect, norm=norm) < TOL
+
+
+def test_conv_stem_shape(lib):
+    assert oc.conv_case(lib, DEV, 2, 64, 64, 8, 64, 7, 1, 3, True) < TOL
+
+
+def test_conv_head_tanh(lib):
+    assert oc.conv_case(lib, DEV, 1, 32, 32, 64, 3, 7, 1, 3, True, norm=True, act=1) < TOL
+
+
+def test_conv_fuse_shape(lib):
+    assert oc.conv_case(lib, DEV, 2, 16, 16, 1024, 1024, 3, 1, 1, True, norm=True) < 1e-4
+
+
+def test_conv_ragged_m_and_no_bias(lib):
+    assert oc.conv_case(lib, DEV, 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL
+
+
+@pytest.mark.parametrize("C,H,W", [(8, 6, 5), (64, 64, 64), (24, 9, 3), (512, 32, 32), (1024, 8, 8)])
+@pytest.mark.parametrize("relu,resid", [(True, False), (False, True)])
+def test_instnorm(lib, C, H, W, relu, resid):
+    assert oc.instnorm_case(lib, DEV, 2, H, W, C, relu, resid) < TOL
+
+
+def test_instnorm_large_mean(lib):
+    assert oc.instnorm_case(lib, DEV, 1, 16, 16, 8, False, False, offset=300.0) < 2e-3
+
+
+@pytest.mark.parametrize("norm", [False, True])
+def test_upsample(lib, norm):
+    assert oc.upsample_case(lib, DEV, 2, 16, 12, 64, norm) < TOL
+
+
+@pytest.mark.parametrize("mask_mode", ["bernoulli", "ones", "zeros", "soft"])
+def test_flow_masks(lib, mask_mode):
+    df, dw = oc.flow_case(lib, DEV, 2, 8, 8, 512, mask_mode)
+    assert df < 5e-5 and dw < 5e-4
+
+
+def test_flow_full_size(lib):
+    df, dw = oc.flow_case(lib, DEV, 2, 32, 32, 512, "bernoulli", spike=True)
+    assert df < 5e-5 and dw < 5e-4
+
+
+def test_flow_ragged_positions(lib):
+    df, dw = oc.flow_case(lib, DEV, 1, 7, 9, 32, "bernoulli", spike=True)
+    assert df < 5e-5 and dw < 5e-4
+
+
+def test_warp_out_of_range(lib):
+    assert oc.warp_case(lib, DEV, 2, 16, 12, 128) < TOL

@@ -1,0 +1,45 @@
+"""Build the HIP extension in-tree: wacv23_tsnet_amd/lib/libtsnet_hip.so (gfx950 only).
+
+    python -m wacv23_tsnet_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with gpurun snapshots.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "engine.cpp")
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("conv_igemm.hpp", "flow_warp.hpp", "norm_elementwise.hpp")] + \
+       [os.path.join(os.path.dirname(HERE), "include", "tsnet_abi.h")]
+OUT = os.path.join(HERE, "lib", "libtsnet_hip.so")
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
+         "-fhip-fp32-correctly-rounded-divide-sqrt",   # IEEE / and sqrt: the /255, F.normalize and softmax divisions
+         "-ffp-contract=off"]                           # FMAs only where the source asks for them (fmaf)
+
+
+def up_to_date() -> bool:
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and up_to_date():
+        return OUT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found; cannot build the HIP extension")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc] + FLAGS + [SRC, "-o", OUT]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

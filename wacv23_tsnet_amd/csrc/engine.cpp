@@ -1,0 +1,922 @@
+// engine.cpp -- host side of the TS-Net forward engine behind include/tsnet_abi.h.
+//
+// Compiled with hipcc for gfx950 (the product) and, by tests only, with a host compiler against
+// tests/emu's HIP emulation headers so the launch geometry / indexing logic of every kernel can be
+// checked against the oracle without a GPU.  There is no CPU fallback in the product: every entry
+// point launches HIP kernels and reports HIP failures through tsnet_last_error.
+//
+// Schedule of one forward (reference: model/TSNet.py:309-407), NHWC fp32 throughout, the K sources
+// batched into one launch per layer (image index n = s*B + b):
+//   pack_input -> img_enc (stem 7x7, 3 stride-2 convs, 9 ResnetBlocks)           [A2, A4]
+//   pack_input -> lbl_enc (stem + 3 stride-2 convs)                              [A3]
+//   l2norm x2 -> flow_kernel -> warp_mean_kernel                                 [A5, A6]
+//   fuse conv1 (cat on load) -> conv2 -> residual+mean -> 1x1 conv               [A7, A6]
+//   dec map 1x1 (cat on load) -> ResnetBlocks -> 3x (upsample, conv) -> 7x7+tanh [A8, A9]
+// InstanceNorm is split: statistics right after the producing conv (two tiny kernels), the
+// normalise+ReLU inside the consuming conv's loader.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tsnet_abi.h"
+#include "conv_igemm.hpp"
+#include "flow_warp.hpp"
+#include "norm_elementwise.hpp"
+
+using namespace tsnet;
+
+namespace {
+
+thread_local std::string g_op_error;
+std::string g_create_error;
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            char buf__[512];                                                                        \
+            snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            throw std::runtime_error(buf__);                                                        \
+        }                                                                                           \
+    } while (0)
+
+struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct WeightError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+inline int next_pow2(int x) { int p = 4; while (p < x) p <<= 1; return p; }
+
+// ------------------------------------------------------------------------------------------------
+// timing of launch classes (bench.py's roofline object)
+struct Timing {
+    bool on = false;
+    struct Rec { int cls; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    double ms[TSNET_TIMING_CLASSES] = {0};
+    int64_t launches[TSNET_TIMING_CLASSES] = {0};
+    void begin(int cls, hipStream_t s) {
+        if (!on) return;
+        Rec r{cls, nullptr, nullptr};
+        HIP_TRY(hipEventCreate(&r.a));
+        HIP_TRY(hipEventCreate(&r.b));
+        HIP_TRY(hipEventRecord(r.a, s));
+        recs.push_back(r);
+    }
+    void end(hipStream_t s) {
+        if (!on) return;
+        HIP_TRY(hipEventRecord(recs.back().b, s));
+    }
+    void collect() {
+        for (auto& r : recs) {
+            HIP_TRY(hipEventSynchronize(r.b));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+            ms[r.cls] += t;
+            launches[r.cls] += 1;
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        recs.clear();
+    }
+};
+
+struct Ctx {            // what a launch helper needs
+    hipStream_t stream = nullptr;
+    Timing* timing = nullptr;
+};
+
+struct TimeScope {
+    Ctx& c;
+    TimeScope(Ctx& c_, int cls) : c(c_) { if (c.timing) c.timing->begin(cls, c.stream); }
+    ~TimeScope() { if (c.timing) { try { c.timing->end(c.stream); } catch (...) {} } }
+};
+
+inline void check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + " launch failed: " + hipGetErrorString(e));
+}
+
+inline int ew_grid(size_t total, int block = 256) {
+    size_t g = (total + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;    // grid-stride above ~8 blocks per CU
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// convolution layer description + launch
+struct ConvLayer {
+    std::string name;       // state_dict prefix, e.g. "img_enc.model.1"
+    int cin_real = 0, cin_pad = 0, cout = 0, ks = 1, stride = 1, pad = 0, reflect = 0;
+    int kpad = 0, npad = 0;
+    size_t w_off = 0, b_off = 0;  // offsets (floats) into the packed buffer
+    const float* w = nullptr;     // device, packed
+    const float* bias = nullptr;  // device (cout)
+};
+
+constexpr int BK = 16;
+
+inline int conv_kpad(int ks, int cin_pad) { return round_up(ks * ks * cin_pad, BK); }
+inline int conv_npad(int cout) { return cout >= 128 ? round_up(cout, 128) : round_up(cout, 32); }
+
+struct ConvCall {
+    const float* x = nullptr; const float* x2 = nullptr;
+    int N = 0, H = 0, W = 0;
+    int csplit = 0, x2_nmod = 1;
+    const float* alpha = nullptr; const float* beta = nullptr; int in_relu = 0;
+    float* y = nullptr; int act = 0; int out_nchw = 0;
+    int composite = 0; float bg[3] = {0, 0, 0};
+};
+
+template <int KS, int BM, int BN, int WM_, int WN_>
+void launch_conv_t(const ConvArgs& a, hipStream_t s) {
+    constexpr int KQ = BK / 4, PAD = 8 / KQ;
+    const size_t lds = (size_t)2 * KQ * ((BM + PAD) + (BN + PAD)) * 16;
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, BM, BN, BK, WM_, WN_>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
+}
+
+template <int KS>
+void launch_conv_ks(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    // tile choice: minimise (sequential tiles per CU) x (tile area), smaller tiles slightly penalised
+    struct Cand { int bm, bn; double eff; };
+    const Cand cands[] = {{128, 128, 1.0}, {128, 64, 0.95}, {64, 64, 0.85}, {128, 32, 0.8}};
+    int best = -1; double best_cost = 0;
+    static const int forced = [] { const char* e = getenv("TSNET_CONV_TILE"); return e ? atoi(e) : -1; }();   // test hook
+    for (int i = 0; i < 4; ++i) {
+        if (a.Npad % cands[i].bn) continue;
+        if (forced >= 0 && forced < 4 && a.Npad % cands[forced].bn == 0) { best = forced; break; }
+        if (cands[i].bn > 32 && a.Cout <= cands[i].bn / 2) continue;   // don't waste half the columns
+        const long tm = (a.M + cands[i].bm - 1) / cands[i].bm, tn = (a.Cout + cands[i].bn - 1) / cands[i].bn;
+        const long seq = (tm * tn + 255) / 256;
+        const double cost = (double)seq * cands[i].bm * cands[i].bn / cands[i].eff;
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    if (best < 0) throw std::runtime_error("conv: no tile configuration for Npad");
+    const int bm = cands[best].bm, bn = cands[best].bn;
+    a.tiles_m = (a.M + bm - 1) / bm;
+    a.tiles_n = (a.Cout + bn - 1) / bn;
+    switch (best) {
+        case 0: launch_conv_t<KS, 128, 128, 2, 2>(a, s); break;
+        case 1: launch_conv_t<KS, 128, 64, 2, 2>(a, s); break;
+        case 2: launch_conv_t<KS, 64, 64, 2, 2>(a, s); break;
+        default: launch_conv_t<KS, 128, 32, 4, 1>(a, s); break;
+    }
+}
+
+void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
+    ConvArgs a{};
+    a.x = c.x; a.x2 = c.x2; a.in_alpha = c.alpha; a.in_beta = c.beta;
+    a.w = L.w; a.bias = L.bias; a.y = c.y;
+    a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = L.cin_pad; a.cin_log2 = ilog2(L.cin_pad);
+    a.Csplit = c.x2 ? c.csplit : L.cin_pad; a.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
+    a.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
+    a.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
+    a.Cout = L.cout; a.Npad = L.npad;
+    a.stride = L.stride; a.pad = L.pad; a.reflect = L.reflect;
+    a.taps = L.ks * L.ks; a.nchunks = L.kpad / BK;
+    a.M = c.N * a.Ho * a.Wo;
+    a.in_relu = c.in_relu; a.act = c.act; a.out_nchw = c.out_nchw;
+    a.composite = c.composite; a.fore_x0 = 64; a.fore_x1 = 192;   // TSNet_pose.py:279
+    a.bg[0] = c.bg[0]; a.bg[1] = c.bg[1]; a.bg[2] = c.bg[2];
+    if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
+    if ((a.Csplit & 3) || ((L.cin_pad - a.Csplit) & 3)) throw ArgError("conv: channel split must be a multiple of 4");
+    if ((double)c.N * c.H * c.W * L.cin_pad >= 2147483647.0 || (double)a.M * L.cout >= 2147483647.0)
+        throw ArgError("conv: tensor exceeds 2^31 elements");
+    TimeScope ts(ctx, TSNET_T_CONV);
+    switch (L.ks) {
+        case 1: launch_conv_ks<1>(a, ctx.stream); break;
+        case 3: launch_conv_ks<3>(a, ctx.stream); break;
+        case 7: launch_conv_ks<7>(a, ctx.stream); break;
+        default: throw ArgError("conv: kernel size must be 1, 3 or 7");
+    }
+    check_launch("conv_igemm");
+}
+
+// InstanceNorm statistics -> (alpha, beta); `part` must hold N*64*C*2 doubles
+void run_stats(Ctx& ctx, const float* x, int N, int HW, int C, double* part, float* alpha, float* beta) {
+    if (C & 3) throw ArgError("instnorm: C must be a multiple of 4");
+    TimeScope ts(ctx, TSNET_T_STATS);
+    const int cq = C / 4, cols = cq < 256 ? cq : 256, R = 256 / cols;
+    int S = (HW + R * 8 - 1) / (R * 8);
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    const int rps = (HW + S - 1) / S;
+    S = (HW + rps - 1) / rps;
+    StatsArgs sa{x, part, HW, C, S, rps};
+    hipLaunchKernelGGL(in_stats_partial_kernel, dim3(S, N, (cq + 255) / 256), dim3(256), 0, ctx.stream, sa);
+    check_launch("in_stats_partial");
+    const int NC = N * C;
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, ctx.stream, part, alpha, beta, NC, C, S, HW, 1e-5f);
+    check_launch("in_finalize");
+}
+
+void run_norm_act(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, const float* resid,
+                  int N, int HW, int C, float* y) {
+    if (C & 3) throw ArgError("norm_act: C must be a multiple of 4");
+    TimeScope ts(ctx, TSNET_T_ELEMWISE);
+    NormActArgs a{x, alpha, beta, resid, y, HW, C, relu, (size_t)N * HW * C / 4};
+    hipLaunchKernelGGL(norm_act_kernel, dim3(ew_grid(a.total4)), dim3(256), 0, ctx.stream, a);
+    check_launch("norm_act");
+}
+
+void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, int N, int H, int W, int C, float* y) {
+    if (C & 3) throw ArgError("upsample: C must be a multiple of 4");
+    TimeScope ts(ctx, TSNET_T_UPSAMPLE);
+    UpsampleArgs a{x, alpha, beta, y, N, H, W, C, relu};
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, ctx.stream, a);
+    check_launch("upsample2x");
+}
+
+void run_l2norm(Ctx& ctx, const float* x, float* y, int rows, int C) {
+    TimeScope ts(ctx, TSNET_T_ELEMWISE);
+    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, ctx.stream, x, y, rows, C);
+    check_launch("l2norm");
+}
+
+void run_flow(Ctx& ctx, FlowArgs a, int NB) {
+    if (a.C & 7) throw ArgError("flow: C must be a multiple of 8");
+    TimeScope ts(ctx, TSNET_T_FLOW);
+    const size_t lds = ((size_t)32 * (a.C + 4) + ((a.P + 3) & ~3) + 8 * 32 * 4) * sizeof(float);
+    if (lds > 160 * 1024) throw ArgError("flow: feature width / position count exceed the LDS budget");
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(flow_kernel, dim3((a.P + 31) / 32, NB), dim3(256), lds, ctx.stream, a);
+    check_launch("flow");
+}
+
+void run_warp(Ctx& ctx, const float* src, const float* flow, float* out, int B, int K, int h, int w, int C) {
+    TimeScope ts(ctx, TSNET_T_WARP);
+    WarpArgs a{src, flow, out, B, K, h, w, C};
+    hipLaunchKernelGGL(warp_mean_kernel, dim3(ew_grid((size_t)B * h * w * C / 4)), dim3(256), 0, ctx.stream, a);
+    check_launch("warp_mean");
+}
+
+void pack_layer_weights(const float* w_oihw_dev, float* out_dev, const ConvLayer& L, hipStream_t s) {
+    const size_t total = (size_t)L.kpad * L.npad;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw_dev, out_dev,
+                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad);
+    check_launch("pack_weights");
+}
+
+// torch.linspace(-1, 1, n) in float32: step = (end-start)/(n-1); first half start+i*step, second half
+// end-(n-1-i)*step (ATen's symmetric formula).
+void linspace_pm1(int n, float* out) {
+    if (n == 1) { out[0] = -1.f; return; }
+    const float start = -1.f, end = 1.f;
+    const float step = (end - start) / (float)(n - 1);
+    const int half = n / 2;
+    for (int i = 0; i < n; ++i) out[i] = i < half ? start + step * (float)i : end - step * (float)(n - i - 1);
+}
+
+// Encoder.coord_conv channels: xx = 2*(j/(w-1))-1, yy likewise, rr = sqrt(xx*xx+yy*yy); layout (H,W,3).
+void coord_table(int H, int W, float* out) {
+    for (int i = 0; i < H; ++i) {
+        volatile float ys = (float)i / (float)(H - 1);
+        volatile float yy = 2.f * ys - 1.f;
+        for (int j = 0; j < W; ++j) {
+            volatile float xs = (float)j / (float)(W - 1);
+            volatile float xx = 2.f * xs - 1.f;
+            volatile float x2 = xx * xx;
+            volatile float y2 = yy * yy;
+            volatile float ss = x2 + y2;
+            float* o = out + ((size_t)i * W + j) * 3;
+            o[0] = xx; o[1] = yy; o[2] = sqrtf(ss);
+        }
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+struct tsnet_engine {
+    tsnet_cfg cfg{};
+    std::string err;
+    bool finalized = false;
+    int C = 0, h = 0, w = 0, P = 0, K = 0, Bmax = 0;
+    int cp_img = 0, cp_lbl = 0;
+
+    struct Param { std::string name; std::vector<int64_t> shape; std::vector<float> host; bool loaded = false; };
+    std::vector<Param> params;
+    std::map<std::string, int> pindex;
+
+    // layers
+    std::vector<ConvLayer> img_enc, lbl_enc;            // stem, downs, then 2 per resblock
+    ConvLayer fuse_c1, fuse_c2, fuse_out, dec_map, dec_head;
+    std::vector<ConvLayer> dec_res, dec_up;
+    std::vector<ConvLayer*> all_layers;
+
+    // device memory
+    float* wpack = nullptr; size_t wpack_floats = 0;
+    float* arena = nullptr; size_t arena_floats = 0;
+    float* d_coords = nullptr; float* d_gx = nullptr; float* d_gy = nullptr;
+
+    // arena buffers (sized for Bmax)
+    float *x_img = nullptr, *x_lbl = nullptr;
+    std::vector<float*> raw_img, raw_lbl;
+    float *X = nullptr, *Y1 = nullptr, *Y2 = nullptr;
+    float *tar_fea = nullptr, *that = nullptr, *shat = nullptr, *flow = nullptr, *pg = nullptr;
+    float *F1 = nullptr, *F2 = nullptr, *zbar = nullptr, *sg = nullptr;
+    float *D = nullptr, *DY1 = nullptr, *DY2 = nullptr;
+    std::vector<float*> U, R;
+    float* ab[4][2] = {{nullptr}};
+    double* part = nullptr;
+    int ab_rr = 0;
+
+    // clip-mode cache
+    int cached_B = 0;
+    const float* cached_bbox[TSNET_MAX_SOURCES] = {nullptr};
+    float* bbox_copy = nullptr;     // (K, Bmax, H, W) device copies of the source bboxes
+    int last_B = 0;
+
+    Timing timing;
+
+    void add_param(const std::string& name, std::vector<int64_t> shape) {
+        pindex[name] = (int)params.size();
+        Param p; p.name = name; p.shape = std::move(shape);
+        params.push_back(std::move(p));
+    }
+    ConvLayer make_conv(const std::string& name, int cin_real, int cin_pad, int cout, int ks, int stride, int pad, int reflect) {
+        ConvLayer L; L.name = name; L.cin_real = cin_real; L.cin_pad = cin_pad; L.cout = cout; L.ks = ks;
+        L.stride = stride; L.pad = pad; L.reflect = reflect;
+        L.kpad = conv_kpad(ks, cin_pad); L.npad = conv_npad(cout);
+        add_param(name + ".weight", {cout, cin_real, ks, ks});
+        add_param(name + ".bias", {cout});
+        return L;
+    }
+    void build_layers();
+    void alloc_all(hipStream_t s);
+    void encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin, int N, int cp, std::vector<float*>& raw, float* out_fea, int nblocks);
+    void resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww);
+    void set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B);
+    void forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
+    std::pair<float*, float*> next_ab() { auto r = std::make_pair(ab[ab_rr][0], ab[ab_rr][1]); ab_rr = (ab_rr + 1) & 3; return r; }
+};
+
+void tsnet_engine::build_layers() {
+    const tsnet_cfg& c = cfg;
+    const int coords = c.addcoords ? 3 : 0;
+    auto enc = [&](const std::string& net, int cin, int nblocks, std::vector<ConvLayer>& out) {
+        const int cin_real = cin + coords;
+        const int cp = next_pow2(cin_real);
+        out.push_back(make_conv(net + ".model.1", cin_real, cp, c.ngf, 7, 1, 3, 1));
+        int idx = 4, ch = c.ngf;
+        for (int i = 0; i < c.n_downsampling; ++i) {
+            out.push_back(make_conv(net + ".model." + std::to_string(idx), ch, ch, ch * 2, 3, 2, 1, 0));
+            ch *= 2; idx += 3;
+        }
+        for (int i = 0; i < nblocks; ++i) {
+            out.push_back(make_conv(net + ".model." + std::to_string(idx) + ".conv_block.1", ch, ch, ch, 3, 1, 1, 1));
+            out.push_back(make_conv(net + ".model." + std::to_string(idx) + ".conv_block.5", ch, ch, ch, 3, 1, 1, 1));
+            idx += 1;
+        }
+        return cp;
+    };
+    cp_img = enc("img_enc", 3 + c.label_nc, c.enc_blocks, img_enc);
+    cp_lbl = enc("lbl_enc", c.label_nc, 0, lbl_enc);
+    const int fc = 2 * C;   // FuseNet width: cat of two feature maps (1024 in the reference, TSNet.py:227)
+    fuse_c1 = make_conv("fuse_net.model.0.conv_block.1", fc, fc, fc, 3, 1, 1, 1);
+    fuse_c2 = make_conv("fuse_net.model.0.conv_block.5", fc, fc, fc, 3, 1, 1, 1);
+    fuse_out = make_conv("fuse_net.conv", fc, fc, fc / 2, 1, 1, 0, 0);
+    dec_map = make_conv("dec.map_conv", 2 * C, 2 * C, C, 1, 1, 0, 0);
+    int n = 0;
+    for (int i = 0; i < c.n_blocks; ++i) {
+        dec_res.push_back(make_conv("dec.model" + std::to_string(n) + ".0.conv_block.1", C, C, C, 3, 1, 1, 1));
+        dec_res.push_back(make_conv("dec.model" + std::to_string(n) + ".0.conv_block.5", C, C, C, 3, 1, 1, 1));
+        ++n;
+    }
+    for (int i = 0; i < c.n_downsampling; ++i) {
+        const int ci = c.ngf << (c.n_downsampling - i);
+        dec_up.push_back(make_conv("dec.model" + std::to_string(n) + ".2", ci, ci, ci / 2, 3, 1, 1, 1));
+        ++n;
+    }
+    dec_head = make_conv("dec.model" + std::to_string(n) + ".1", c.ngf, c.ngf, 3, 7, 1, 3, 1);
+    for (auto& L : img_enc) all_layers.push_back(&L);
+    for (auto& L : lbl_enc) all_layers.push_back(&L);
+    all_layers.push_back(&fuse_c1); all_layers.push_back(&fuse_c2); all_layers.push_back(&fuse_out);
+    all_layers.push_back(&dec_map);
+    for (auto& L : dec_res) all_layers.push_back(&L);
+    for (auto& L : dec_up) all_layers.push_back(&L);
+    all_layers.push_back(&dec_head);
+}
+
+void tsnet_engine::alloc_all(hipStream_t s) {
+    // ---- packed weights: one contiguous buffer (single RCCL broadcast replicates a model)
+    size_t off = 0;
+    for (ConvLayer* L : all_layers) {
+        L->w_off = off; off += (size_t)L->kpad * L->npad;
+        L->b_off = off; off += (size_t)round_up(L->cout, 4);
+    }
+    wpack_floats = off;
+    HIP_TRY(hipMalloc((void**)&wpack, wpack_floats * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(wpack, 0, wpack_floats * sizeof(float), s));
+    size_t max_w = 0;
+    for (ConvLayer* L : all_layers) max_w = std::max(max_w, (size_t)L->cout * L->cin_real * L->ks * L->ks);
+    float* stage = nullptr;
+    HIP_TRY(hipMalloc((void**)&stage, max_w * sizeof(float)));
+    for (ConvLayer* L : all_layers) {
+        const Param& pw = params[pindex[L->name + ".weight"]];
+        const Param& pb = params[pindex[L->name + ".bias"]];
+        HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        pack_layer_weights(stage, wpack + L->w_off, *L, s);
+        HIP_TRY(hipMemcpyAsync(wpack + L->b_off, pb.host.data(), pb.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));   // host vectors / staging buffer reused next iteration
+        L->w = wpack + L->w_off;
+        L->bias = wpack + L->b_off;
+    }
+    HIP_TRY(hipFree(stage));
+    for (auto& p : params) { std::vector<float>().swap(p.host); }   // host copies no longer needed
+
+    // ---- constant tables
+    const int H = cfg.height, W = cfg.width;
+    {
+        std::vector<float> t((size_t)H * W * 3), gx(w), gy(h);
+        coord_table(H, W, t.data());
+        linspace_pm1(w, gx.data());
+        linspace_pm1(h, gy.data());
+        HIP_TRY(hipMalloc((void**)&d_coords, t.size() * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&d_gx, w * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&d_gy, h * sizeof(float)));
+        HIP_TRY(hipMemcpy(d_coords, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_gx, gx.data(), w * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_gy, gy.data(), h * sizeof(float), hipMemcpyHostToDevice));
+    }
+
+    // ---- workspace arena: every buffer gets a fixed offset (no allocation after finalize)
+    const size_t NB = (size_t)K * Bmax, B = Bmax;
+    std::vector<std::pair<float**, size_t>> req;
+    auto want = [&](float** p, size_t n) { req.emplace_back(p, (n + 63) & ~(size_t)63); };
+    want(&x_img, NB * H * W * cp_img);
+    want(&x_lbl, B * H * W * cp_lbl);
+    raw_img.assign(cfg.n_downsampling + 1, nullptr);
+    raw_lbl.assign(cfg.n_downsampling + 1, nullptr);
+    for (int l = 0; l <= cfg.n_downsampling; ++l) {
+        const size_t e = (size_t)(H >> l) * (W >> l) * (cfg.ngf << l);
+        want(&raw_img[l], NB * e);
+        want(&raw_lbl[l], B * e);
+    }
+    const size_t fe = (size_t)P * C;
+    want(&X, NB * fe); want(&Y1, NB * fe); want(&Y2, NB * fe);
+    want(&tar_fea, B * fe); want(&that, B * fe); want(&shat, NB * fe); want(&flow, NB * P * 2); want(&pg, B * fe);
+    want(&F1, NB * fe * 2); want(&F2, NB * fe * 2); want(&zbar, B * fe * 2); want(&sg, B * fe);
+    want(&D, B * fe); want(&DY1, B * fe); want(&DY2, B * fe);
+    U.assign(cfg.n_downsampling, nullptr); R.assign(cfg.n_downsampling, nullptr);
+    for (int i = 0; i < cfg.n_downsampling; ++i) {
+        const size_t sp = (size_t)(h << (i + 1)) * (w << (i + 1));
+        want(&U[i], B * sp * (C >> i));
+        want(&R[i], B * sp * (C >> (i + 1)));
+    }
+    for (int i = 0; i < 4; ++i) { want(&ab[i][0], NB * 2 * C); want(&ab[i][1], NB * 2 * C); }
+    want(&bbox_copy, NB * H * W);
+    float* part_f = nullptr;
+    want(&part_f, NB * 64 * 2 * C * 2 * 2);   // doubles: N*S*C*2, as floats x2
+    size_t total = 0;
+    for (auto& r : req) total += r.second;
+    arena_floats = total;
+    HIP_TRY(hipMalloc((void**)&arena, total * sizeof(float)));
+    size_t o = 0;
+    for (auto& r : req) { *r.first = arena + o; o += r.second; }
+    part = reinterpret_cast<double*>(part_f);
+}
+
+// one ResnetBlock on a materialised NHWC tensor Xs (in place): Xs += IN(conv2(relu(IN(conv1(Xs)))))
+void tsnet_engine::resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww) {
+    const int Cc = c1.cout, HW = hh * ww;
+    ConvCall a; a.x = Xs; a.N = N; a.H = hh; a.W = ww; a.y = y1;
+    run_conv(ctx, c1, a);
+    auto s1 = next_ab();
+    run_stats(ctx, y1, N, HW, Cc, part, s1.first, s1.second);
+    ConvCall b; b.x = y1; b.N = N; b.H = hh; b.W = ww; b.alpha = s1.first; b.beta = s1.second; b.in_relu = 1; b.y = y2;
+    run_conv(ctx, c2, b);
+    auto s2 = next_ab();
+    run_stats(ctx, y2, N, HW, Cc, part, s2.first, s2.second);
+    run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs);
+}
+
+// Encoder.forward on a packed NHWC input; out_fea = final feature map (materialised)
+void tsnet_engine::encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin, int N, int cp, std::vector<float*>& raw, float* out_fea, int nblocks) {
+    (void)cp;
+    int hh = cfg.height, ww = cfg.width;
+    ConvCall a; a.x = xin; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
+    run_conv(ctx, L[0], a);
+    auto st = next_ab();
+    run_stats(ctx, raw[0], N, hh * ww, L[0].cout, part, st.first, st.second);
+    for (int l = 1; l <= cfg.n_downsampling; ++l) {
+        ConvCall d; d.x = raw[l - 1]; d.N = N; d.H = hh; d.W = ww; d.alpha = st.first; d.beta = st.second; d.in_relu = 1; d.y = raw[l];
+        run_conv(ctx, L[l], d);
+        hh /= 2; ww /= 2;
+        st = next_ab();
+        run_stats(ctx, raw[l], N, hh * ww, L[l].cout, part, st.first, st.second);
+    }
+    run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea);
+    for (int i = 0; i < nblocks; ++i)
+        resblock(ctx, L[cfg.n_downsampling + 1 + 2 * i], L[cfg.n_downsampling + 2 + 2 * i], out_fea, Y1, Y2, N, hh, ww);
+}
+
+void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B) {
+    const int H = cfg.height, W = cfg.width;
+    {
+        TimeScope ts(ctx, TSNET_T_PACK);
+        PackArgs p{};
+        for (int s = 0; s < K; ++s) { p.img[s] = src_img[s]; p.lbl[s] = src_lbl[s]; }
+        p.coords = cfg.addcoords ? d_coords : nullptr;
+        p.out = x_img; p.S = K; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 3; p.Cp = cp_img;
+        hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)K * B * H * W)), dim3(256), 0, ctx.stream, p);
+        check_launch("pack_input(img)");
+        for (int s = 0; s < K; ++s)
+            HIP_TRY(hipMemcpyAsync(bbox_copy + (size_t)s * Bmax * H * W, src_bbox[s], (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
+    }
+    encode(ctx, img_enc, x_img, K * B, cp_img, raw_img, X, cfg.enc_blocks);
+    run_l2norm(ctx, X, shat, K * B * P, C);
+    cached_B = B;
+}
+
+void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
+    const int H = cfg.height, W = cfg.width, NB = K * B;
+    {
+        TimeScope ts(ctx, TSNET_T_PACK);
+        PackArgs p{};
+        p.img[0] = nullptr; p.lbl[0] = tar_lbl;
+        p.coords = cfg.addcoords ? d_coords : nullptr;
+        p.out = x_lbl; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
+        hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ctx.stream, p);
+        check_launch("pack_input(lbl)");
+    }
+    encode(ctx, lbl_enc, x_lbl, B, cp_lbl, raw_lbl, tar_fea, 0);
+
+    // ---- transformation branch
+    run_l2norm(ctx, tar_fea, that, B * P, C);
+    FlowArgs fa{};
+    fa.that = that; fa.shat = shat; fa.tar_bbox = tar_bbox;
+    for (int s = 0; s < K; ++s) fa.src_bbox[s] = bbox_copy + (size_t)s * Bmax * H * W;
+    fa.gx = d_gx; fa.gy = d_gy; fa.flow = flow;
+    fa.B = B; fa.P = P; fa.C = C; fa.h = h; fa.w = w; fa.H = H; fa.W = W; fa.sy = H / h; fa.sx = W / w;
+    run_flow(ctx, fa, NB);
+    if (out_flow)
+        HIP_TRY(hipMemcpyAsync(out_flow, flow, (size_t)NB * P * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
+    run_warp(ctx, X, flow, pg, B, K, h, w, C);
+
+    // ---- synthesis branch (FuseNet), cat(src_fea, tar_fea) formed inside the conv loader
+    {
+        ConvCall a; a.x = X; a.x2 = tar_fea; a.csplit = C; a.x2_nmod = B; a.N = NB; a.H = h; a.W = w; a.y = F1;
+        run_conv(ctx, fuse_c1, a);
+        auto s1 = next_ab();
+        run_stats(ctx, F1, NB, P, 2 * C, part, s1.first, s1.second);
+        ConvCall b; b.x = F1; b.N = NB; b.H = h; b.W = w; b.alpha = s1.first; b.beta = s1.second; b.in_relu = 1; b.y = F2;
+        run_conv(ctx, fuse_c2, b);
+        auto s2 = next_ab();
+        run_stats(ctx, F2, NB, P, 2 * C, part, s2.first, s2.second);
+        {
+            TimeScope ts(ctx, TSNET_T_ELEMWISE);
+            FuseTailArgs t{X, tar_fea, F2, s2.first, s2.second, zbar, B, K, P, C};
+            hipLaunchKernelGGL(fuse_resid_mean_kernel, dim3(ew_grid((size_t)B * P * 2 * C / 4)), dim3(256), 0, ctx.stream, t);
+            check_launch("fuse_resid_mean");
+        }
+        ConvCall c; c.x = zbar; c.N = B; c.H = h; c.W = w; c.y = sg;
+        run_conv(ctx, fuse_out, c);
+    }
+
+    // ---- decoder
+    {
+        ConvCall a; a.x = pg; a.x2 = sg; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
+        run_conv(ctx, dec_map, a);
+    }
+    for (int i = 0; i < cfg.n_blocks; ++i) resblock(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, DY1, DY2, B, h, w);
+    const float* cur = D; const float* cal = nullptr; const float* cbe = nullptr;
+    int hh = h, ww = w, cc = C;
+    for (int i = 0; i < cfg.n_downsampling; ++i) {
+        run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, U[i]);
+        hh *= 2; ww *= 2;
+        ConvCall a; a.x = U[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
+        run_conv(ctx, dec_up[i], a);
+        cc /= 2;
+        auto st = next_ab();
+        run_stats(ctx, R[i], B, hh * ww, cc, part, st.first, st.second);
+        cur = R[i]; cal = st.first; cbe = st.second;
+    }
+    ConvCall hd; hd.x = cur; hd.N = B; hd.H = hh; hd.W = ww; hd.alpha = cal; hd.beta = cbe; hd.in_relu = 1;
+    hd.y = out_rgb; hd.act = 1; hd.out_nchw = 1;
+    if (cfg.pose_composite) {
+        hd.composite = 1;
+        for (int c = 0; c < 3; ++c) hd.bg[c] = (-cfg.pose_mean[c]) / 255.0f;   // TSNet_pose.py:276
+    }
+    run_conv(ctx, dec_head, hd);
+    last_B = B;
+}
+
+// ================================================================================================
+// C ABI
+#define API_BEGIN(h)                        \
+    if (!(h)) return TSNET_ERR_ARG;         \
+    try {
+#define API_END(h)                                                              \
+    } catch (const ArgError& e) { (h)->err = e.what(); return TSNET_ERR_ARG; }   \
+      catch (const WeightError& e) { (h)->err = e.what(); return TSNET_ERR_WEIGHT; } \
+      catch (const std::bad_alloc&) { (h)->err = "out of host memory"; return TSNET_ERR_NOMEM; } \
+      catch (const std::exception& e) { (h)->err = e.what(); return TSNET_ERR_HIP; } \
+    return TSNET_OK;
+
+extern "C" {
+
+int tsnet_abi_version(void) { return TSNET_ABI_VERSION; }
+
+int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return TSNET_ERR_ARG; }
+    *out = nullptr;
+    auto bad = [&](const char* m) { g_create_error = m; return TSNET_ERR_ARG; };
+    if (cfg->n_source < 1 || cfg->n_source > TSNET_MAX_SOURCES) return bad("n_source must be in 1..8");
+    if (cfg->label_nc < 1) return bad("label_nc must be >= 1");
+    if (cfg->n_downsampling < 1 || cfg->n_downsampling > 5) return bad("n_downsampling must be in 1..5");
+    if (cfg->ngf < 4 || (cfg->ngf & (cfg->ngf - 1))) return bad("ngf must be a power of two >= 4");
+    if (cfg->n_blocks < 0 || cfg->enc_blocks < 0) return bad("block counts must be >= 0");
+    const int ds = 1 << cfg->n_downsampling;
+    if (cfg->height < ds * 2 || cfg->width < ds * 2 || cfg->height % ds || cfg->width % ds)
+        return bad("height/width must be multiples of 2^n_downsampling (and at least twice that)");
+    if (cfg->max_batch < 1) return bad("max_batch must be >= 1");
+    if (cfg->pose_composite && (cfg->height != 256 || cfg->width != 256))
+        return bad("pose composite is defined for 256x256 frames only (TSNet_pose.py:277-280)");
+    try {
+        tsnet_engine* e = new tsnet_engine();
+        e->cfg = *cfg;
+        e->K = cfg->n_source; e->Bmax = cfg->max_batch;
+        e->C = cfg->ngf << cfg->n_downsampling;
+        e->h = cfg->height / ds; e->w = cfg->width / ds; e->P = e->h * e->w;
+        e->build_layers();
+        *out = e;
+    } catch (const std::exception& ex) { g_create_error = ex.what(); return TSNET_ERR_NOMEM; }
+    return TSNET_OK;
+}
+
+const char* tsnet_last_error(tsnet_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int tsnet_num_params(tsnet_handle h) { return h ? (int)h->params.size() : TSNET_ERR_ARG; }
+
+int tsnet_param_info(tsnet_handle h, int index, const char** name, int64_t shape_out[4], int* rank) {
+    API_BEGIN(h)
+    if (index < 0 || index >= (int)h->params.size()) throw ArgError("param index out of range");
+    const auto& p = h->params[index];
+    if (name) *name = p.name.c_str();
+    if (rank) *rank = (int)p.shape.size();
+    if (shape_out) for (size_t i = 0; i < 4; ++i) shape_out[i] = i < p.shape.size() ? p.shape[i] : 1;
+    API_END(h)
+}
+
+int tsnet_load_weights(tsnet_handle h, const char* name, const float* data, const int64_t* shape, int rank) {
+    API_BEGIN(h)
+    if (h->finalized) throw ArgError("load_weights after finalize");
+    if (!name || !data || !shape) throw ArgError("null argument");
+    auto it = h->pindex.find(name);
+    if (it == h->pindex.end()) throw WeightError(std::string("unknown parameter '") + name + "'");
+    auto& p = h->params[it->second];
+    bool ok = rank == (int)p.shape.size();
+    for (int i = 0; ok && i < rank; ++i) ok = shape[i] == p.shape[i];
+    if (!ok) {
+        std::string m = std::string("shape mismatch for '") + name + "': expected (";
+        for (auto d : p.shape) m += std::to_string(d) + ",";
+        m += ") got (";
+        for (int i = 0; i < rank; ++i) m += std::to_string(shape[i]) + ",";
+        throw WeightError(m + ")");
+    }
+    size_t n = 1;
+    for (auto d : p.shape) n *= (size_t)d;
+    p.host.resize(n);
+    HIP_TRY(hipMemcpy(p.host.data(), data, n * sizeof(float), hipMemcpyDefault));
+    p.loaded = true;
+    API_END(h)
+}
+
+int tsnet_finalize(tsnet_handle h, void* stream) {
+    API_BEGIN(h)
+    if (h->finalized) throw ArgError("finalize called twice");
+    for (auto& p : h->params)
+        if (!p.loaded) throw WeightError("parameter '" + p.name + "' was never loaded");
+    h->alloc_all((hipStream_t)stream);
+    h->finalized = true;
+    API_END(h)
+}
+
+void tsnet_destroy(tsnet_handle h) {
+    if (!h) return;
+    (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
+    delete h;
+}
+
+int tsnet_packed_weights(tsnet_handle h, void** dev_ptr, size_t* bytes) {
+    API_BEGIN(h)
+    if (!h->finalized) throw ArgError("packed_weights before finalize");
+    if (dev_ptr) *dev_ptr = h->wpack;
+    if (bytes) *bytes = h->wpack_floats * sizeof(float);
+    API_END(h)
+}
+
+static void check_forward_args(tsnet_handle h, int B) {
+    if (!h->finalized) throw ArgError("forward before finalize");
+    if (B < 1 || B > h->Bmax) throw ArgError("batch size outside 1..max_batch");
+}
+
+int tsnet_set_sources(tsnet_handle h, const float* const* src_img, const float* const* src_lbl,
+                      const float* const* src_bbox, int B, void* stream) {
+    API_BEGIN(h)
+    check_forward_args(h, B);
+    if (!src_img || !src_lbl || !src_bbox) throw ArgError("null source list");
+    for (int s = 0; s < h->K; ++s)
+        if (!src_img[s] || !src_lbl[s] || !src_bbox[s]) throw ArgError("null source tensor (need n_source entries)");
+    Ctx ctx; ctx.stream = (hipStream_t)stream; ctx.timing = h->timing.on ? &h->timing : nullptr;
+    h->set_sources(ctx, src_img, src_lbl, src_bbox, B);
+    API_END(h)
+}
+
+int tsnet_forward_target(tsnet_handle h, const float* tar_lbl, const float* tar_bbox,
+                         float* out_rgb, float* out_flow, int B, void* stream) {
+    API_BEGIN(h)
+    check_forward_args(h, B);
+    if (!tar_lbl || !tar_bbox || !out_rgb) throw ArgError("null target/output tensor");
+    if (h->cached_B != B) throw ArgError("forward_target: batch differs from the cached sources (call tsnet_set_sources first)");
+    Ctx ctx; ctx.stream = (hipStream_t)stream; ctx.timing = h->timing.on ? &h->timing : nullptr;
+    h->forward_target(ctx, tar_lbl, tar_bbox, out_rgb, out_flow, B);
+    API_END(h)
+}
+
+int tsnet_forward(tsnet_handle h, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox,
+                  const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B, void* stream) {
+    int rc = tsnet_set_sources(h, src_img, src_lbl, src_bbox, B, stream);
+    if (rc != TSNET_OK) return rc;
+    return tsnet_forward_target(h, tar_lbl, tar_bbox, out_rgb, out_flow, B, stream);
+}
+
+int tsnet_stage_ptr(tsnet_handle h, const char* name, const float** dev_ptr, size_t* count) {
+    API_BEGIN(h)
+    if (!h->finalized || h->last_B < 1) throw ArgError("stage_ptr before a forward");
+    const size_t fe = (size_t)h->P * h->C, B = h->last_B;
+    std::string n = name ? name : "";
+    const float* p = nullptr; size_t c = 0;
+    if (n == "src_fea") { p = h->X; c = (size_t)h->K * B * fe; }
+    else if (n == "tar_fea") { p = h->tar_fea; c = B * fe; }
+    else if (n == "pg") { p = h->pg; c = B * fe; }
+    else if (n == "sg") { p = h->sg; c = B * fe; }
+    else if (n == "dec_map") { p = h->D; c = B * fe; }
+    else throw ArgError("unknown stage '" + n + "'");
+    if (dev_ptr) *dev_ptr = p;
+    if (count) *count = c;
+    API_END(h)
+}
+
+double tsnet_forward_macs(tsnet_handle h, int B) {
+    if (!h) return 0.0;
+    // SURVEY.md section 8-a closed form, generalised: every conv = M*N*K_real, plus the correlation
+    // (one masked GEMM per source) and the soft-argmax.
+    const tsnet_cfg& c = h->cfg;
+    const double H = c.height, W = c.width, P = h->P, C = h->C, K = h->K;
+    auto enc = [&](double cin, int nres) {
+        double t = H * W * c.ngf * cin * 49;
+        for (int i = 0; i < c.n_downsampling; ++i) {
+            const double ho = H / (2 << i), wo = W / (2 << i), ci = c.ngf << i;
+            t += ho * wo * (2 * ci) * ci * 9;
+        }
+        return t + nres * 2.0 * P * C * C * 9;
+    };
+    const double coords = c.addcoords ? 3 : 0;
+    const double fuse = 2.0 * P * (2 * C) * (2 * C) * 9 + P * C * (2 * C);
+    double dec = P * C * (2 * C) + c.n_blocks * 2.0 * P * C * C * 9;
+    for (int i = 0; i < c.n_downsampling; ++i) {
+        const double sp = P * (double)(1 << (2 * (i + 1))), ci = C / (1 << i);
+        dec += sp * (ci / 2) * ci * 9;
+    }
+    dec += H * W * 3 * c.ngf * 49;
+    const double corr = K * P * P * C + K * P * P * 2;
+    return B * (K * enc(3 + c.label_nc + coords, c.enc_blocks) + enc(c.label_nc + coords, 0) + K * fuse + dec + corr);
+}
+
+int tsnet_timing_enable(tsnet_handle h, int on) {
+    API_BEGIN(h)
+    h->timing.on = on != 0;
+    API_END(h)
+}
+
+int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64_t launches_out[TSNET_TIMING_CLASSES], int reset) {
+    API_BEGIN(h)
+    h->timing.collect();
+    for (int i = 0; i < TSNET_TIMING_CLASSES; ++i) {
+        if (ms_out) ms_out[i] = h->timing.ms[i];
+        if (launches_out) launches_out[i] = h->timing.launches[i];
+        if (reset) { h->timing.ms[i] = 0; h->timing.launches[i] = 0; }
+    }
+    API_END(h)
+}
+
+// ---------------------------------------------------------------------------------------------
+// single operators
+const char* tsnet_op_last_error(void) { return g_op_error.c_str(); }
+
+#define OP_BEGIN try {
+#define OP_END                                                                   \
+    } catch (const ArgError& e) { g_op_error = e.what(); return TSNET_ERR_ARG; }  \
+      catch (const std::exception& e) { g_op_error = e.what(); return TSNET_ERR_HIP; } \
+    return TSNET_OK;
+
+int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
+                    int ksize, int stride, int pad, int pad_mode, const float* in_alpha, const float* in_beta,
+                    int in_relu, int act, float* y, void* stream) {
+    OP_BEGIN
+    if (!x || !w_oihw || !y) throw ArgError("null tensor");
+    if (Cin < 4 || (Cin & (Cin - 1))) throw ArgError("conv2d op: Cin must be a power of two >= 4 (pad channels with zeros)");
+    hipStream_t s = (hipStream_t)stream;
+    Ctx ctx; ctx.stream = s;
+    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
+    L.reflect = pad_mode; L.kpad = conv_kpad(ksize, Cin); L.npad = conv_npad(Cout);
+    const size_t wn = (size_t)Cout * Cin * ksize * ksize;
+    float *wd = nullptr, *wp = nullptr, *bd = nullptr;
+    HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&wp, (size_t)L.kpad * L.npad * sizeof(float)));
+    HIP_TRY(hipMemcpy(wd, w_oihw, wn * sizeof(float), hipMemcpyDefault));
+    pack_layer_weights(wd, wp, L, s);
+    if (bias) {
+        HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
+        HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
+    }
+    L.w = wp; L.bias = bd;
+    ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.alpha = in_alpha; c.beta = in_beta; c.in_relu = in_relu; c.y = y; c.act = act;
+    run_conv(ctx, L, c);
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(wd); (void)hipFree(wp); (void)hipFree(bd);
+    OP_END
+}
+
+int tsnet_op_instnorm_stats(const float* x, int N, int HW, int C, float* alpha, float* beta, void* stream) {
+    OP_BEGIN
+    if (!x || !alpha || !beta) throw ArgError("null tensor");
+    Ctx ctx; ctx.stream = (hipStream_t)stream;
+    double* part = nullptr;
+    HIP_TRY(hipMalloc((void**)&part, (size_t)N * 64 * C * 2 * sizeof(double)));
+    run_stats(ctx, x, N, HW, C, part, alpha, beta);
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    (void)hipFree(part);
+    OP_END
+}
+
+int tsnet_op_norm_act(const float* x, const float* alpha, const float* beta, int relu, const float* resid,
+                      int N, int HW, int C, float* y, void* stream) {
+    OP_BEGIN
+    if (!x || !y) throw ArgError("null tensor");
+    Ctx ctx; ctx.stream = (hipStream_t)stream;
+    run_norm_act(ctx, x, alpha, beta, relu, resid, N, HW, C, y);
+    OP_END
+}
+
+int tsnet_op_upsample2x(const float* x, const float* alpha, const float* beta, int relu, int N, int H, int W, int C, float* y, void* stream) {
+    OP_BEGIN
+    if (!x || !y) throw ArgError("null tensor");
+    Ctx ctx; ctx.stream = (hipStream_t)stream;
+    run_upsample(ctx, x, alpha, beta, relu, N, H, W, C, y);
+    OP_END
+}
+
+int tsnet_op_flow(const float* tar_fea, const float* src_fea, const float* tar_bbox, const float* src_bbox,
+                  int B, int h, int w, int C, int H, int W, float* flow, void* stream) {
+    OP_BEGIN
+    if (!tar_fea || !src_fea || !tar_bbox || !src_bbox || !flow) throw ArgError("null tensor");
+    if (H % h || W % w) throw ArgError("flow op: bbox size must be a multiple of the feature size");
+    Ctx ctx; ctx.stream = (hipStream_t)stream;
+    const int P = h * w;
+    float *that = nullptr, *shat = nullptr, *gx = nullptr, *gy = nullptr;
+    HIP_TRY(hipMalloc((void**)&that, (size_t)B * P * C * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&shat, (size_t)B * P * C * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&gx, w * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&gy, h * sizeof(float)));
+    std::vector<float> hx(w), hy(h);
+    linspace_pm1(w, hx.data()); linspace_pm1(h, hy.data());
+    HIP_TRY(hipMemcpy(gx, hx.data(), w * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(gy, hy.data(), h * sizeof(float), hipMemcpyHostToDevice));
+    run_l2norm(ctx, tar_fea, that, B * P, C);
+    run_l2norm(ctx, src_fea, shat, B * P, C);
+    FlowArgs fa{};
+    fa.that = that; fa.shat = shat; fa.tar_bbox = tar_bbox; fa.src_bbox[0] = src_bbox; fa.gx = gx; fa.gy = gy; fa.flow = flow;
+    fa.B = B; fa.P = P; fa.C = C; fa.h = h; fa.w = w; fa.H = H; fa.W = W; fa.sy = H / h; fa.sx = W / w;
+    run_flow(ctx, fa, B);
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    (void)hipFree(that); (void)hipFree(shat); (void)hipFree(gx); (void)hipFree(gy);
+    OP_END
+}
+
+int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, int C, float* out, void* stream) {
+    OP_BEGIN
+    if (!src_fea || !flow || !out) throw ArgError("null tensor");
+    if (C & 3) throw ArgError("warp op: C must be a multiple of 4");
+    Ctx ctx; ctx.stream = (hipStream_t)stream;
+    run_warp(ctx, src_fea, flow, out, B, 1, h, w, C);
+    OP_END
+}
+
+void tsnet_linspace(int n, float* out) { linspace_pm1(n, out); }
+void tsnet_coord_table(int H, int W, float* out) { coord_table(H, W, out); }
+
+}  // extern "C"

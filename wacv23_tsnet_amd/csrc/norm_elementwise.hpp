@@ -1,0 +1,294 @@
+// norm_elementwise.hpp -- HBM-bound kernels around the convolutions (NHWC fp32, 16 B per lane).
+//
+// Replaces on the reference hot path:
+//   * nn.InstanceNorm2d statistics (affine=False, eps=1e-5, biased variance; TSNet.py:53 default
+//     norm_layer)                                                        -> in_stats_partial + in_finalize
+//   * the ResnetBlock tail  x + IN(conv(..))   (TSNet.py:47-49)          -> norm_act_kernel(resid)
+//   * Encoder tail  ReLU(IN(.)) materialised once (TSNet.py:70-71)       -> norm_act_kernel(relu)
+//   * FuseNet residual + the mean over sources (TSNet.py:195-200, :400)  -> fuse_resid_mean_kernel
+//   * nn.Upsample(x2, bilinear, align_corners=False) (TSNet.py:145)      -> upsample2x_kernel
+//   * set_test_input's /255 + torch.cat + coord_conv (TSNet.py:286,312,107-125) -> pack_input_kernel
+//   * F.normalize(p=2, dim=1) (TSNet.py:319,339)                         -> l2norm_kernel
+// All reductions use a fixed order (no float atomics): results are run-to-run deterministic.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tsnet {
+
+#ifndef TSNET_F4_DEFINED
+#define TSNET_F4_DEFINED
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// InstanceNorm statistics, stage 1: per (image n, split s) partial sum / sum of squares per channel,
+// accumulated in fp64.  x: (N, HW, C).  part: (N, S, C, 2) doubles.
+// Thread layout: cq = float4 column within the row, rg = row group; block covers all C/4 columns
+// (or 256 of them; grid.z walks the rest).
+struct StatsArgs {
+    const float* x;
+    double* part;
+    int HW, C, S, rows_per_split;
+};
+
+__global__ __launch_bounds__(256) void in_stats_partial_kernel(StatsArgs a) {
+    __shared__ double red[256 * 8];
+    const int cq_total = a.C >> 2;
+    const int cols = cq_total < 256 ? cq_total : 256;   // float4 columns handled per block
+    const int R = 256 / cols;                            // row groups
+    const int tid = threadIdx.x;
+    const int cq = tid % cols + blockIdx.z * 256;
+    const int rg = tid / cols;
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int r0 = s * a.rows_per_split;
+    int r1 = r0 + a.rows_per_split;
+    if (r1 > a.HW) r1 = a.HW;
+    double sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    if (rg < R && cq < cq_total) {
+        const float* base = a.x + ((size_t)n * a.HW) * a.C + (size_t)cq * 4;
+        for (int r = r0 + rg; r < r1; r += R) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * a.C);
+            sm[0] += v.x; sq[0] += (double)v.x * v.x;
+            sm[1] += v.y; sq[1] += (double)v.y * v.y;
+            sm[2] += v.z; sq[2] += (double)v.z * v.z;
+            sm[3] += v.w; sq[3] += (double)v.w * v.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = sm[e]; red[tid * 8 + 4 + e] = sq[e]; }
+    __syncthreads();
+    if (rg == 0 && cq < cq_total) {
+        double tsm[4] = {0, 0, 0, 0}, tsq[4] = {0, 0, 0, 0};
+        for (int g = 0; g < R; ++g) {
+            const int t = g * cols + tid;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { tsm[e] += red[t * 8 + e]; tsq[e] += red[t * 8 + 4 + e]; }
+        }
+        double* o = a.part + (((size_t)n * a.S + s) * a.C + (size_t)cq * 4) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e * 2] = tsm[e]; o[e * 2 + 1] = tsq[e]; }
+    }
+}
+
+// stage 2: alpha = 1/sqrt(var+eps), beta = -mean*alpha  (the x*alpha+beta form ATen's CPU
+// batch-norm transform uses), one thread per (n, c).
+__global__ void in_finalize_kernel(const double* __restrict__ part, float* __restrict__ alpha, float* __restrict__ beta,
+                                   int NC, int C, int S, int HW, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    const int n = i / C, c = i - n * C;
+    double sm = 0, sq = 0;
+    for (int s = 0; s < S; ++s) {
+        const double* p = part + (((size_t)n * S + s) * C + c) * 2;
+        sm += p[0];
+        sq += p[1];
+    }
+    const double mean = sm / HW;
+    double var = sq / HW - mean * mean;
+    if (var < 0) var = 0;
+    const float al = 1.0f / sqrtf((float)var + eps);
+    alpha[i] = al;
+    beta[i] = -((float)mean) * al;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = alpha*x + beta (optionally ReLU) (+ resid).  alpha==null -> y = x (+resid).  In-place safe.
+struct NormActArgs {
+    const float* x;
+    const float* alpha;
+    const float* beta;
+    const float* resid;
+    float* y;
+    int HW, C, relu;
+    size_t total4;   // N*HW*C/4
+};
+
+__global__ __launch_bounds__(256) void norm_act_kernel(NormActArgs a) {
+    const int c4n = a.C >> 2;
+    const size_t per_img = (size_t)a.HW * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / per_img);
+        const int c = (int)(i % c4n) * 4;
+        float4 v = reinterpret_cast<const float4*>(a.x)[i];
+        if (a.alpha) {
+            const float4 al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * a.C + c);
+            const float4 be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * a.C + c);
+            v.x = __builtin_fmaf(v.x, al.x, be.x);
+            v.y = __builtin_fmaf(v.y, al.y, be.y);
+            v.z = __builtin_fmaf(v.z, al.z, be.z);
+            v.w = __builtin_fmaf(v.w, al.w, be.w);
+        }
+        if (a.relu) {
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+            v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        }
+        if (a.resid) {
+            const float4 r = reinterpret_cast<const float4*>(a.resid)[i];
+            v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
+        }
+        reinterpret_cast<float4*>(a.y)[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FuseNet tail: zbar[b,p,:] = (1/K) * sum_i ( cat(src_fea[i*B+b], tar_fea[b])[p,:] + IN(y2[i*B+b])[p,:] )
+// The 1x1 `fuse_net.conv` that follows is linear, so it is applied once to the mean
+// (mean_i conv(z_i)+bias == conv(mean_i z_i)+bias).
+struct FuseTailArgs {
+    const float* src_fea;   // (K*B, P, C1)
+    const float* tar_fea;   // (B, P, C1)
+    const float* y2;        // (K*B, P, 2*C1)
+    const float* alpha;     // (K*B * 2*C1)
+    const float* beta;
+    float* zbar;            // (B, P, 2*C1)
+    int B, K, P, C1;
+};
+
+__global__ __launch_bounds__(256) void fuse_resid_mean_kernel(FuseTailArgs a) {
+    const int C = 2 * a.C1;
+    const int c4n = C >> 2;
+    const size_t total = (size_t)a.B * a.P * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const size_t bp = i / c4n;                  // b*P + p
+        const int b = (int)(bp / a.P);
+        const int p = (int)(bp - (size_t)b * a.P);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < a.K; ++s) {
+            const int n = s * a.B + b;
+            float4 xr;
+            if (c < a.C1) xr = *reinterpret_cast<const float4*>(a.src_fea + ((size_t)n * a.P + p) * a.C1 + c);
+            else          xr = *reinterpret_cast<const float4*>(a.tar_fea + ((size_t)b * a.P + p) * a.C1 + (c - a.C1));
+            const float4 y = *reinterpret_cast<const float4*>(a.y2 + ((size_t)n * a.P + p) * C + c);
+            const float4 al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * C + c);
+            const float4 be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * C + c);
+            acc.x += xr.x + __builtin_fmaf(y.x, al.x, be.x);
+            acc.y += xr.y + __builtin_fmaf(y.y, al.y, be.y);
+            acc.z += xr.z + __builtin_fmaf(y.z, al.z, be.z);
+            acc.w += xr.w + __builtin_fmaf(y.w, al.w, be.w);
+        }
+        const float kf = (float)a.K;
+        acc.x /= kf; acc.y /= kf; acc.z /= kf; acc.w /= kf;
+        *reinterpret_cast<float4*>(a.zbar + ((size_t)b * a.P + p) * C + c) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear x2 upsample, align_corners=False: src = (dst+0.5)/2-0.5 clamped at 0, neighbour index
+// clamped at in-1; horizontal lerp first, then vertical (ATen's separable order).  Optional
+// producer InstanceNorm+ReLU applied to the four taps on load.
+struct UpsampleArgs {
+    const float* x;       // (N,H,W,C)
+    const float* alpha;   // (N*C) or null
+    const float* beta;
+    float* y;             // (N,2H,2W,C)
+    int N, H, W, C, relu;
+};
+
+__device__ __forceinline__ float4 na4(float4 v, const float4& al, const float4& be, bool norm, bool relu) {
+    if (norm) {
+        v.x = __builtin_fmaf(v.x, al.x, be.x); v.y = __builtin_fmaf(v.y, al.y, be.y);
+        v.z = __builtin_fmaf(v.z, al.z, be.z); v.w = __builtin_fmaf(v.w, al.w, be.w);
+    }
+    if (relu) {
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_kernel(UpsampleArgs a) {
+    const int c4n = a.C >> 2;
+    const int Ho = 2 * a.H, Wo = 2 * a.W;
+    const size_t total = (size_t)a.N * Ho * Wo * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        size_t t = i / c4n;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float sy = (oy + 0.5f) * 0.5f - 0.5f; if (sy < 0.f) sy = 0.f;
+        float sx = (ox + 0.5f) * 0.5f - 0.5f; if (sx < 0.f) sx = 0.f;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0), x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+        const float wy1 = sy - y0, wy0 = 1.f - wy1, wx1 = sx - x0, wx0 = 1.f - wx1;
+        const bool norm = a.alpha != nullptr;
+        float4 al = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (norm) {
+            al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * a.C + c);
+            be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * a.C + c);
+        }
+        const float* base = a.x + ((size_t)n * a.H * a.W) * a.C + c;
+        const float4 v00 = na4(*reinterpret_cast<const float4*>(base + ((size_t)y0 * a.W + x0) * a.C), al, be, norm, a.relu);
+        const float4 v01 = na4(*reinterpret_cast<const float4*>(base + ((size_t)y0 * a.W + x1) * a.C), al, be, norm, a.relu);
+        const float4 v10 = na4(*reinterpret_cast<const float4*>(base + ((size_t)y1 * a.W + x0) * a.C), al, be, norm, a.relu);
+        const float4 v11 = na4(*reinterpret_cast<const float4*>(base + ((size_t)y1 * a.W + x1) * a.C), al, be, norm, a.relu);
+        float4 o;
+        o.x = wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
+        o.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
+        o.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
+        o.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
+        reinterpret_cast<float4*>(a.y)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem input assembly: NCHW planes -> one NHWC tensor with Cp channels
+//   [ img/255 (nimg) | lbl (L) | xx yy rr (if coords) | 0 ... ]   image index n = s*B + b.
+struct PackArgs {
+    const float* img[8];   // per source: (B,3,H,W) or null (label encoder input)
+    const float* lbl[8];   // per source: (B,L,H,W)
+    const float* coords;   // (H,W,3) table or null
+    float* out;            // (S*B, H, W, Cp)
+    int S, B, H, W, L, nimg, Cp;
+};
+
+__global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
+    const size_t HW = (size_t)a.H * a.W;
+    const size_t total = (size_t)a.S * a.B * HW;
+    const int creal = a.nimg + a.L + (a.coords ? 3 : 0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % HW;
+        const int n = (int)(i / HW);
+        const int s = n / a.B, b = n - s * a.B;
+        float* o = a.out + i * a.Cp;
+        for (int c0 = 0; c0 < a.Cp; c0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + e;
+                float t = 0.f;
+                if (c < a.nimg) t = a.img[s][((size_t)b * a.nimg + c) * HW + pix] / 255.0f;
+                else if (c < a.nimg + a.L) t = a.lbl[s][((size_t)b * a.L + (c - a.nimg)) * HW + pix];
+                else if (c < creal) t = a.coords[pix * 3 + (c - a.nimg - a.L)];
+                v[e] = t;
+            }
+            *reinterpret_cast<float4*>(o + c0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.normalize(p=2, dim=channel, eps=1e-12) on NHWC rows: one wave per position.
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = x + (size_t)row * C;
+    float ss = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    float nrm = sqrtf(ss);
+    if (nrm < 1e-12f) nrm = 1e-12f;
+    float* q = y + (size_t)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(p + c);
+        v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
+        *reinterpret_cast<float4*>(q + c) = v;
+    }
+}
+
+}  // namespace tsnet

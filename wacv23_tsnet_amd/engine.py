@@ -1,0 +1,206 @@
+"""Python owner of one `tsnet_handle` (include/tsnet_abi.h): device buffers in, device buffers out.
+
+PyTorch is plumbing here -- tensors provide device memory and the current HIP stream; every
+FLOP of the forward runs in libtsnet_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+POSE_MEAN = (101.84807705937696, 112.10832843463207, 111.65973036298041)  # reference model/TSNet_pose.py:215
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream_of(t: torch.Tensor) -> Optional[int]:
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None
+
+
+class TSNetEngine:
+    """One model replica on one device.
+
+    lib: the bound C library.  Product code never passes it (the in-tree HIP library is used and
+    its absence is an error); tests pass the CPU *emulation* build of the same sources to check
+    host logic without a GPU.
+    """
+
+    def __init__(self, *, label_nc: int, n_blocks: int, n_downsampling: int = 3, n_source: int = 3, ngf: int = 64,
+                 enc_blocks: int = 9, addcoords: bool = True, pose_composite: bool = False,
+                 pose_mean: Sequence[float] = POSE_MEAN, height: int = 256, width: int = 256, max_batch: int = 4,
+                 lib=None):
+        self.lib = lib if lib is not None else _lib.load()
+        cfg = _lib.TsnetCfg()
+        cfg.label_nc, cfg.n_blocks, cfg.n_downsampling, cfg.n_source = label_nc, n_blocks, n_downsampling, n_source
+        cfg.ngf, cfg.enc_blocks, cfg.addcoords, cfg.pose_composite = ngf, enc_blocks, int(addcoords), int(pose_composite)
+        for i in range(3):
+            cfg.pose_mean[i] = float(pose_mean[i])
+        cfg.height, cfg.width, cfg.max_batch = height, width, max_batch
+        self.cfg = cfg
+        self.K = n_source
+        self.h = height >> n_downsampling
+        self.w = width >> n_downsampling
+        self.C = ngf << n_downsampling
+        self._h = C.c_void_p()
+        rc = self.lib.tsnet_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"tsnet_create failed ({rc}): {self.lib.tsnet_last_error(None).decode()}")
+        self.finalized = False
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.tsnet_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.tsnet_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def param_shapes(self) -> Dict[str, tuple]:
+        n = self.lib.tsnet_num_params(self._h)
+        out = {}
+        name = C.c_char_p()
+        shape = (C.c_int64 * 4)()
+        rank = C.c_int()
+        for i in range(n):
+            self._check(self.lib.tsnet_param_info(self._h, i, C.byref(name), shape, C.byref(rank)), "tsnet_param_info")
+            out[name.value.decode()] = tuple(int(shape[j]) for j in range(rank.value))
+        return out
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """sd keys: '<net>.<key>' with nets img_enc / lbl_enc / fuse_net / dec (checkpoint schema of
+        the reference, train_face.py:350-355).  Extra keys (netD, netDF, ...) are ignored unless strict."""
+        expected = self.param_shapes()
+        for k, v in sd.items():
+            if k not in expected:
+                if strict:
+                    raise KeyError(f"unexpected parameter {k!r}")
+                continue
+            t = v.detach().to(torch.float32).contiguous()
+            shp = (C.c_int64 * t.dim())(*t.shape)
+            self._check(self.lib.tsnet_load_weights(self._h, k.encode(), t.data_ptr(), shp, t.dim()), f"load_weights({k})")
+            if t.is_cuda:
+                torch.cuda.current_stream(t.device).synchronize()
+        return self
+
+    def finalize(self, device: Optional[torch.device] = None):
+        stream = torch.cuda.current_stream(device).cuda_stream if (device is not None and torch.device(device).type == "cuda") else None
+        self._check(self.lib.tsnet_finalize(self._h, stream), "tsnet_finalize")
+        self.finalized = True
+        return self
+
+    def packed_weights(self, device) -> torch.Tensor:
+        """Alias the engine's packed weight buffer as a flat uint8 torch tensor (for the RCCL broadcast)."""
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._check(self.lib.tsnet_packed_weights(self._h, C.byref(p), C.byref(n)), "tsnet_packed_weights")
+        return _alias_device_bytes(p.value, n.value, device)
+
+    # ------------------------------------------------------------------ forward
+    def _ptr_array(self, ts: Sequence[torch.Tensor]):
+        arr = (C.c_void_p * _lib.MAX_SOURCES)()
+        for i, t in enumerate(ts):
+            arr[i] = t.data_ptr()
+        return arr
+
+    @staticmethod
+    def _prep(t: torch.Tensor, shape: tuple, name: str) -> torch.Tensor:
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        if t.dtype != torch.float32:
+            raise TypeError(f"{name}: expected float32, got {t.dtype}")
+        return t if t.is_contiguous() else t.contiguous()
+
+    def forward(self, src_img: List[torch.Tensor], src_lbl: List[torch.Tensor], src_bbox: List[torch.Tensor],
+                tar_lbl: torch.Tensor, tar_bbox: torch.Tensor, return_flow: bool = False):
+        """tsnet_forward.  All tensors on one device.  Returns (rec (B,3,H,W), flows K x (B,h,w,2) | None)."""
+        B = tar_lbl.shape[0]
+        H, W, L, K = self.cfg.height, self.cfg.width, self.cfg.label_nc, self.K
+        if len(src_img) < K or len(src_lbl) < K or len(src_bbox) < K:
+            raise ValueError(f"need {K} sources")
+        si = [self._prep(src_img[i], (B, 3, H, W), f"src_img[{i}]") for i in range(K)]
+        sl = [self._prep(src_lbl[i], (B, L, H, W), f"src_lbl[{i}]") for i in range(K)]
+        sb = [self._prep(src_bbox[i], (B, H, W), f"src_bbox[{i}]") for i in range(K)]
+        tl = self._prep(tar_lbl, (B, L, H, W), "tar_lbl")
+        tb = self._prep(tar_bbox, (B, H, W), "tar_bbox")
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=tl.device)
+        flow = torch.empty((K, B, self.h, self.w, 2), dtype=torch.float32, device=tl.device) if return_flow else None
+        rc = self.lib.tsnet_forward(self._h, self._ptr_array(si), self._ptr_array(sl), self._ptr_array(sb),
+                                    tl.data_ptr(), tb.data_ptr(), out.data_ptr(), _ptr(flow), B, _stream_of(tl))
+        self._check(rc, "tsnet_forward")
+        self._keep = (si, sl, sb, tl, tb)   # keep inputs alive until the stream has consumed them
+        return out, ([flow[i] for i in range(K)] if return_flow else None)
+
+    def set_sources(self, src_img, src_lbl, src_bbox):
+        B = src_img[0].shape[0]
+        H, W, L, K = self.cfg.height, self.cfg.width, self.cfg.label_nc, self.K
+        si = [self._prep(src_img[i], (B, 3, H, W), f"src_img[{i}]") for i in range(K)]
+        sl = [self._prep(src_lbl[i], (B, L, H, W), f"src_lbl[{i}]") for i in range(K)]
+        sb = [self._prep(src_bbox[i], (B, H, W), f"src_bbox[{i}]") for i in range(K)]
+        rc = self.lib.tsnet_set_sources(self._h, self._ptr_array(si), self._ptr_array(sl), self._ptr_array(sb), B, _stream_of(si[0]))
+        self._check(rc, "tsnet_set_sources")
+        self._keep_src = (si, sl, sb)
+
+    def forward_target(self, tar_lbl, tar_bbox, return_flow: bool = False):
+        B = tar_lbl.shape[0]
+        H, W, L, K = self.cfg.height, self.cfg.width, self.cfg.label_nc, self.K
+        tl = self._prep(tar_lbl, (B, L, H, W), "tar_lbl")
+        tb = self._prep(tar_bbox, (B, H, W), "tar_bbox")
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=tl.device)
+        flow = torch.empty((K, B, self.h, self.w, 2), dtype=torch.float32, device=tl.device) if return_flow else None
+        rc = self.lib.tsnet_forward_target(self._h, tl.data_ptr(), tb.data_ptr(), out.data_ptr(), _ptr(flow), B, _stream_of(tl))
+        self._check(rc, "tsnet_forward_target")
+        self._keep = (tl, tb)
+        return out, ([flow[i] for i in range(K)] if return_flow else None)
+
+    def stage(self, name: str, device) -> torch.Tensor:
+        """Copy of a stage tensor of the last forward, NHWC (see tsnet_stage_ptr)."""
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._check(self.lib.tsnet_stage_ptr(self._h, name.encode(), C.byref(p), C.byref(n)), "tsnet_stage_ptr")
+        flat = _alias_device_bytes(p.value, n.value * 4, device).view(torch.float32).clone()
+        return flat.view(-1, self.h, self.w, self.C)
+
+    def forward_macs(self, B: int) -> float:
+        return float(self.lib.tsnet_forward_macs(self._h, B))
+
+    def timing_enable(self, on: bool):
+        self._check(self.lib.tsnet_timing_enable(self._h, int(on)), "tsnet_timing_enable")
+
+    def timing_read(self, reset: bool = True):
+        ms = (C.c_double * _lib.TIMING_CLASSES)()
+        cnt = (C.c_int64 * _lib.TIMING_CLASSES)()
+        self._check(self.lib.tsnet_timing_read(self._h, ms, cnt, int(reset)), "tsnet_timing_read")
+        return {n: (ms[i], int(cnt[i])) for i, n in enumerate(_lib.TIMING_NAMES)}
+
+
+def _alias_device_bytes(ptr: int, nbytes: int, device) -> torch.Tensor:
+    """View `nbytes` of memory at `ptr` as a uint8 tensor without copying.
+
+    cuda: through __cuda_array_interface__ (zero-copy, the engine keeps ownership);
+    cpu (emulation build in tests): through ctypes."""
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        class _Holder:
+            pass
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(h, device=dev)
+    buf = (C.c_ubyte * nbytes).from_address(ptr)
+    return torch.frombuffer(buf, dtype=torch.uint8)
