@@ -154,7 +154,7 @@ def transformation_branch(tar_fea: torch.Tensor, src_fea: torch.Tensor, tar_bbox
     ms = F.interpolate(src_bbox, (h, w), mode="nearest").view(b, 1, h * w)            # :347-348
     corr = torch.bmm(t * mt, s * ms) + torch.bmm(t * (1.0 - mt), s * (1.0 - ms))      # :350-358
     att = F.softmax(100 * corr, dim=2)                                                # :359
-    flow = torch.matmul(att, get_grid(b, h, w).view(b, h * w, 2)).view(b, h, w, 2)    # :362-365
+    flow = torch.matmul(att, get_grid(b, h, w).to(att.dtype).view(b, h * w, 2)).view(b, h, w, 2)  # :362-365
     warped = F.grid_sample(src_fea, flow, align_corners=False)                        # :366
     return warped, flow
 
@@ -163,7 +163,7 @@ def pose_composite(rec: torch.Tensor, cfg: TSNetConfig) -> torch.Tensor:
     """TSNet_pose fixed-background composite (TSNet_pose.py:276-280, 416-417):
     rec*fore + (-mean/255)*(1-fore), fore = columns 64:192 of a 256x256 frame."""
     mean = torch.tensor(cfg.mean, dtype=torch.float32)
-    mask_img = (-mean).view(1, 3, 1, 1).repeat(1, 1, 256, 256) / 255.0
+    mask_img = ((-mean).view(1, 3, 1, 1).repeat(1, 1, 256, 256) / 255.0).to(rec.dtype)
     fore = torch.zeros((256, 256), dtype=torch.float32)
     fore[:, 64:192] = 1
     fore = fore.view(1, 1, 256, 256)

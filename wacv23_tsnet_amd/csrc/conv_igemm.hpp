@@ -57,7 +57,7 @@ struct alignas(16) F4 { float v[4]; };
 
 __device__ __forceinline__ F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
 
-template <int KS, int BM, int BN, int BK, int WARPS_M, int WARPS_N>
+template <int KS, int BM, int BN, int BK, int WARPS_M, int WARPS_N, int FLUSH>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N)
 void conv_igemm_kernel(ConvArgs a) {
     constexpr int NT = 64 * WARPS_M * WARPS_N;
@@ -187,13 +187,16 @@ void conv_igemm_kernel(ConvArgs a) {
         }
     };
 
-    f32x16 acc[MT][NTL];
+    // Two-level accumulation: the MFMA chain `acc` is folded into `tot` every FLUSH chunks
+    // (FLUSH*BK products), so no fp32 fmaf chain is longer than that and the rounding error grows
+    // like sqrt(FLUSH*BK)+sqrt(K/(FLUSH*BK)) instead of sqrt(K) (K is up to 9216 here).
+    f32x16 acc[MT][NTL], tot[MT][NTL];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTL; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
     load_chunk(0);
     store_chunk(0);
@@ -222,6 +225,17 @@ void conv_igemm_kernel(ConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].v[e], bf[j].v[e], acc[i][j], 0, 0, 0);
         }
 
+        if (FLUSH > 0 && ((kc + 1) % FLUSH) == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {
+                    tot[i][j] += acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+        }
+
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
     }
@@ -239,7 +253,7 @@ void conv_igemm_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= a.M) continue;
-                float v = acc[i][j][r] + bv;
+                float v = (tot[i][j][r] + acc[i][j][r]) + bv;
                 if (a.act == 1) v = tanhf(v);
                 if (a.out_nchw) {
                     const int img = m / hw;

@@ -124,6 +124,7 @@ struct ConvLayer {
 };
 
 constexpr int BK = 16;
+constexpr int FLUSH = 4;   // fold the MFMA chain every FLUSH*BK = 64 products (conv_igemm.hpp)
 
 inline int conv_kpad(int ks, int cin_pad) { return round_up(ks * ks * cin_pad, BK); }
 inline int conv_npad(int cout) { return cout >= 128 ? round_up(cout, 128) : round_up(cout, 32); }
@@ -141,7 +142,7 @@ template <int KS, int BM, int BN, int WM_, int WN_>
 void launch_conv_t(const ConvArgs& a, hipStream_t s) {
     constexpr int KQ = BK / 4, PAD = 8 / KQ;
     const size_t lds = (size_t)2 * KQ * ((BM + PAD) + (BN + PAD)) * 16;
-    hipLaunchKernelGGL((conv_igemm_kernel<KS, BM, BN, BK, WM_, WN_>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, BM, BN, BK, WM_, WN_, FLUSH>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
 }
 
 template <int KS>
