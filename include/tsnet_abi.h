@@ -150,6 +150,12 @@ int tsnet_op_flow(const float* tar_fea, const float* src_fea, const float* tar_b
 int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, int C, float* out, void* stream);
 const char* tsnet_op_last_error(void);
 
+/* Micro-benchmark of one convolution shape on synthetic (non-zero) data: average milliseconds per
+ * launch over `iters` back-to-back launches, hipEvent-timed on `stream`.  variant: -1 = the engine's
+ * own tile heuristic, else tile index + 8*(BK==32) (tools/conv_sweep.py).  Diagnostic only. */
+int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int pad_mode, int norm,
+                     int variant, int iters, float* ms_out, void* stream);
+
 /* Host-side constant tables, exported so CPU tests can pin them against torch:
  * tsnet_linspace <- torch.linspace(-1,1,n) as used by get_grid (TSNet.py:301-302);
  * tsnet_coord_table <- Encoder.coord_conv channels (xx,yy,rr) at (H,W), layout (H,W,3) (TSNet.py:107-122). */

@@ -8,13 +8,19 @@ import op_cases as oc
 TOL = 2e-5
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
-def test_conv_tiles(emu_lib, tile, monkeypatch):
-    # the tile override is read once per process: exercise it through a subprocess-free path by
-    # using shapes whose natural choice is that tile
-    shapes = {0: (1, 32, 32, 16, 256), 1: (1, 32, 32, 16, 64), 2: (2, 9, 7, 16, 40), 3: (1, 16, 16, 8, 3)}
-    N, H, W, Cin, Cout = shapes[tile]
-    assert oc.conv_case(emu_lib, "cpu", N, H, W, Cin, Cout, 3, 1, 1, True, norm=True) < TOL
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("bk32", [0, 1])
+def test_conv_tiles(emu_lib, tile, bk32, monkeypatch):
+    """every (tile, BK) instantiation of the implicit-GEMM kernel, forced through the tuning hook"""
+    monkeypatch.setenv("TSNET_CONV_TILE", str(tile))
+    monkeypatch.setenv("TSNET_CONV_BK32", str(bk32))
+    assert oc.conv_case(emu_lib, "cpu", 2, 11, 13, 16, 256, 3, 1, 1, True, norm=True) < TOL
+    assert oc.conv_case(emu_lib, "cpu", 1, 20, 13, 32, 128, 3, 2, 1, False) < TOL
+    assert oc.conv_case(emu_lib, "cpu", 1, 9, 9, 8, 128, 7, 1, 3, True) < TOL
+
+
+def test_conv_dual_source_forward_is_covered_by_test_emu_forward():
+    pass
 
 
 @pytest.mark.parametrize("k,stride,pad,reflect", [(7, 1, 3, True), (3, 2, 1, False), (3, 1, 1, True), (1, 1, 0, False)])

@@ -1,0 +1,46 @@
+"""GPU-box diagnostic: time every conv shape of the cfg0 forward under every tile variant.
+usage: conv_sweep.py [quick]   -> prints one line per (layer, variant): ms, TFLOP/s (real FLOPs)."""
+import ctypes as C, sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wacv23_tsnet_amd import _lib
+lib = _lib.load()
+torch.zeros(1, device="cuda")
+#        name       N   H    W   Cin  Cout k s p refl norm
+LAYERS = [
+    ("stem_img",   12, 256, 256,   8,   64, 7, 1, 3, 1, 0),
+    ("down1",      12, 256, 256,  64,  128, 3, 2, 1, 0, 1),
+    ("down2",      12, 128, 128, 128,  256, 3, 2, 1, 0, 1),
+    ("down3",      12,  64,  64, 256,  512, 3, 2, 1, 0, 1),
+    ("res_c1",     12,  32,  32, 512,  512, 3, 1, 1, 1, 0),
+    ("res_c2",     12,  32,  32, 512,  512, 3, 1, 1, 1, 1),
+    ("fuse_c2",    12,  32,  32, 1024, 1024, 3, 1, 1, 1, 1),
+    ("fuse_1x1",    4,  32,  32, 1024, 512, 1, 1, 0, 0, 0),
+    ("dec_up0",     4,  64,  64, 512,  256, 3, 1, 1, 1, 0),
+    ("dec_up1",     4, 128, 128, 256,  128, 3, 1, 1, 1, 0),
+    ("dec_up2",     4, 256, 256, 128,   64, 3, 1, 1, 1, 0),
+    ("head",        4, 256, 256,  64,    3, 7, 1, 3, 1, 1),
+    ("lbl_stem",    4, 256, 256,   8,   64, 7, 1, 3, 1, 0),
+    ("lbl_down3",   4,  64,  64, 256,  512, 3, 2, 1, 0, 1),
+]
+TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (96, 128)}
+quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
+    npad = (Cout + 127) // 128 * 128 if Cout >= 128 else (Cout + 31) // 32 * 32
+    res = []
+    for v in list(range(5)) + [8 + t for t in range(5)] + [-1]:
+        if v >= 0 and (npad % TILES[v & 7][1] or (TILES[v & 7][1] > 32 and Cout <= TILES[v & 7][1] // 2)):
+            continue
+        if quick and v >= 8:
+            continue
+        ms = C.c_float()
+        iters = 5 if flops > 5e10 else 10
+        rc = lib.tsnet_bench_conv(N, H, W, Cin, Cout, k, s, p, refl, norm, v, iters, C.byref(ms), None)
+        if rc != 0:
+            print(name, v, "ERR", lib.tsnet_op_last_error().decode()); continue
+        res.append((v, ms.value, flops / ms.value / 1e9))
+    best = max(r[2] for r in res if r[0] >= 0)
+    print(f"{name:10s} M={N*Ho*Wo:7d} N={Cout:5d} K={Cin*k*k:5d} GF={flops/1e9:7.1f} | " +
+          " ".join(f"{('h' if v < 0 else ('t%d%s' % (v & 7, 'k32' if v & 8 else '')))}:{ms:.3f}ms/{tf:.0f}TF{'*' if tf == best else ''}" for v, ms, tf in res), flush=True)

@@ -19,7 +19,8 @@ OUT = os.path.join(HERE, "lib", "libtsnet_hip.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
          "-fhip-fp32-correctly-rounded-divide-sqrt",   # IEEE / and sqrt: the /255, F.normalize and softmax divisions
-         "-ffp-contract=off"]                           # FMAs only where the source asks for them (fmaf)
+         "-ffp-contract=off",                           # FMAs only where the source asks for them (fmaf)
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]            # MFMA C/D in VGPRs: no AGPR<->VGPR copies around the K loop
 
 
 def up_to_date() -> bool:

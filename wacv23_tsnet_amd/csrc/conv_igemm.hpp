@@ -64,11 +64,10 @@ void conv_igemm_kernel(ConvArgs a) {
     constexpr int KQ = BK / 4;                 // float4 units along K per chunk
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 32, NTL = WN / 32;
-    constexpr int UA = BM * KQ / NT;           // A units per thread
+    constexpr int UA = (BM * KQ + NT - 1) / NT;  // A units per thread (last one predicated when BM*KQ % NT != 0)
     constexpr int UB = (BN * KQ + NT - 1) / NT;  // B units per thread (last one predicated when BN*KQ < NT)
     constexpr int RSTEP = NT / KQ;             // row step between a thread's A units
     static_assert(BM % (32 * WARPS_M) == 0 && BN % (32 * WARPS_N) == 0, "tile/wave mismatch");
-    static_assert((BM * KQ) % NT == 0, "loader mismatch");
     constexpr int PAD = 8 / KQ;                // row pad (in float4) that keeps ds_write_b128 8-lane groups on distinct slots
     constexpr int LDA = BM + PAD, LDB = BN + PAD;  // float4 row pitch
 
@@ -95,34 +94,43 @@ void conv_igemm_kernel(ConvArgs a) {
 
     // ---- per-thread A-unit geometry (fixed over the K loop)
     const int ak4 = tid % KQ;
-    int a_img[UA], a_oy[UA], a_ox[UA];
+    int a_img[UA], a_img2[UA], a_oy[UA], a_ox[UA];
     bool a_rowok[UA];
 #pragma unroll
     for (int j = 0; j < UA; ++j) {
         const int row = tid / KQ + j * RSTEP;
         const int m = m0 + row;
-        a_rowok[j] = m < a.M;
+        a_rowok[j] = m < a.M && row < BM;
         const int mm = a_rowok[j] ? m : 0;
         const int hw = a.Ho * a.Wo;
         const int img = mm / hw;
         const int rem = mm - img * hw;
         const int oy = rem / a.Wo;
         a_img[j] = img;
+        a_img2[j] = img % a.x2_nmod;
         a_oy[j] = oy * a.stride - a.pad;
         a_ox[j] = (rem - oy * a.Wo) * a.stride - a.pad;
     }
     const int C2 = a.Cin - a.Csplit;
+    const bool has_norm = a.in_alpha != nullptr;
 
     F4 ra[UA], rb[UB], ral[UA], rbe[UA];
     bool rok[UA];
 
+    // Loads are unconditional (out-of-range units read a clamped, valid address and are zeroed at
+    // store time) so the K loop stays one basic block and the accumulators never leave their
+    // registers; the only branches are wave-uniform (source select, has_norm).
     auto load_chunk = [&](int kc) {
-        // A: im2col-free gather
         const int k = kc * BK + ak4 * 4;
         const int tap = k >> a.cin_log2;
         const int c = k & (a.Cin - 1);
         const int ky = tap / KS, kx = tap - ky * KS;
         const bool tapok = tap < a.taps;
+        // a chunk never straddles the channel split (Csplit is a multiple of BK whenever x2 is set)
+        const bool second = ((kc * BK) & (a.Cin - 1)) >= a.Csplit;
+        const float* src = second ? a.x2 : a.x;
+        const int cs = second ? C2 : a.Csplit;
+        const int coff = second ? c - a.Csplit : c;
 #pragma unroll
         for (int j = 0; j < UA; ++j) {
             int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
@@ -135,21 +143,15 @@ void conv_igemm_kernel(ConvArgs a) {
             } else {
                 ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             }
+            iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);     // clamp: keeps padded-K / ragged-M loads in bounds
+            ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
             rok[j] = ok;
-            F4 v = {{0.f, 0.f, 0.f, 0.f}};
-            if (ok) {
-                if (c < a.Csplit) {
-                    v = ld4(a.x + ((size_t)((a_img[j] * a.H + iy) * a.W + ix)) * a.Csplit + c);
-                } else {
-                    const int n2 = a_img[j] % a.x2_nmod;
-                    v = ld4(a.x2 + ((size_t)((n2 * a.H + iy) * a.W + ix)) * C2 + (c - a.Csplit));
-                }
-                if (a.in_alpha) {
-                    ral[j] = ld4(a.in_alpha + a_img[j] * a.Cin + c);
-                    rbe[j] = ld4(a.in_beta + a_img[j] * a.Cin + c);
-                }
+            const int img = second ? a_img2[j] : a_img[j];
+            ra[j] = ld4(src + ((size_t)((img * a.H + iy) * a.W + ix)) * cs + coff);
+            if (has_norm) {
+                ral[j] = ld4(a.in_alpha + a_img[j] * a.Cin + c);
+                rbe[j] = ld4(a.in_beta + a_img[j] * a.Cin + c);
             }
-            ra[j] = v;
         }
         // B: packed weights, fully coalesced
 #pragma unroll
@@ -168,14 +170,16 @@ void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < UA; ++j) {
             F4 v = ra[j];
-            if (a.in_alpha && rok[j]) {
+            if (has_norm) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = __builtin_fmaf(v.v[e], ral[j].v[e], rbe[j].v[e]);
                     v.v[e] = a.in_relu ? (t > 0.f ? t : 0.f) : t;
                 }
             }
-            dA[ak4 * LDA + tid / KQ + j * RSTEP] = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = rok[j] ? v.v[e] : 0.f;
+            if ((BM * KQ) % NT == 0 || tid / KQ + j * RSTEP < BM) dA[ak4 * LDA + tid / KQ + j * RSTEP] = v;
         }
 #pragma unroll
         for (int j = 0; j < UB; ++j) {

@@ -123,10 +123,10 @@ struct ConvLayer {
     const float* bias = nullptr;  // device (cout)
 };
 
-constexpr int BK = 16;
-constexpr int FLUSH = 4;   // fold the MFMA chain every FLUSH*BK = 64 products (conv_igemm.hpp)
+constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded so both BK=16 and BK=32 kernels can stream them
+constexpr int FLUSH_K = 64;      // fold the MFMA chain into the running total every 64 products (conv_igemm.hpp)
 
-inline int conv_kpad(int ks, int cin_pad) { return round_up(ks * ks * cin_pad, BK); }
+inline int conv_kpad(int ks, int cin_pad) { return round_up(ks * ks * cin_pad, KPAD_ALIGN); }
 inline int conv_npad(int cout) { return cout >= 128 ? round_up(cout, 128) : round_up(cout, 32); }
 
 struct ConvCall {
@@ -136,42 +136,69 @@ struct ConvCall {
     const float* alpha = nullptr; const float* beta = nullptr; int in_relu = 0;
     float* y = nullptr; int act = 0; int out_nchw = 0;
     int composite = 0; float bg[3] = {0, 0, 0};
+    int variant = -1;      // -1 = heuristic; else tile index + 8*(BK==32)   (bench / test hook)
 };
 
-template <int KS, int BM, int BN, int WM_, int WN_>
+struct TileCfg { int bm, bn, wm, wn; double eff; };
+// eff: relative per-tile efficiency used by the selection heuristic (measured)
+const TileCfg kTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 4, 1, 0.7}, {96, 128, 1, 4, 0.97}};
+constexpr int kNumTiles = 5;
+
+template <int KS, int BM, int BN, int BK_, int WM_, int WN_>
 void launch_conv_t(const ConvArgs& a, hipStream_t s) {
-    constexpr int KQ = BK / 4, PAD = 8 / KQ;
+    constexpr int KQ = BK_ / 4, PAD = 8 / KQ;
     const size_t lds = (size_t)2 * KQ * ((BM + PAD) + (BN + PAD)) * 16;
-    hipLaunchKernelGGL((conv_igemm_kernel<KS, BM, BN, BK, WM_, WN_, FLUSH>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
+    auto kern = conv_igemm_kernel<KS, BM, BN, BK_, WM_, WN_, FLUSH_K / BK_>;
+    if (lds > 48 * 1024) {
+        static bool done = false;   // per instantiation
+        if (!done) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
 }
 
-template <int KS>
-void launch_conv_ks(const ConvArgs& a0, hipStream_t s) {
-    ConvArgs a = a0;
-    // tile choice: minimise (sequential tiles per CU) x (tile area), smaller tiles slightly penalised
-    struct Cand { int bm, bn; double eff; };
-    const Cand cands[] = {{128, 128, 1.0}, {128, 64, 0.95}, {64, 64, 0.85}, {128, 32, 0.8}};
+template <int KS, int BK_>
+void launch_conv_tile(const ConvArgs& a, int tile, hipStream_t s) {
+    switch (tile) {
+        case 0: launch_conv_t<KS, 128, 128, BK_, 2, 2>(a, s); break;
+        case 1: launch_conv_t<KS, 128, 64, BK_, 2, 2>(a, s); break;
+        case 2: launch_conv_t<KS, 64, 64, BK_, 2, 2>(a, s); break;
+        case 3: launch_conv_t<KS, 128, 32, BK_, 4, 1>(a, s); break;
+        default: launch_conv_t<KS, 96, 128, BK_, 1, 4>(a, s); break;
+    }
+}
+
+// Tile choice: minimise (sequential tiles per CU) x (tile area) / efficiency.  The 256 CUs each run
+// ceil(tiles/256) tiles back to back (co-resident blocks share the MFMA pipe, so residency does not
+// change this count), which makes tile-count quantisation the first-order term at B=4.
+int choose_variant(const ConvArgs& a, int forced) {
+    const char* e_tile = getenv("TSNET_CONV_TILE");   // test / tuning hooks
+    const char* e_bk32 = getenv("TSNET_CONV_BK32");
+    const int env_tile = e_tile ? atoi(e_tile) : -1, env_bk32 = e_bk32 ? atoi(e_bk32) : 0;
+    if (forced >= 0) return forced;
     int best = -1; double best_cost = 0;
-    static const int forced = [] { const char* e = getenv("TSNET_CONV_TILE"); return e ? atoi(e) : -1; }();   // test hook
-    for (int i = 0; i < 4; ++i) {
-        if (a.Npad % cands[i].bn) continue;
-        if (forced >= 0 && forced < 4 && a.Npad % cands[forced].bn == 0) { best = forced; break; }
-        if (cands[i].bn > 32 && a.Cout <= cands[i].bn / 2) continue;   // don't waste half the columns
-        const long tm = (a.M + cands[i].bm - 1) / cands[i].bm, tn = (a.Cout + cands[i].bn - 1) / cands[i].bn;
+    for (int i = 0; i < kNumTiles; ++i) {
+        if (a.Npad % kTiles[i].bn) continue;
+        if (env_tile >= 0 && env_tile < kNumTiles && a.Npad % kTiles[env_tile].bn == 0) { best = env_tile; break; }
+        if (kTiles[i].bn > 32 && a.Cout <= kTiles[i].bn / 2) continue;   // don't waste half the columns
+        const long tm = (a.M + kTiles[i].bm - 1) / kTiles[i].bm, tn = (a.Cout + kTiles[i].bn - 1) / kTiles[i].bn;
         const long seq = (tm * tn + 255) / 256;
-        const double cost = (double)seq * cands[i].bm * cands[i].bn / cands[i].eff;
+        const double cost = (double)seq * kTiles[i].bm * kTiles[i].bn / kTiles[i].eff;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
     }
     if (best < 0) throw std::runtime_error("conv: no tile configuration for Npad");
-    const int bm = cands[best].bm, bn = cands[best].bn;
-    a.tiles_m = (a.M + bm - 1) / bm;
-    a.tiles_n = (a.Cout + bn - 1) / bn;
-    switch (best) {
-        case 0: launch_conv_t<KS, 128, 128, 2, 2>(a, s); break;
-        case 1: launch_conv_t<KS, 128, 64, 2, 2>(a, s); break;
-        case 2: launch_conv_t<KS, 64, 64, 2, 2>(a, s); break;
-        default: launch_conv_t<KS, 128, 32, 4, 1>(a, s); break;
-    }
+    return best + (env_bk32 ? 8 : 0);
+}
+
+template <int KS>
+void launch_conv_ks(const ConvArgs& a0, int forced, hipStream_t s) {
+    ConvArgs a = a0;
+    const int v = choose_variant(a, forced);
+    const int tile = v & 7, bk = (v & 8) ? 32 : 16;
+    if (tile >= kNumTiles || a.Npad % kTiles[tile].bn) throw ArgError("conv: tile variant does not divide the padded width");
+    a.tiles_m = (a.M + kTiles[tile].bm - 1) / kTiles[tile].bm;
+    a.tiles_n = (a.Cout + kTiles[tile].bn - 1) / kTiles[tile].bn;
+    a.nchunks = (a.taps * a.Cin + bk - 1) / bk;
+    if (bk == 32) launch_conv_tile<KS, 32>(a, tile, s); else launch_conv_tile<KS, 16>(a, tile, s);
 }
 
 void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
@@ -184,7 +211,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
     a.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
     a.Cout = L.cout; a.Npad = L.npad;
     a.stride = L.stride; a.pad = L.pad; a.reflect = L.reflect;
-    a.taps = L.ks * L.ks; a.nchunks = L.kpad / BK;
+    a.taps = L.ks * L.ks; a.nchunks = 0;   // set per BK in launch_conv_ks
     a.M = c.N * a.Ho * a.Wo;
     a.in_relu = c.in_relu; a.act = c.act; a.out_nchw = c.out_nchw;
     a.composite = c.composite; a.fore_x0 = 64; a.fore_x1 = 192;   // TSNet_pose.py:279
@@ -195,9 +222,9 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         throw ArgError("conv: tensor exceeds 2^31 elements");
     TimeScope ts(ctx, TSNET_T_CONV);
     switch (L.ks) {
-        case 1: launch_conv_ks<1>(a, ctx.stream); break;
-        case 3: launch_conv_ks<3>(a, ctx.stream); break;
-        case 7: launch_conv_ks<7>(a, ctx.stream); break;
+        case 1: launch_conv_ks<1>(a, c.variant, ctx.stream); break;
+        case 3: launch_conv_ks<3>(a, c.variant, ctx.stream); break;
+        case 7: launch_conv_ks<7>(a, c.variant, ctx.stream); break;
         default: throw ArgError("conv: kernel size must be 1, 3 or 7");
     }
     check_launch("conv_igemm");
@@ -914,6 +941,45 @@ int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, 
     if (C & 3) throw ArgError("warp op: C must be a multiple of 4");
     Ctx ctx; ctx.stream = (hipStream_t)stream;
     run_warp(ctx, src_fea, flow, out, B, 1, h, w, C);
+    OP_END
+}
+
+int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int pad_mode, int norm,
+                     int variant, int iters, float* ms_out, void* stream) {
+    OP_BEGIN
+    if (Cin < 4 || (Cin & (Cin - 1)) || iters < 1 || !ms_out) throw ArgError("bench_conv: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    Ctx ctx; ctx.stream = s;
+    ConvLayer L; L.name = "bench"; L.cin_real = Cin; L.cin_pad = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
+    L.reflect = pad_mode; L.kpad = conv_kpad(ksize, Cin); L.npad = conv_npad(Cout);
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const size_t xn = (size_t)N * H * W * Cin, yn = (size_t)N * Ho * Wo * Cout, wn = (size_t)L.kpad * L.npad;
+    float *x = nullptr, *y = nullptr, *w = nullptr, *al = nullptr, *be = nullptr;
+    HIP_TRY(hipMalloc((void**)&x, xn * 4)); HIP_TRY(hipMalloc((void**)&y, yn * 4)); HIP_TRY(hipMalloc((void**)&w, wn * 4));
+    HIP_TRY(hipMalloc((void**)&al, (size_t)N * Cin * 4)); HIP_TRY(hipMalloc((void**)&be, (size_t)N * Cin * 4));
+    // pseudo-random fill (not zeros: MI355X clocks higher on zero operands, cdna_hip_programming.md rule 25)
+    std::vector<float> hbuf(std::max(std::max(xn, wn), (size_t)N * Cin));
+    unsigned st = 12345u;
+    auto fill = [&](float* d, size_t n, float scale, float off) {
+        for (size_t i = 0; i < n; ++i) { st = st * 1664525u + 1013904223u; hbuf[i] = off + scale * ((float)(st >> 8) / 16777216.0f - 0.5f); }
+        HIP_TRY(hipMemcpy(d, hbuf.data(), n * 4, hipMemcpyHostToDevice));
+    };
+    fill(x, xn, 2.f, 0.f); fill(w, wn, 0.1f, 0.f); fill(al, (size_t)N * Cin, 1.f, 1.f); fill(be, (size_t)N * Cin, 0.5f, 0.f);
+    L.w = w; L.bias = nullptr;
+    ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.variant = variant;
+    if (norm) { c.alpha = al; c.beta = be; c.in_relu = 1; }
+    for (int i = 0; i < 2; ++i) run_conv(ctx, L, c);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) run_conv(ctx, L, c);
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(al); (void)hipFree(be);
     OP_END
 }
 
