@@ -156,6 +156,10 @@ const char* tsnet_op_last_error(void);
 int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int pad_mode, int norm,
                      int variant, int iters, float* ms_out, void* stream);
 
+/* Launch counters since the last reset: out[0] = LDS-DMA conv launches (conv_glds_kernel),
+ * out[1] = register-staged conv launches (conv_igemm_kernel); out[2..3] reserved.  Diagnostic. */
+void tsnet_debug_counters(int64_t out[4], int reset);
+
 /* Host-side constant tables, exported so CPU tests can pin them against torch:
  * tsnet_linspace <- torch.linspace(-1,1,n) as used by get_grid (TSNet.py:301-302);
  * tsnet_coord_table <- Encoder.coord_conv channels (xx,yy,rr) at (H,W), layout (H,W,3) (TSNet.py:107-122). */

@@ -51,7 +51,7 @@ const char* g_error = nullptr;
 // block barrier
 int g_bar_count = 0; unsigned g_bar_gen = 0;
 // wave rendezvous
-struct WaveState { int count = 0; unsigned gen = 0; float a[2][64], b[2][64]; int alive = 0; };
+struct WaveState { int count = 0; unsigned gen = 0; float a[2][64], b[2][64]; const void* gp[2][64]; void* lp[2][64]; int alive = 0; };
 std::vector<WaveState> g_waves;
 
 void yield() { emu_switch(&g_fibers[g_cur].sp, g_sched_sp); }
@@ -111,6 +111,17 @@ f32x16_t mfma_32x32x2(float a, float b, f32x16_t c) {
         d[r] = t;
     }
     return d;
+}
+
+void global_load_lds(const void* g, void* lds, int size) {
+    WaveState& w = g_waves[g_cur / 64];
+    const int lane = g_cur & 63, par = w.gen & 1;
+    w.gp[par][lane] = g;
+    w.lp[par][lane] = lds;
+    if (w.alive != 64) throw std::runtime_error("emu: global_load_lds needs a full, converged wave");
+    wave_rendezvous(w);
+    // every lane copies its own element to (lane 0's LDS pointer) + lane*size
+    memcpy(static_cast<unsigned char*>(w.lp[par][0]) + (size_t)lane * size, w.gp[par][lane], size);
 }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {

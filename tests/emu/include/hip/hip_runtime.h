@@ -48,6 +48,7 @@ void syncthreads();
 float shfl_xor(float v, int mask);
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 f32x16_t mfma_32x32x2(float a, float b, f32x16_t c);
+void global_load_lds(const void* g, void* lds, int size);
 }  // namespace emu
 
 #define threadIdx (emu::g_threadIdx)
@@ -60,6 +61,15 @@ f32x16_t mfma_32x32x2(float a, float b, f32x16_t c);
 static inline void __syncthreads() { emu::syncthreads(); }
 static inline float __shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
+// LDS-DMA: destination = the wave's FIRST lane's LDS pointer + lane*size (the per-lane pointers of the
+// other lanes are ignored, exactly the hardware's M0 semantics), source address per lane.
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::global_load_lds((const void*)(g), (void*)(l), (size))
+// the one hook the kernels expose for their inline-asm LDS-DMA (conv_glds.hpp)
+#define TSNET_GLDS16(g, lds) emu::global_load_lds((const void*)(g), (void*)(lds), 16)
+#define TSNET_LDS_ADDR(p) (p)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() emu::syncthreads()
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 
 static inline const char* hipGetErrorString(hipError_t) { return "emu error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
@@ -68,6 +78,7 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/tsnet_abi.h"
+#include "conv_glds.hpp"
 #include "conv_igemm.hpp"
 #include "flow_warp.hpp"
 #include "norm_elementwise.hpp"
@@ -36,6 +37,7 @@ using namespace tsnet;
 namespace {
 
 thread_local std::string g_op_error;
+int64_t g_launch_counters[4] = {0, 0, 0, 0};   // [0] LDS-DMA conv launches, [1] register-staged conv launches
 std::string g_create_error;
 
 #define HIP_TRY(expr)                                                                               \
@@ -118,8 +120,9 @@ struct ConvLayer {
     std::string name;       // state_dict prefix, e.g. "img_enc.model.1"
     int cin_real = 0, cin_pad = 0, cout = 0, ks = 1, stride = 1, pad = 0, reflect = 0;
     int kpad = 0, npad = 0;
-    size_t w_off = 0, b_off = 0;  // offsets (floats) into the packed buffer
-    const float* w = nullptr;     // device, packed
+    size_t w_off = 0, w2_off = 0, b_off = 0;  // offsets (floats) into the packed buffer
+    const float* w = nullptr;     // device, packed for conv_igemm_kernel  [K/4][Npad][4]
+    const float* w2 = nullptr;    // device, packed for conv_glds_kernel   [K/16][Npad][4 swizzled quads][4]
     const float* bias = nullptr;  // device (cout)
 };
 
@@ -153,6 +156,15 @@ void launch_conv_t(const ConvArgs& a, hipStream_t s) {
         static bool done = false;   // per instantiation
         if (!done) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
     }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
+}
+
+template <int BM, int BN, int BK_, int WM_, int WN_, int ABL>
+void launch_conv_abl(const ConvArgs& a, hipStream_t s) {     // 3x3 only, diagnostic
+    constexpr int KQ = BK_ / 4, PAD = 8 / KQ;
+    const size_t lds = (size_t)2 * KQ * ((BM + PAD) + (BN + PAD)) * 16;
+    auto kern = conv_igemm_kernel<3, BM, BN, BK_, WM_, WN_, FLUSH_K / BK_, ABL>;
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
 }
 
@@ -193,15 +205,110 @@ template <int KS>
 void launch_conv_ks(const ConvArgs& a0, int forced, hipStream_t s) {
     ConvArgs a = a0;
     const int v = choose_variant(a, forced);
-    const int tile = v & 7, bk = (v & 8) ? 32 : 16;
+    const int tile = v & 7, bk = (v & 8) ? 32 : 16, abl = (v >> 4) & 3;
     if (tile >= kNumTiles || a.Npad % kTiles[tile].bn) throw ArgError("conv: tile variant does not divide the padded width");
     a.tiles_m = (a.M + kTiles[tile].bm - 1) / kTiles[tile].bm;
     a.tiles_n = (a.Cout + kTiles[tile].bn - 1) / kTiles[tile].bn;
     a.nchunks = (a.taps * a.Cin + bk - 1) / bk;
+    if (abl && KS == 3) {
+        if (tile == 0 && bk == 16) { if (abl == 1) launch_conv_abl<128, 128, 16, 2, 2, 1>(a, s); else launch_conv_abl<128, 128, 16, 2, 2, 2>(a, s); return; }
+        if (tile == 4 && bk == 32) { if (abl == 1) launch_conv_abl<96, 128, 32, 1, 4, 1>(a, s); else launch_conv_abl<96, 128, 32, 1, 4, 2>(a, s); return; }
+        throw ArgError("conv: ablation variants exist for (tile0,BK16) and (tile4,BK32) only");
+    }
     if (bk == 32) launch_conv_tile<KS, 32>(a, tile, s); else launch_conv_tile<KS, 16>(a, tile, s);
 }
 
+// ---- LDS-DMA kernel (conv_glds.hpp): tiles whose A and B images split into whole wave DMAs
+struct GTileCfg { int bm, bn, wm, wn; double eff; };
+const GTileCfg kGTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 2, 1, 0.7}};
+constexpr int kNumGTiles = 4;
+
+const float* zero_page() {
+    static float* zp = nullptr;
+    if (!zp) {
+        HIP_TRY(hipMalloc((void**)&zp, 256));
+        HIP_TRY(hipMemset(zp, 0, 256));
+    }
+    return zp;
+}
+
+template <int KS, int BM, int BN, int WM_, int WN_>
+void launch_glds_t(const GldsArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)4 * (BM + BN) * 4 * 16;     // NSTAGE x (A + B image)
+    auto kern = conv_glds_kernel<KS, BM, BN, WM_, WN_, FLUSH_K / 16>;
+    if (lds > 48 * 1024) {
+        static bool done = false;
+        if (!done) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
+}
+
+template <int KS>
+void launch_glds_ks(GldsArgs a, int forced_tile, hipStream_t s) {
+    int best = forced_tile;
+    if (best < 0) {
+        const char* e_tile = getenv("TSNET_GLDS_TILE");
+        const int env_tile = e_tile ? atoi(e_tile) : -1;
+        double best_cost = 0;
+        for (int i = 0; i < kNumGTiles; ++i) {
+            if (a.Npad % kGTiles[i].bn) continue;
+            if (env_tile >= 0 && env_tile < kNumGTiles && a.Npad % kGTiles[env_tile].bn == 0) { best = env_tile; break; }
+            if (kGTiles[i].bn > 32 && a.Cout <= kGTiles[i].bn / 2) continue;
+            const long tm = (a.M + kGTiles[i].bm - 1) / kGTiles[i].bm, tn = (a.Cout + kGTiles[i].bn - 1) / kGTiles[i].bn;
+            const long seq = (tm * tn + 255) / 256;
+            const double cost = (double)seq * kGTiles[i].bm * kGTiles[i].bn / kGTiles[i].eff;
+            if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+        }
+    }
+    if (best < 0 || best >= kNumGTiles || a.Npad % kGTiles[best].bn) throw ArgError("conv(glds): no tile configuration");
+    a.tiles_m = (a.M + kGTiles[best].bm - 1) / kGTiles[best].bm;
+    a.tiles_n = (a.Cout + kGTiles[best].bn - 1) / kGTiles[best].bn;
+    switch (best) {
+        case 0: launch_glds_t<KS, 128, 128, 2, 2>(a, s); break;
+        case 1: launch_glds_t<KS, 128, 64, 2, 2>(a, s); break;
+        case 2: launch_glds_t<KS, 64, 64, 2, 2>(a, s); break;
+        default: launch_glds_t<KS, 128, 32, 2, 1>(a, s); break;
+    }
+}
+
+bool use_glds_path(const ConvLayer& L, const ConvCall& c) {
+    if (c.alpha || !L.w2) return false;                 // the DMA cannot apply the IN+ReLU transform
+    if (c.variant >= 0) return (c.variant & 64) != 0;   // bench / test hook
+    const char* e = getenv("TSNET_CONV_LEGACY");
+    return !(e && atoi(e));
+}
+
 void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
+    if (use_glds_path(L, c)) {
+        GldsArgs g{};
+        g.x = c.x; g.x2 = c.x2; g.zero_page = zero_page(); g.w = L.w2; g.bias = L.bias; g.y = c.y;
+        g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
+        g.Csplit = c.x2 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
+        g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
+        g.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
+        g.Cout = L.cout; g.Npad = L.npad;
+        g.stride = L.stride; g.pad = L.pad; g.reflect = L.reflect;
+        g.taps = L.ks * L.ks; g.nchunks = (g.taps * g.Cin + 15) / 16;
+        g.M = c.N * g.Ho * g.Wo;
+        g.act = c.act; g.out_nchw = c.out_nchw;
+        g.composite = c.composite; g.fore_x0 = 64; g.fore_x1 = 192;
+        g.bg[0] = c.bg[0]; g.bg[1] = c.bg[1]; g.bg[2] = c.bg[2];
+        if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
+        if ((g.Csplit & 15) && c.x2) throw ArgError("conv(glds): channel split must be a multiple of 16");
+        if ((double)c.N * c.H * c.W * L.cin_pad >= 2147483647.0 || (double)g.M * L.cout >= 2147483647.0)
+            throw ArgError("conv: tensor exceeds 2^31 elements");
+        TimeScope ts(ctx, TSNET_T_CONV);
+        const int forced = c.variant >= 0 ? (c.variant & 7) : -1;
+        switch (L.ks) {
+            case 1: launch_glds_ks<1>(g, forced, ctx.stream); break;
+            case 3: launch_glds_ks<3>(g, forced, ctx.stream); break;
+            case 7: launch_glds_ks<7>(g, forced, ctx.stream); break;
+            default: throw ArgError("conv: kernel size must be 1, 3 or 7");
+        }
+        check_launch("conv_glds");
+        ++g_launch_counters[0];
+        return;
+    }
     ConvArgs a{};
     a.x = c.x; a.x2 = c.x2; a.in_alpha = c.alpha; a.in_beta = c.beta;
     a.w = L.w; a.bias = L.bias; a.y = c.y;
@@ -228,6 +335,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         default: throw ArgError("conv: kernel size must be 1, 3 or 7");
     }
     check_launch("conv_igemm");
+    ++g_launch_counters[1];
 }
 
 // InstanceNorm statistics -> (alpha, beta); `part` must hold N*64*C*2 doubles
@@ -289,11 +397,16 @@ void run_warp(Ctx& ctx, const float* src, const float* flow, float* out, int B, 
     check_launch("warp_mean");
 }
 
-void pack_layer_weights(const float* w_oihw_dev, float* out_dev, const ConvLayer& L, hipStream_t s) {
+void pack_layer_weights(const float* w_oihw_dev, float* out_dev, float* out2_dev, const ConvLayer& L, hipStream_t s) {
     const size_t total = (size_t)L.kpad * L.npad;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw_dev, out_dev,
                        L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad);
     check_launch("pack_weights");
+    if (out2_dev) {
+        hipLaunchKernelGGL(pack_weights_glds_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw_dev, out2_dev,
+                           L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad);
+        check_launch("pack_weights_glds");
+    }
 }
 
 // torch.linspace(-1, 1, n) in float32: step = (end-start)/(n-1); first half start+i*step, second half
@@ -387,6 +500,14 @@ struct tsnet_engine {
     void resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww);
     void set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B);
     void forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
+    // A conv whose input is ReLU(IN(raw)): materialise it in place (one HBM-bound pass; required by the
+    // LDS-DMA conv kernel, which cannot transform data in flight) or, on the legacy register-staged
+    // kernel (TSNET_CONV_LEGACY=1), apply it inside the loader.
+    bool fuse_norm_in_loader = false;
+    void norm_input(Ctx& ctx, float* raw, const float* alpha, const float* beta, int N, int HW, int Cc, ConvCall& call) {
+        if (fuse_norm_in_loader) { call.alpha = alpha; call.beta = beta; call.in_relu = 1; return; }
+        run_norm_act(ctx, raw, alpha, beta, 1, nullptr, N, HW, Cc, raw);
+    }
     std::pair<float*, float*> next_ab() { auto r = std::make_pair(ab[ab_rr][0], ab[ab_rr][1]); ab_rr = (ab_rr + 1) & 3; return r; }
 };
 
@@ -442,6 +563,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     size_t off = 0;
     for (ConvLayer* L : all_layers) {
         L->w_off = off; off += (size_t)L->kpad * L->npad;
+        L->w2_off = off; off += (size_t)L->kpad * L->npad;
         L->b_off = off; off += (size_t)round_up(L->cout, 4);
     }
     wpack_floats = off;
@@ -455,10 +577,11 @@ void tsnet_engine::alloc_all(hipStream_t s) {
         const Param& pw = params[pindex[L->name + ".weight"]];
         const Param& pb = params[pindex[L->name + ".bias"]];
         HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        pack_layer_weights(stage, wpack + L->w_off, *L, s);
+        pack_layer_weights(stage, wpack + L->w_off, wpack + L->w2_off, *L, s);
         HIP_TRY(hipMemcpyAsync(wpack + L->b_off, pb.host.data(), pb.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));   // host vectors / staging buffer reused next iteration
         L->w = wpack + L->w_off;
+        L->w2 = wpack + L->w2_off;
         L->bias = wpack + L->b_off;
     }
     HIP_TRY(hipFree(stage));
@@ -523,7 +646,8 @@ void tsnet_engine::resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, 
     run_conv(ctx, c1, a);
     auto s1 = next_ab();
     run_stats(ctx, y1, N, HW, Cc, part, s1.first, s1.second);
-    ConvCall b; b.x = y1; b.N = N; b.H = hh; b.W = ww; b.alpha = s1.first; b.beta = s1.second; b.in_relu = 1; b.y = y2;
+    ConvCall b; b.x = y1; b.N = N; b.H = hh; b.W = ww; b.y = y2;
+    norm_input(ctx, y1, s1.first, s1.second, N, HW, Cc, b);
     run_conv(ctx, c2, b);
     auto s2 = next_ab();
     run_stats(ctx, y2, N, HW, Cc, part, s2.first, s2.second);
@@ -539,7 +663,8 @@ void tsnet_engine::encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin,
     auto st = next_ab();
     run_stats(ctx, raw[0], N, hh * ww, L[0].cout, part, st.first, st.second);
     for (int l = 1; l <= cfg.n_downsampling; ++l) {
-        ConvCall d; d.x = raw[l - 1]; d.N = N; d.H = hh; d.W = ww; d.alpha = st.first; d.beta = st.second; d.in_relu = 1; d.y = raw[l];
+        ConvCall d; d.x = raw[l - 1]; d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
+        norm_input(ctx, raw[l - 1], st.first, st.second, N, hh * ww, L[l].cin_pad, d);
         run_conv(ctx, L[l], d);
         hh /= 2; ww /= 2;
         st = next_ab();
@@ -599,7 +724,8 @@ void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* t
         run_conv(ctx, fuse_c1, a);
         auto s1 = next_ab();
         run_stats(ctx, F1, NB, P, 2 * C, part, s1.first, s1.second);
-        ConvCall b; b.x = F1; b.N = NB; b.H = h; b.W = w; b.alpha = s1.first; b.beta = s1.second; b.in_relu = 1; b.y = F2;
+        ConvCall b; b.x = F1; b.N = NB; b.H = h; b.W = w; b.y = F2;
+        norm_input(ctx, F1, s1.first, s1.second, NB, P, 2 * C, b);
         run_conv(ctx, fuse_c2, b);
         auto s2 = next_ab();
         run_stats(ctx, F2, NB, P, 2 * C, part, s2.first, s2.second);
@@ -631,7 +757,8 @@ void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* t
         run_stats(ctx, R[i], B, hh * ww, cc, part, st.first, st.second);
         cur = R[i]; cal = st.first; cbe = st.second;
     }
-    ConvCall hd; hd.x = cur; hd.N = B; hd.H = hh; hd.W = ww; hd.alpha = cal; hd.beta = cbe; hd.in_relu = 1;
+    ConvCall hd; hd.x = cur; hd.N = B; hd.H = hh; hd.W = ww;
+    norm_input(ctx, R[cfg.n_downsampling - 1], cal, cbe, B, hh * ww, cc, hd);
     hd.y = out_rgb; hd.act = 1; hd.out_nchw = 1;
     if (cfg.pose_composite) {
         hd.composite = 1;
@@ -679,6 +806,7 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
         e->C = cfg->ngf << cfg->n_downsampling;
         e->h = cfg->height / ds; e->w = cfg->width / ds; e->P = e->h * e->w;
         e->build_layers();
+        { const char* lg = getenv("TSNET_CONV_LEGACY"); e->fuse_norm_in_loader = lg && atoi(lg); }
         *out = e;
     } catch (const std::exception& ex) { g_create_error = ex.what(); return TSNET_ERR_NOMEM; }
     return TSNET_OK;
@@ -862,20 +990,21 @@ int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w
     ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
     L.reflect = pad_mode; L.kpad = conv_kpad(ksize, Cin); L.npad = conv_npad(Cout);
     const size_t wn = (size_t)Cout * Cin * ksize * ksize;
-    float *wd = nullptr, *wp = nullptr, *bd = nullptr;
+    float *wd = nullptr, *wp = nullptr, *wp2 = nullptr, *bd = nullptr;
     HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&wp, (size_t)L.kpad * L.npad * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&wp2, (size_t)L.kpad * L.npad * sizeof(float)));
     HIP_TRY(hipMemcpy(wd, w_oihw, wn * sizeof(float), hipMemcpyDefault));
-    pack_layer_weights(wd, wp, L, s);
+    pack_layer_weights(wd, wp, wp2, L, s);
     if (bias) {
         HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
         HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
     }
-    L.w = wp; L.bias = bd;
+    L.w = wp; L.w2 = wp2; L.bias = bd;
     ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.alpha = in_alpha; c.beta = in_beta; c.in_relu = in_relu; c.y = y; c.act = act;
     run_conv(ctx, L, c);
     HIP_TRY(hipStreamSynchronize(s));
-    (void)hipFree(wd); (void)hipFree(wp); (void)hipFree(bd);
+    (void)hipFree(wd); (void)hipFree(wp); (void)hipFree(wp2); (void)hipFree(bd);
     OP_END
 }
 
@@ -955,6 +1084,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const size_t xn = (size_t)N * H * W * Cin, yn = (size_t)N * Ho * Wo * Cout, wn = (size_t)L.kpad * L.npad;
     float *x = nullptr, *y = nullptr, *w = nullptr, *al = nullptr, *be = nullptr;
+    if (norm && variant >= 0 && (variant & 64)) throw ArgError("bench_conv: the LDS-DMA kernel takes no input transform");
     HIP_TRY(hipMalloc((void**)&x, xn * 4)); HIP_TRY(hipMalloc((void**)&y, yn * 4)); HIP_TRY(hipMalloc((void**)&w, wn * 4));
     HIP_TRY(hipMalloc((void**)&al, (size_t)N * Cin * 4)); HIP_TRY(hipMalloc((void**)&be, (size_t)N * Cin * 4));
     // pseudo-random fill (not zeros: MI355X clocks higher on zero operands, cdna_hip_programming.md rule 25)
@@ -965,7 +1095,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
         HIP_TRY(hipMemcpy(d, hbuf.data(), n * 4, hipMemcpyHostToDevice));
     };
     fill(x, xn, 2.f, 0.f); fill(w, wn, 0.1f, 0.f); fill(al, (size_t)N * Cin, 1.f, 1.f); fill(be, (size_t)N * Cin, 0.5f, 0.f);
-    L.w = w; L.bias = nullptr;
+    L.w = w; L.w2 = w; L.bias = nullptr;   // timing only: both kernels stream the same random buffer
     ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.variant = variant;
     if (norm) { c.alpha = al; c.beta = be; c.in_relu = 1; }
     for (int i = 0; i < 2; ++i) run_conv(ctx, L, c);
@@ -981,6 +1111,10 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(al); (void)hipFree(be);
     OP_END
+}
+
+void tsnet_debug_counters(int64_t out[4], int reset) {
+    for (int i = 0; i < 4; ++i) { if (out) out[i] = g_launch_counters[i]; if (reset) g_launch_counters[i] = 0; }
 }
 
 void tsnet_linspace(int n, float* out) { linspace_pm1(n, out); }
