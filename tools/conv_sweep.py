@@ -24,15 +24,16 @@ LAYERS = [
     ("lbl_down3",   4,  64,  64, 256,  512, 3, 2, 1, 0, 1),
 ]
 TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (96, 128)}
-GT = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32)}
+WT = {0: (128, 128), 1: (128, 64), 2: (128, 128), 3: (64, 64)}
+GT = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (128, 128), 5: (128, 128)}
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
     npad = (Cout + 127) // 128 * 128 if Cout >= 128 else (Cout + 31) // 32 * 32
     res = []
-    for v in [0, 1, 4, 8 + 4, 64, 65, 66, 67]:
-        tl = GT if v & 64 else TILES
+    for v in ([64, 65, 192, 193, 194, 195] if quick else [0, 1, 4, 8 + 4, 64, 65, 66, 67, 192, 193, 194, 195]):
+        tl = WT if v & 128 else (GT if v & 64 else TILES)
         if npad % tl[v & 7][1] or (tl[v & 7][1] > 32 and Cout <= tl[v & 7][1] // 2):
             continue
         ms = C.c_float()
@@ -43,4 +44,4 @@ for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
         res.append((v, ms.value, flops / ms.value / 1e9))
     best = max(r[2] for r in res if r[0] >= 0)
     print(f"{name:10s} M={N*Ho*Wo:7d} N={Cout:5d} K={Cin*k*k:5d} GF={flops/1e9:7.1f} | " +
-          " ".join(f"{('h' if v < 0 else ('%s%d%s' % ('G' if v & 64 else 't', v & 7, 'k32' if v & 8 else '')))}:{ms:.3f}ms/{tf:.0f}TF{'*' if tf == best else ''}" for v, ms, tf in res), flush=True)
+          " ".join(f"{('h' if v < 0 else ('%s%d%s' % ('W' if v & 128 else ('G' if v & 64 else 't'), v & 7, 'k32' if v & 8 else '')))}:{ms:.3f}ms/{tf:.0f}TF{'*' if tf == best else ''}" for v, ms, tf in res), flush=True)

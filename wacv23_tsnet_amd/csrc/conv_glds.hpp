@@ -62,7 +62,9 @@ struct GldsArgs {
 // s_waitcnt vmcnt(n) only (expcnt / lgkmcnt left unconstrained); gfx9 simm16 encoding
 #define TSNET_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14))
 
-template <int KS, int BM, int BN, int WARPS_M, int WARPS_N, int FLUSH>
+// ABL (tools/conv_ablate.py only; any non-zero value computes garbage): bit0 no DMA in the loop,
+// bit1 no vmcnt/barrier, bit2 no two-level flush, bit3 no ds_reads (MFMA-only loop).
+template <int KS, int BM, int BN, int WARPS_M, int WARPS_N, int FLUSH, int ABL = 0>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N)
 void conv_glds_kernel(GldsArgs a) {
     constexpr int BK = 16, KQ = 4, NSTAGE = 4;
@@ -172,11 +174,255 @@ void conv_glds_kernel(GldsArgs a) {
     for (int s = 0; s < NSTAGE - 1; ++s) issue_chunk(s < nch ? s : nch - 1, s);
 
     for (int kc = 0; kc < nch; ++kc) {
-        const F4* st = ring + (kc % NSTAGE) * STAGE_F4;
+        const F4* st = ring + (((ABL & 8) ? 0 : kc) % NSTAGE) * STAGE_F4;
         // chunk kc landed when at most (NSTAGE-2) newer chunks of this wave are outstanding
+        if (!(ABL & 2)) {
         TSNET_VMCNT(LPC * (NSTAGE - 2));
         asm volatile("" ::: "memory");         // compiler-level fence only: no LDS access may cross the barrier
         __builtin_amdgcn_s_barrier();          // every wave's share of chunk kc landed; stage (kc-1)%NSTAGE is free again
+        asm volatile("" ::: "memory");
+        }
+        F4 af[2][MT], bf[2][NTL];
+        if ((ABL & 8) && kc > 0) { st = ring; }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[0][i] = st[a_base + i * 32 * KQ + q_s0];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) bf[0][j] = st[b_base + j * 32 * KQ + q_s0];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[1][i] = st[a_base + i * 32 * KQ + q_s1];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) bf[1][j] = st[b_base + j * 32 * KQ + q_s1];
+        if (!(ABL & 1)) {   // refill the stage freed by the barrier (after this chunk's ds_reads in program order)
+            const int nk = kc + NSTAGE - 1;
+            issue_chunk(nk < nch ? nk : nch - 1, nk % NSTAGE);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i].v[e], bf[s][j].v[e], acc[i][j], 0, 0, 0);
+        if (FLUSH > 0 && !(ABL & 4) && ((kc + 1) % FLUSH) == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {
+                    tot[i][j] += acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+        }
+    }
+    TSNET_VMCNT(0);   // drain the tail DMAs before the block may exit
+
+    // ---- epilogue (identical to conv_igemm.hpp)
+    const int hw = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int n = n0 + wn0 + j * 32 + li;
+            if (n >= a.Cout) continue;
+            const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = (tot[i][j][r] + acc[i][j][r]) + bv;
+                if (a.act == 1) v = tanhf(v);
+                if (a.out_nchw) {
+                    const int img = m / hw;
+                    const int rem = m - img * hw;
+                    if (a.composite) {
+                        const int ox = rem % a.Wo;
+                        if (ox < a.fore_x0 || ox >= a.fore_x1) v = a.bg[n];
+                    }
+                    a.y[((size_t)img * a.Cout + n) * hw + rem] = v;
+                } else {
+                    a.y[(size_t)m * a.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised variant: NL loader waves issue every LDS-DMA of the workgroup, the
+// WARPS_M x WARPS_N consumer waves only ds_read + MFMA.
+//
+// Why (profiles/round1_notes.md, ablation of conv_glds_kernel): removing the barrier / vmcnt wait
+// changes nothing, removing the DMA *issue* from the MFMA-issuing waves gives +24 % -- one LDS-DMA
+// instruction holds its wave's issue for ~60-185 cycles (MI355X_MICROARCH.md, "LDS-DMA piece"),
+// and a wave issues in order, so the MFMAs queued behind it wait.  A separate wave issues VMEM in
+// parallel with another wave's MFMA (different issue ports), so the cost leaves the critical path.
+// Loader addressing is incremental: one base pointer per image row per tap, +16 floats per chunk.
+// Protocol per chunk (all waves execute the same number of s_barrier):
+//   loader  : wait own vmcnt so chunk kc has landed -> s_barrier -> issue chunk kc+3 into the stage
+//             the consumers finished reading before that barrier
+//   consumer: s_barrier -> ds_read chunk kc -> 32 MFMA
+template <int KS, int BM, int BN, int WARPS_M, int WARPS_N, int NL, int FLUSH, bool SMALL_CIN>
+__global__ __launch_bounds__(64 * (WARPS_M * WARPS_N + NL))
+void conv_glds_ws_kernel(GldsArgs a) {
+    constexpr int BK = 16, KQ = 4, NSTAGE = 4;
+    constexpr int NC = WARPS_M * WARPS_N;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 32, NTL = WN / 32;
+    constexpr int TA = BM / 16, TB = BN / 16;       // DMA instructions per chunk for A and B (1 KiB each)
+    static_assert(TA % NL == 0 && TB % NL == 0, "loaders must split the DMA list evenly");
+    constexpr int IA = TA / NL, IB = TB / NL, LPC = IA + IB;
+    static_assert(LPC * (NSTAGE - 1) < 64, "vmcnt is 6 bits");
+    constexpr int STAGE_F4 = (BM + BN) * KQ;
+
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    F4* ring = reinterpret_cast<F4*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nch = a.nchunks;
+
+    if (wave >= NC) {
+        // =================================================================== loader wave
+        const int ld = wave - NC;
+        const int kq_phys = lane & 3;
+        int r_img[IA], r_img2[IA], r_oy[IA], r_ox[IA], r_kq[IA];
+        bool r_ok[IA];
+#pragma unroll
+        for (int j = 0; j < IA; ++j) {
+            const int row = (j * NL + ld) * 16 + (lane >> 2);
+            r_kq[j] = kq_phys ^ ((row >> 2) & 3);
+            const int m = m0 + row;
+            r_ok[j] = m < a.M;
+            const int mm = r_ok[j] ? m : 0;
+            const int hw = a.Ho * a.Wo;
+            const int img = mm / hw;
+            const int rem = mm - img * hw;
+            const int oy = rem / a.Wo;
+            r_img[j] = img;
+            r_img2[j] = img % a.x2_nmod;
+            r_oy[j] = oy * a.stride - a.pad;
+            r_ox[j] = (rem - oy * a.Wo) * a.stride - a.pad;
+        }
+        const int C2 = a.Cin - a.Csplit;
+        const int cpt_log2 = a.cin_log2 - 4;          // chunks per tap = Cin/16 (Cin >= 16 unless SMALL_CIN)
+        const float* p1[IA];                           // per-row pixel base in source 0 / source 1 for the current tap
+        const float* p2[IA];
+        bool pok[IA];
+        int cur_tap = -1;
+
+        auto issue = [&](int kc, int stage) {
+            F4* sA = ring + stage * STAGE_F4;
+            F4* sB = sA + BM * KQ;
+            if (SMALL_CIN) {
+                // stem (Cin = 8): a chunk spans two taps, so the tap is per lane; recompute every time
+#pragma unroll
+                for (int j = 0; j < IA; ++j) {
+                    const int k = kc * BK + r_kq[j] * 4;
+                    const int tap = k >> a.cin_log2;
+                    const int c = k & (a.Cin - 1);
+                    const int ky = tap / KS, kx = tap - ky * KS;
+                    int iy = r_oy[j] + ky, ix = r_ox[j] + kx;
+                    bool ok = r_ok[j] && tap < a.taps;
+                    if (a.reflect) {
+                        iy = iy < 0 ? -iy : iy;
+                        iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+                        ix = ix < 0 ? -ix : ix;
+                        ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+                    } else {
+                        ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    }
+                    const float* p = a.x + ((size_t)((r_img[j] * a.H + iy) * a.W + ix)) * a.Csplit + c;
+                    const float* gp = ok ? p : a.zero_page;
+                    TSNET_GLDS16(gp, TSNET_LDS_ADDR(sA + (j * NL + ld) * 64));
+                }
+            } else {
+                const int tap = kc >> cpt_log2;                   // wave-uniform
+                const int c0 = (kc << 4) & (a.Cin - 1);
+                if (tap != cur_tap) {                              // new tap: rebuild the per-row base pointers
+                    cur_tap = tap;
+                    const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+                    for (int j = 0; j < IA; ++j) {
+                        int iy = r_oy[j] + ky, ix = r_ox[j] + kx;
+                        bool ok = r_ok[j] && tap < a.taps;
+                        if (a.reflect) {
+                            iy = iy < 0 ? -iy : iy;
+                            iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+                            ix = ix < 0 ? -ix : ix;
+                            ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+                        } else {
+                            ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                        }
+                        iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+                        ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+                        pok[j] = ok;
+                        p1[j] = a.x + ((size_t)((r_img[j] * a.H + iy) * a.W + ix)) * a.Csplit + r_kq[j] * 4;
+                        p2[j] = a.x2 ? a.x2 + ((size_t)((r_img2[j] * a.H + iy) * a.W + ix)) * C2 + r_kq[j] * 4 : a.zero_page;
+                    }
+                }
+                const bool second = c0 >= a.Csplit;
+#pragma unroll
+                for (int j = 0; j < IA; ++j) {
+                    const float* p = second ? p2[j] + (c0 - a.Csplit) : p1[j] + c0;
+                    const float* gp = pok[j] ? p : a.zero_page;
+                    TSNET_GLDS16(gp, TSNET_LDS_ADDR(sA + (j * NL + ld) * 64));
+                }
+            }
+            const float* wb = a.w + ((size_t)kc * a.Npad + n0) * (KQ * 4);
+#pragma unroll
+            for (int j = 0; j < IB; ++j) {
+                const float* gp = wb + ((j * NL + ld) * 64 + lane) * 4;
+                TSNET_GLDS16(gp, TSNET_LDS_ADDR(sB + (j * NL + ld) * 64));
+            }
+        };
+
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s) issue(s < nch ? s : nch - 1, s);
+        for (int kc = 0; kc < nch; ++kc) {
+            TSNET_VMCNT(LPC * (NSTAGE - 2));        // this loader's share of chunk kc has landed
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int nk = kc + NSTAGE - 1;
+            issue(nk < nch ? nk : nch - 1, nk % NSTAGE);
+        }
+        TSNET_VMCNT(0);
+        return;
+    }
+
+    // ======================================================================= consumer wave
+    const int wm0 = (wave / WARPS_N) * WM;
+    const int wn0 = (wave % WARPS_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[MT][NTL], tot[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+    const int rswz = (li >> 2) & 3;
+    const int q_s0 = (lh ^ rswz), q_s1 = ((2 + lh) ^ rswz);
+    const int a_base = (wm0 + li) * KQ, b_base = BM * KQ + (wn0 + li) * KQ;
+
+    for (int kc = 0; kc < nch; ++kc) {
+        const F4* st = ring + (kc % NSTAGE) * STAGE_F4;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // the loaders' chunk kc is in LDS; see protocol above
         asm volatile("" ::: "memory");
         F4 af[2][MT], bf[2][NTL];
 #pragma unroll
@@ -187,10 +433,6 @@ void conv_glds_kernel(GldsArgs a) {
         for (int i = 0; i < MT; ++i) af[1][i] = st[a_base + i * 32 * KQ + q_s1];
 #pragma unroll
         for (int j = 0; j < NTL; ++j) bf[1][j] = st[b_base + j * 32 * KQ + q_s1];
-        {   // refill the stage freed by the barrier (after this chunk's ds_reads in program order)
-            const int nk = kc + NSTAGE - 1;
-            issue_chunk(nk < nch ? nk : nch - 1, nk % NSTAGE);
-        }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -211,9 +453,7 @@ void conv_glds_kernel(GldsArgs a) {
                 }
         }
     }
-    TSNET_VMCNT(0);   // drain the tail DMAs before the block may exit
 
-    // ---- epilogue (identical to conv_igemm.hpp)
     const int hw = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {

@@ -220,8 +220,8 @@ void launch_conv_ks(const ConvArgs& a0, int forced, hipStream_t s) {
 
 // ---- LDS-DMA kernel (conv_glds.hpp): tiles whose A and B images split into whole wave DMAs
 struct GTileCfg { int bm, bn, wm, wn; double eff; };
-const GTileCfg kGTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 2, 1, 0.7}};
-constexpr int kNumGTiles = 4;
+const GTileCfg kGTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 2, 1, 0.7}, {128, 128, 4, 2, 0.0}, {128, 128, 2, 4, 0.0}};
+constexpr int kNumGTiles = 6;   // 4,5: 8-wave experiments (eff 0 = never chosen by the heuristic)
 
 const float* zero_page() {
     static float* zp = nullptr;
@@ -243,6 +243,42 @@ void launch_glds_t(const GldsArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
 }
 
+// wave-specialised kernel: tile index 8.. in the glds variant space
+template <int KS, int BM, int BN, int WM_, int WN_, int NL>
+void launch_ws_t(const GldsArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)4 * (BM + BN) * 4 * 16;
+    const bool small = a.Cin < 16;
+    auto kern = small ? conv_glds_ws_kernel<KS, BM, BN, WM_, WN_, NL, FLUSH_K / 16, true>
+                      : conv_glds_ws_kernel<KS, BM, BN, WM_, WN_, NL, FLUSH_K / 16, false>;
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * (WM_ * WN_ + NL)), lds, s, a);
+}
+
+struct WTileCfg { int bm, bn, wm, wn, nl; double eff; };
+const WTileCfg kWTiles[] = {{128, 128, 2, 2, 1, 1.0}, {128, 64, 2, 2, 2, 0.93}, {128, 128, 2, 2, 2, 0.0}, {64, 64, 2, 2, 1, 0.8}};
+constexpr int kNumWTiles = 4;
+
+template <int KS>
+void launch_ws_ks(GldsArgs a, int tile, hipStream_t s) {
+    if (tile < 0 || tile >= kNumWTiles || a.Npad % kWTiles[tile].bn) throw ArgError("conv(ws): bad tile");
+    a.tiles_m = (a.M + kWTiles[tile].bm - 1) / kWTiles[tile].bm;
+    a.tiles_n = (a.Cout + kWTiles[tile].bn - 1) / kWTiles[tile].bn;
+    switch (tile) {
+        case 0: launch_ws_t<KS, 128, 128, 2, 2, 1>(a, s); break;
+        case 1: launch_ws_t<KS, 128, 64, 2, 2, 2>(a, s); break;
+        case 2: launch_ws_t<KS, 128, 128, 2, 2, 2>(a, s); break;
+        default: launch_ws_t<KS, 64, 64, 2, 2, 1>(a, s); break;
+    }
+}
+
+template <int ABL>
+void launch_glds_abl(const GldsArgs& a, hipStream_t s) {    // 3x3, 128x128 tile only; diagnostic
+    const size_t lds = (size_t)4 * (128 + 128) * 4 * 16;
+    auto kern = conv_glds_kernel<3, 128, 128, 2, 2, FLUSH_K / 16, ABL>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+}
+
 template <int KS>
 void launch_glds_ks(GldsArgs a, int forced_tile, hipStream_t s) {
     int best = forced_tile;
@@ -253,7 +289,7 @@ void launch_glds_ks(GldsArgs a, int forced_tile, hipStream_t s) {
         for (int i = 0; i < kNumGTiles; ++i) {
             if (a.Npad % kGTiles[i].bn) continue;
             if (env_tile >= 0 && env_tile < kNumGTiles && a.Npad % kGTiles[env_tile].bn == 0) { best = env_tile; break; }
-            if (kGTiles[i].bn > 32 && a.Cout <= kGTiles[i].bn / 2) continue;
+            if (kGTiles[i].eff <= 0 || (kGTiles[i].bn > 32 && a.Cout <= kGTiles[i].bn / 2)) continue;
             const long tm = (a.M + kGTiles[i].bm - 1) / kGTiles[i].bm, tn = (a.Cout + kGTiles[i].bn - 1) / kGTiles[i].bn;
             const long seq = (tm * tn + 255) / 256;
             const double cost = (double)seq * kGTiles[i].bm * kGTiles[i].bn / kGTiles[i].eff;
@@ -267,7 +303,9 @@ void launch_glds_ks(GldsArgs a, int forced_tile, hipStream_t s) {
         case 0: launch_glds_t<KS, 128, 128, 2, 2>(a, s); break;
         case 1: launch_glds_t<KS, 128, 64, 2, 2>(a, s); break;
         case 2: launch_glds_t<KS, 64, 64, 2, 2>(a, s); break;
-        default: launch_glds_t<KS, 128, 32, 2, 1>(a, s); break;
+        case 3: launch_glds_t<KS, 128, 32, 2, 1>(a, s); break;
+        case 4: launch_glds_t<KS, 128, 128, 4, 2>(a, s); break;
+        default: launch_glds_t<KS, 128, 128, 2, 4>(a, s); break;
     }
 }
 
@@ -299,6 +337,50 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
             throw ArgError("conv: tensor exceeds 2^31 elements");
         TimeScope ts(ctx, TSNET_T_CONV);
         const int forced = c.variant >= 0 ? (c.variant & 7) : -1;
+        const int abl = c.variant >= 0 ? (c.variant >> 8) & 15 : 0;
+        int ws_tile = -1;
+        if (c.variant >= 0) { if (c.variant & 128) ws_tile = forced; }
+        else {
+            const char* e_ws = getenv("TSNET_GLDS_WS");
+            if (!(e_ws && !atoi(e_ws))) {              // default on; TSNET_GLDS_WS=0 selects the symmetric kernel
+                const char* e_t = getenv("TSNET_WS_TILE");
+                double best_cost = 0;
+                for (int i = 0; i < kNumWTiles; ++i) {
+                    if (g.Npad % kWTiles[i].bn || kWTiles[i].eff <= 0) continue;
+                    if (e_t && atoi(e_t) == i) { ws_tile = i; break; }
+                    if (kWTiles[i].bn > 32 && g.Cout <= kWTiles[i].bn / 2) continue;
+                    const long tm = (g.M + kWTiles[i].bm - 1) / kWTiles[i].bm, tn = (g.Cout + kWTiles[i].bn - 1) / kWTiles[i].bn;
+                    const double cost = (double)((tm * tn + 255) / 256) * kWTiles[i].bm * kWTiles[i].bn / kWTiles[i].eff;
+                    if (ws_tile < 0 || cost < best_cost) { ws_tile = i; best_cost = cost; }
+                }
+            }
+        }
+        if (ws_tile >= 0) {     // wave-specialised kernel
+            switch (L.ks) {
+                case 1: launch_ws_ks<1>(g, ws_tile, ctx.stream); break;
+                case 3: launch_ws_ks<3>(g, ws_tile, ctx.stream); break;
+                case 7: launch_ws_ks<7>(g, ws_tile, ctx.stream); break;
+                default: throw ArgError("conv: kernel size must be 1, 3 or 7");
+            }
+            check_launch("conv_glds_ws");
+            ++g_launch_counters[0];
+            return;
+        }
+        if (abl && L.ks == 3) {
+            g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.Cout + 127) / 128;
+            switch (abl) {
+                case 1: launch_glds_abl<1>(g, ctx.stream); break;
+                case 2: launch_glds_abl<2>(g, ctx.stream); break;
+                case 3: launch_glds_abl<3>(g, ctx.stream); break;
+                case 4: launch_glds_abl<4>(g, ctx.stream); break;
+                case 7: launch_glds_abl<7>(g, ctx.stream); break;
+                case 11: launch_glds_abl<11>(g, ctx.stream); break;
+                case 15: launch_glds_abl<15>(g, ctx.stream); break;
+                default: throw ArgError("unsupported ablation mask");
+            }
+            check_launch("conv_glds(abl)");
+            return;
+        }
         switch (L.ks) {
             case 1: launch_glds_ks<1>(g, forced, ctx.stream); break;
             case 3: launch_glds_ks<3>(g, forced, ctx.stream); break;
