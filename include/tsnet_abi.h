@@ -156,8 +156,8 @@ const char* tsnet_op_last_error(void);
 int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int pad_mode, int norm,
                      int variant, int iters, float* ms_out, void* stream);
 
-/* Launch counters since the last reset: out[0] = LDS-DMA conv launches (conv_glds_kernel),
- * out[1] = register-staged conv launches (conv_igemm_kernel); out[2..3] reserved.  Diagnostic. */
+/* Conv launch counters since the last reset: out[0] = conv_glds kernels, out[1] = conv_igemm (register-staged),
+ * out[2] = conv_dma (default, buffer-descriptor LDS-DMA); out[3] reserved.  Diagnostic. */
 void tsnet_debug_counters(int64_t out[4], int reset);
 
 /* Host-side constant tables, exported so CPU tests can pin them against torch:

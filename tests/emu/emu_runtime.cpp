@@ -124,6 +124,19 @@ void global_load_lds(const void* g, void* lds, int size) {
     memcpy(static_cast<unsigned char*>(w.lp[par][0]) + (size_t)lane * size, w.gp[par][lane], size);
 }
 
+void buf_dma16(const unsigned char* base, unsigned bytes, unsigned voff, unsigned soff, unsigned char* lds) {
+    // raw-buffer LDS-DMA: range check on voffset against num_records - soffset (gfx9 raw-buffer rule);
+    // destination = lane 0's LDS address + 16*lane (M0 semantics)
+    WaveState& w = g_waves[g_cur / 64];
+    const int lane = g_cur & 63, par = w.gen & 1;
+    w.lp[par][lane] = lds;
+    if (w.alive != 64) throw std::runtime_error("emu: buffer LDS-DMA needs a full, converged wave");
+    wave_rendezvous(w);
+    unsigned char* dst = static_cast<unsigned char*>(w.lp[par][0]) + (size_t)lane * 16;
+    const bool oob = soff > bytes || (unsigned long long)voff + 16 > (unsigned long long)(bytes - soff);
+    if (oob) memset(dst, 0, 16); else memcpy(dst, base + (size_t)voff + soff, 16);
+}
+
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
     const int nt = (int)(block.x * block.y * block.z);
     if (nt <= 0 || nt > 1024) throw std::runtime_error("emu: bad block size");

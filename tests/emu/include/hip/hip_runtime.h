@@ -49,6 +49,7 @@ float shfl_xor(float v, int mask);
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 f32x16_t mfma_32x32x2(float a, float b, f32x16_t c);
 void global_load_lds(const void* g, void* lds, int size);
+void buf_dma16(const unsigned char* base, unsigned bytes, unsigned voff, unsigned soff, unsigned char* lds);
 }  // namespace emu
 
 #define threadIdx (emu::g_threadIdx)
@@ -67,6 +68,13 @@ static inline float __shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask
 // the one hook the kernels expose for their inline-asm LDS-DMA (conv_glds.hpp)
 #define TSNET_GLDS16(g, lds) emu::global_load_lds((const void*)(g), (void*)(lds), 16)
 #define TSNET_LDS_ADDR(p) (p)
+// hooks of conv_dma.hpp (buffer_load ... lds): descriptor = (base, bytes), out-of-range lanes read zeros
+struct tsnet_rsrc_t { const unsigned char* base; unsigned bytes; };
+typedef unsigned char* tsnet_lds_t;
+static inline tsnet_rsrc_t tsnet_make_rsrc(const void* p, unsigned bytes) { tsnet_rsrc_t r; r.base = (const unsigned char*)p; r.bytes = bytes; return r; }
+#define TSNET_LDS_BASE(p) ((unsigned char*)(p))
+#define TSNET_BUF_DMA16(rsrc, voff, soff, lds) emu::buf_dma16((rsrc).base, (rsrc).bytes, (voff), (soff), (lds))
+#define TSNET_UNIFORM(x) (x)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

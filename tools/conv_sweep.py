@@ -32,7 +32,7 @@ for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
     flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
     npad = (Cout + 127) // 128 * 128 if Cout >= 128 else (Cout + 31) // 32 * 32
     res = []
-    for v in ([64, 65, 192, 193, 194, 195] if quick else [0, 1, 4, 8 + 4, 64, 65, 66, 67, 192, 193, 194, 195]):
+    for v in ([64, 65, 4096 + 64, 4097 + 64, 4098 + 64, 4099 + 64] if quick else [0, 1, 4, 8 + 4, 64, 65, 66, 67, 192, 193, 194, 195, 4096 + 64, 4097 + 64, 4098 + 64, 4099 + 64]):
         tl = WT if v & 128 else (GT if v & 64 else TILES)
         if npad % tl[v & 7][1] or (tl[v & 7][1] > 32 and Cout <= tl[v & 7][1] // 2):
             continue
@@ -42,6 +42,7 @@ for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
         if rc != 0:
             print(name, v, "ERR", lib.tsnet_op_last_error().decode()); continue
         res.append((v, ms.value, flops / ms.value / 1e9))
-    best = max(r[2] for r in res if r[0] >= 0)
+    if not res: continue
+    best = max(r[2] for r in res)
     print(f"{name:10s} M={N*Ho*Wo:7d} N={Cout:5d} K={Cin*k*k:5d} GF={flops/1e9:7.1f} | " +
-          " ".join(f"{('h' if v < 0 else ('%s%d%s' % ('W' if v & 128 else ('G' if v & 64 else 't'), v & 7, 'k32' if v & 8 else '')))}:{ms:.3f}ms/{tf:.0f}TF{'*' if tf == best else ''}" for v, ms, tf in res), flush=True)
+          " ".join(f"{('h' if v < 0 else ('%s%d%s' % ('D' if v & 4096 else ('W' if v & 128 else ('G' if v & 64 else 't')), v & 7, 'k32' if v & 8 else '')))}:{ms:.3f}ms/{tf:.0f}TF{'*' if tf == best else ''}" for v, ms, tf in res), flush=True)

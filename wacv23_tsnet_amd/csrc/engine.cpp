@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/tsnet_abi.h"
+#include "conv_dma.hpp"
 #include "conv_glds.hpp"
 #include "conv_igemm.hpp"
 #include "flow_warp.hpp"
@@ -37,7 +38,7 @@ using namespace tsnet;
 namespace {
 
 thread_local std::string g_op_error;
-int64_t g_launch_counters[4] = {0, 0, 0, 0};   // [0] LDS-DMA conv launches, [1] register-staged conv launches
+int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] conv_glds(+ws), [1] conv_igemm, [2] conv_dma
 std::string g_create_error;
 
 #define HIP_TRY(expr)                                                                               \
@@ -243,6 +244,45 @@ void launch_glds_t(const GldsArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
 }
 
+// lean buffer-descriptor LDS-DMA kernel (conv_dma.hpp): the default conv path
+const GTileCfg kDTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 2, 1, 0.7}};
+constexpr int kNumDTiles = 4;
+
+template <int KS, int BM, int BN, int WM_, int WN_>
+void launch_dma_t(const GldsArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)4 * (BM + BN) * 4 * 16;
+    const bool small = a.Cin < 16;
+    auto kern = small ? conv_dma_kernel<KS, BM, BN, WM_, WN_, true> : conv_dma_kernel<KS, BM, BN, WM_, WN_, false>;
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
+}
+
+template <int KS>
+void launch_dma_ks(GldsArgs a, int forced_tile, hipStream_t s) {
+    int best = forced_tile;
+    if (best < 0) {
+        const char* e_tile = getenv("TSNET_DMA_TILE");
+        double best_cost = 0;
+        for (int i = 0; i < kNumDTiles; ++i) {
+            if (a.Npad % kDTiles[i].bn) continue;
+            if (e_tile && atoi(e_tile) == i) { best = i; break; }
+            if (kDTiles[i].bn > 32 && a.Cout <= kDTiles[i].bn / 2) continue;
+            const long tm = (a.M + kDTiles[i].bm - 1) / kDTiles[i].bm, tn = (a.Cout + kDTiles[i].bn - 1) / kDTiles[i].bn;
+            const double cost = (double)((tm * tn + 255) / 256) * kDTiles[i].bm * kDTiles[i].bn / kDTiles[i].eff;
+            if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+        }
+    }
+    if (best < 0 || best >= kNumDTiles || a.Npad % kDTiles[best].bn) throw ArgError("conv(dma): no tile configuration");
+    a.tiles_m = (a.M + kDTiles[best].bm - 1) / kDTiles[best].bm;
+    a.tiles_n = (a.Cout + kDTiles[best].bn - 1) / kDTiles[best].bn;
+    switch (best) {
+        case 0: launch_dma_t<KS, 128, 128, 2, 2>(a, s); break;
+        case 1: launch_dma_t<KS, 128, 64, 2, 2>(a, s); break;
+        case 2: launch_dma_t<KS, 64, 64, 2, 2>(a, s); break;
+        default: launch_dma_t<KS, 128, 32, 2, 1>(a, s); break;
+    }
+}
+
 // wave-specialised kernel: tile index 8.. in the glds variant space
 template <int KS, int BM, int BN, int WM_, int WN_, int NL>
 void launch_ws_t(const GldsArgs& a, hipStream_t s) {
@@ -338,11 +378,28 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         TimeScope ts(ctx, TSNET_T_CONV);
         const int forced = c.variant >= 0 ? (c.variant & 7) : -1;
         const int abl = c.variant >= 0 ? (c.variant >> 8) & 15 : 0;
+        // kernel generation: default = conv_dma (buffer-descriptor LDS-DMA); TSNET_CONV_KERNEL=glds|ws select the
+        // two predecessors for A/B runs (bench variant bits: 4096 dma, 128 ws, else glds)
+        const char* e_kern = getenv("TSNET_CONV_KERNEL");
+        const bool tensor_small = (double)c.N * c.H * c.W * g.Csplit * 4 < 2147483648.0 &&
+                                  (double)g.x2_nmod * c.H * c.W * (g.Cin - g.Csplit) * 4 < 2147483648.0 &&
+                                  (double)L.kpad * L.npad * 4 < 2147483648.0;      // 32-bit buffer offsets / OOB marker
+        const bool want_dma = c.variant >= 0 ? (c.variant & 4096) != 0 : (!e_kern || !strcmp(e_kern, "dma"));
+        if (want_dma && tensor_small) {
+            switch (L.ks) {
+                case 1: launch_dma_ks<1>(g, forced, ctx.stream); break;
+                case 3: launch_dma_ks<3>(g, forced, ctx.stream); break;
+                case 7: launch_dma_ks<7>(g, forced, ctx.stream); break;
+                default: throw ArgError("conv: kernel size must be 1, 3 or 7");
+            }
+            check_launch("conv_dma");
+            ++g_launch_counters[2];
+            return;
+        }
         int ws_tile = -1;
         if (c.variant >= 0) { if (c.variant & 128) ws_tile = forced; }
         else {
-            const char* e_ws = getenv("TSNET_GLDS_WS");
-            if (!(e_ws && !atoi(e_ws))) {              // default on; TSNET_GLDS_WS=0 selects the symmetric kernel
+            if (e_kern && !strcmp(e_kern, "ws")) {
                 const char* e_t = getenv("TSNET_WS_TILE");
                 double best_cost = 0;
                 for (int i = 0; i < kNumWTiles; ++i) {
