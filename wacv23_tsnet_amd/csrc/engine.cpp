@@ -245,7 +245,8 @@ void launch_glds_t(const GldsArgs& a, hipStream_t s) {
 }
 
 // lean buffer-descriptor LDS-DMA kernel (conv_dma.hpp): the default conv path
-const GTileCfg kDTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 2, 1, 0.7}};
+// eff = measured per-tile efficiency relative to 128x128 (gpurun sweep4, profiles/round1_notes.md)
+const GTileCfg kDTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.99}, {64, 64, 2, 2, 0.96}, {128, 32, 2, 1, 0.7}};
 constexpr int kNumDTiles = 4;
 
 template <int KS, int BM, int BN, int WM_, int WN_>
