@@ -64,8 +64,10 @@ def coord_conv(x: torch.Tensor) -> torch.Tensor:
     bs, _, h, w = x.shape
     xs = torch.arange(w, dtype=x.dtype) / (w - 1)
     ys = torch.arange(h, dtype=x.dtype) / (h - 1)
-    xx = (2 * xs - 1).view(1, 1, 1, w).expand(bs, 1, h, w)
-    yy = (2 * ys - 1).view(1, 1, h, 1).expand(bs, 1, h, w)
+    # materialised (contiguous) like the reference's matmul outputs, so torch.pow takes the same
+    # vectorised x*x path as in the reference (an expanded view goes through scalar powf: 1-ulp differences)
+    xx = (2 * xs - 1).view(1, 1, 1, w).expand(bs, 1, h, w).contiguous()
+    yy = (2 * ys - 1).view(1, 1, h, 1).expand(bs, 1, h, w).contiguous()
     rr = torch.sqrt(torch.pow(xx, 2) + torch.pow(yy, 2))
     return torch.cat((x, xx, yy, rr), dim=1)
 

@@ -1,0 +1,73 @@
+"""CPU tier: the WHOLE forward schedule of the engine (every kernel, every launch geometry, the arena,
+clip mode) executed under the fiber emulator on a narrow net (ngf=8) and compared with the oracle.
+Numerics on real hardware at full width are the GPU tier's job (tests/test_gpu_forward.py)."""
+import ctypes as C
+
+import pytest
+import torch
+
+import helpers as Hh
+from oracle import tsnet_oracle as O
+
+
+def _case(K=2, nb=1, L=2, B=2, H=32, W=32, enc_blocks=2, pose=False, wscale=4.0, bias_std=0.02, mask="box", seed=3):
+    cfg = O.TSNetConfig(label_nc=L, n_blocks=nb, n_source=K, ngf=8, enc_blocks=enc_blocks, fuse_ngf=128, pose=pose)
+    sd = O.synth_state_dict(cfg, seed=seed, bias_std=bias_std)
+    sd = {k: (v * wscale if k.endswith("weight") else v) for k, v in sd.items()}   # non-trivial activations at width 8
+    inp = O.synth_inputs(cfg, B, H, W, seed=seed + 1, mask_mode=mask)
+    return cfg, sd, inp
+
+
+@pytest.mark.parametrize("kw", [dict(K=2, nb=1), dict(K=3, nb=0, mask="bernoulli"), dict(K=1, nb=2, L=5, H=48, W=32, mask="soft")])
+def test_forward_matches_oracle(emu_lib, kw):
+    cfg, sd, inp = _case(**kw)
+    B, H, W = inp[3].shape[0], inp[3].shape[2], inp[3].shape[3]
+    ref = O.tsnet_forward(sd, cfg, *inp, want_stages=True)
+    eng = Hh.make_engine(cfg, sd, H, W, B, "cpu", lib=emu_lib)
+    rec, flows = Hh.run_engine(eng, inp, "cpu")
+    assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
+    for a, b in zip(flows, ref["flows"]):
+        assert (a - b).abs().max().item() < 1e-4
+    rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, B, "cpu")
+    assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4 and rep["pg"] < 2e-3
+    cnt = (C.c_int64 * 4)()
+    emu_lib.tsnet_debug_counters(cnt, 1)
+    assert cnt[2] > 0 and cnt[1] == 0        # every conv went through conv_dma_kernel
+    eng.close()
+
+
+def test_clip_mode_and_determinism(emu_lib):
+    cfg, sd, inp = _case(K=2, nb=0)
+    eng = Hh.make_engine(cfg, sd, 32, 32, 2, "cpu", lib=emu_lib)
+    r1, f1 = Hh.run_engine(eng, inp, "cpu")
+    r2, _ = Hh.run_engine(eng, inp, "cpu")
+    assert torch.equal(r1, r2)
+    eng.set_sources(inp[0], inp[1], inp[2])
+    r3, f3 = eng.forward_target(inp[3], inp[4], return_flow=True)
+    assert torch.equal(r1, r3) and all(torch.equal(a, b) for a, b in zip(f1, f3))
+    # a second driving frame against the cached sources == the one-shot forward on that frame
+    inp2 = O.synth_inputs(cfg, 2, 32, 32, seed=99, mask_mode="box")
+    r4, _ = eng.forward_target(inp2[3], inp2[4])
+    r5, _ = Hh.run_engine(eng, (inp[0], inp[1], inp[2], inp2[3], inp2[4]), "cpu")
+    assert torch.equal(r4, r5)
+    eng.close()
+
+
+def test_batch_items_independent(emu_lib):
+    cfg, sd, inp = _case(K=2, nb=0, B=3)
+    eng = Hh.make_engine(cfg, sd, 32, 32, 3, "cpu", lib=emu_lib)
+    full, _ = Hh.run_engine(eng, inp, "cpu")
+    sub = ([x[1:2] for x in inp[0]], [x[1:2] for x in inp[1]], [x[1:2] for x in inp[2]], inp[3][1:2], inp[4][1:2])
+    one, _ = Hh.run_engine(eng, sub, "cpu")
+    assert (one - full[1:2]).abs().max().item() <= 1e-6
+    eng.close()
+
+
+def test_pose_composite(emu_lib):
+    cfg, sd, inp = _case(K=1, nb=0, L=5, B=1, H=256, W=256, enc_blocks=0, pose=True)
+    ref = O.tsnet_forward(sd, cfg, *inp)
+    eng = Hh.make_engine(cfg, sd, 256, 256, 1, "cpu", lib=emu_lib)
+    rec, _ = Hh.run_engine(eng, inp, "cpu", return_flow=False)
+    assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
+    assert torch.equal(rec[..., :64], ref["rec_tar_img"][..., :64]) and torch.equal(rec[..., 192:], ref["rec_tar_img"][..., 192:])
+    eng.close()

@@ -556,7 +556,8 @@ void linspace_pm1(int n, float* out) {
     const float start = -1.f, end = 1.f;
     const float step = (end - start) / (float)(n - 1);
     const int half = n / 2;
-    for (int i = 0; i < n; ++i) out[i] = i < half ? start + step * (float)i : end - step * (float)(n - i - 1);
+    // ATen evaluates both halves with a fused multiply-add (e.g. linspace(-1,1,7)[3] == -2.98e-8, not 0)
+    for (int i = 0; i < n; ++i) out[i] = i < half ? fmaf(step, (float)i, start) : fmaf(-step, (float)(n - i - 1), end);
 }
 
 // Encoder.coord_conv channels: xx = 2*(j/(w-1))-1, yy likewise, rr = sqrt(xx*xx+yy*yy); layout (H,W,3).
