@@ -24,6 +24,7 @@ def test_forward_matches_oracle(emu_lib, kw):
     B, H, W = inp[3].shape[0], inp[3].shape[2], inp[3].shape[3]
     ref = O.tsnet_forward(sd, cfg, *inp, want_stages=True)
     eng = Hh.make_engine(cfg, sd, H, W, B, "cpu", lib=emu_lib)
+    emu_lib.tsnet_debug_counters(None, 1)      # reset the process-wide launch counters
     rec, flows = Hh.run_engine(eng, inp, "cpu")
     assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
     for a, b in zip(flows, ref["flows"]):
@@ -70,4 +71,16 @@ def test_pose_composite(emu_lib):
     rec, _ = Hh.run_engine(eng, inp, "cpu", return_flow=False)
     assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
     assert torch.equal(rec[..., :64], ref["rec_tar_img"][..., :64]) and torch.equal(rec[..., 192:], ref["rec_tar_img"][..., 192:])
+    eng.close()
+
+
+def test_conv_epilogue_statistics_path(emu_lib):
+    """64x64 input -> 8x8 features: P=64 is a whole number of 64-row tiles, so the conv epilogue (not the
+    stand-alone pass) produces the InstanceNorm partials for the 64x64 and 32x32 layers; the result must
+    still match the oracle."""
+    cfg, sd, inp = _case(K=1, nb=1, B=1, H=64, W=64, enc_blocks=1)
+    ref = O.tsnet_forward(sd, cfg, *inp)
+    eng = Hh.make_engine(cfg, sd, 64, 64, 1, "cpu", lib=emu_lib)
+    rec, _ = Hh.run_engine(eng, inp, "cpu", return_flow=False)
+    assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
     eng.close()

@@ -244,19 +244,28 @@ void conv_dma_kernel(GldsArgs a) {
     TSNET_VMCNT(0);   // drain the tail DMAs before the block may exit
 
     // ---- epilogue: bias, activation, store.  D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+    // With a.stat_part the InstanceNorm statistics of the output are produced here as well (the host
+    // only asks for it when every row of a tile belongs to one image, Ho*Wo % BM == 0): per column the
+    // wave sums its WM rows in fp32 (64 values at most), the WARPS_M waves combine in fp64 through LDS
+    // in a fixed order, one (sum, sumsq) pair per (image, tile, channel) goes to HBM; in_finalize2_kernel
+    // reduces the tiles.  This removes the separate read pass over every conv output.
     const int hw = a.Ho * a.Wo;
+    float csum[NTL], csq[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
             const int n = n0 + wn0 + j * 32 + li;
-            if (n >= a.Cout) continue;
-            const float bv = a.bias ? a.bias[n] : 0.f;
+            const bool nok = n < a.Cout;
+            const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
                 float v = tot[i][j][r] + bv;
+                if (m < a.M) { csum[j] += v; csq[j] = __builtin_fmaf(v, v, csq[j]); }
+                if (!nok || m >= a.M) continue;
                 if (a.act == 1) v = tanhf(v);
                 if (a.out_nchw) {
                     const int img = m / hw;
@@ -270,6 +279,30 @@ void conv_dma_kernel(GldsArgs a) {
                     a.y[(size_t)m * a.Cout + n] = v;
                 }
             }
+        }
+    }
+    if (a.stat_part) {
+        __syncthreads();                                   // the ring is dead: reuse LDS for the cross-wave reduction
+        double* red = reinterpret_cast<double*>(smem_raw);   // [WARPS_M][BN][2]
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const float s2 = csum[j] + __shfl_xor(csum[j], 32);   // the other 4-row groups of the same column
+            const float q2 = csq[j] + __shfl_xor(csq[j], 32);
+            if (lh == 0) {
+                double* o = red + ((size_t)(wave / WARPS_N) * BN + wn0 + j * 32 + li) * 2;
+                o[0] = (double)s2; o[1] = (double)q2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Cout) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int wmi = 0; wmi < WARPS_M; ++wmi) { s += red[((size_t)wmi * BN + tid) * 2]; q += red[((size_t)wmi * BN + tid) * 2 + 1]; }
+            const int img = m0 / hw;
+            const int tile_in_img = (m0 - img * hw) / BM;
+            const int tiles_per_img = hw / BM;
+            double* o = a.stat_part + (((size_t)img * tiles_per_img + tile_in_img) * a.Cout + n0 + tid) * 2;
+            o[0] = s; o[1] = q;
         }
     }
 }

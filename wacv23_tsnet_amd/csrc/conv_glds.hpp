@@ -33,6 +33,7 @@ struct GldsArgs {
     const float* w;         // packed [K/16][Npad][4 quads (swizzled)][4]
     const float* bias;
     float* y;
+    double* stat_part;      // null, or (N, tiles_per_img, Cout, 2) per-tile sum / sum-of-squares of y (conv_dma only)
     int N, H, W, Cin, cin_log2, Csplit, x2_nmod;
     int Ho, Wo, Cout, Npad;
     int stride, pad, reflect, taps, nchunks, M;

@@ -141,6 +141,8 @@ struct ConvCall {
     float* y = nullptr; int act = 0; int out_nchw = 0;
     int composite = 0; float bg[3] = {0, 0, 0};
     int variant = -1;      // -1 = heuristic; else tile index + 8*(BK==32)   (bench / test hook)
+    double* stat_part = nullptr;   // in: where the conv epilogue may leave InstanceNorm partials of y
+    mutable int stat_S = 0;        // out: partials per image actually written (0 = none: run the stats kernel)
 };
 
 struct TileCfg { int bm, bn, wm, wn; double eff; };
@@ -259,7 +261,7 @@ void launch_dma_t(const GldsArgs& a, hipStream_t s) {
 }
 
 template <int KS>
-void launch_dma_ks(GldsArgs a, int forced_tile, hipStream_t s) {
+int launch_dma_ks(GldsArgs a, int forced_tile, hipStream_t s) {   // returns stats partials per image (0 = none)
     int best = forced_tile;
     if (best < 0) {
         const char* e_tile = getenv("TSNET_DMA_TILE");
@@ -276,12 +278,15 @@ void launch_dma_ks(GldsArgs a, int forced_tile, hipStream_t s) {
     if (best < 0 || best >= kNumDTiles || a.Npad % kDTiles[best].bn) throw ArgError("conv(dma): no tile configuration");
     a.tiles_m = (a.M + kDTiles[best].bm - 1) / kDTiles[best].bm;
     a.tiles_n = (a.Cout + kDTiles[best].bn - 1) / kDTiles[best].bn;
+    const int hw = a.Ho * a.Wo;
+    if (hw % kDTiles[best].bm) a.stat_part = nullptr;      // a tile would straddle two images: statistics stay separate
     switch (best) {
         case 0: launch_dma_t<KS, 128, 128, 2, 2>(a, s); break;
         case 1: launch_dma_t<KS, 128, 64, 2, 2>(a, s); break;
         case 2: launch_dma_t<KS, 64, 64, 2, 2>(a, s); break;
         default: launch_dma_t<KS, 128, 32, 2, 1>(a, s); break;
     }
+    return a.stat_part ? hw / kDTiles[best].bm : 0;
 }
 
 // wave-specialised kernel: tile index 8.. in the glds variant space
@@ -361,6 +366,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
     if (use_glds_path(L, c)) {
         GldsArgs g{};
         g.x = c.x; g.x2 = c.x2; g.zero_page = zero_page(); g.w = L.w2; g.bias = L.bias; g.y = c.y;
+        g.stat_part = nullptr; c.stat_S = 0;
         g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
         g.Csplit = c.x2 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
         g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
@@ -387,10 +393,11 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
                                   (double)L.kpad * L.npad * 4 < 2147483648.0;      // 32-bit buffer offsets / OOB marker
         const bool want_dma = c.variant >= 0 ? (c.variant & 4096) != 0 : (!e_kern || !strcmp(e_kern, "dma"));
         if (want_dma && tensor_small) {
+            g.stat_part = (c.act == 0 && !c.out_nchw) ? c.stat_part : nullptr;
             switch (L.ks) {
-                case 1: launch_dma_ks<1>(g, forced, ctx.stream); break;
-                case 3: launch_dma_ks<3>(g, forced, ctx.stream); break;
-                case 7: launch_dma_ks<7>(g, forced, ctx.stream); break;
+                case 1: c.stat_S = launch_dma_ks<1>(g, forced, ctx.stream); break;
+                case 3: c.stat_S = launch_dma_ks<3>(g, forced, ctx.stream); break;
+                case 7: c.stat_S = launch_dma_ks<7>(g, forced, ctx.stream); break;
                 default: throw ArgError("conv: kernel size must be 1, 3 or 7");
             }
             check_launch("conv_dma");
@@ -494,6 +501,15 @@ void run_stats(Ctx& ctx, const float* x, int N, int HW, int C, double* part, flo
     const int NC = N * C;
     hipLaunchKernelGGL(in_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, ctx.stream, part, alpha, beta, NC, C, S, HW, 1e-5f);
     check_launch("in_finalize");
+}
+
+// statistics of a conv output: reduce the partials the conv epilogue left (S per image), or run the
+// stand-alone statistics pass when the conv could not produce them
+void finish_stats(Ctx& ctx, const ConvCall& c, const float* y, int N, int HW, int C, double* part, float* alpha, float* beta) {
+    if (c.stat_S <= 0) { run_stats(ctx, y, N, HW, C, part, alpha, beta); return; }
+    TimeScope ts(ctx, TSNET_T_STATS);
+    hipLaunchKernelGGL(in_finalize2_kernel, dim3((C + 63) / 64, N), dim3(256), 0, ctx.stream, part, alpha, beta, C, c.stat_S, HW, 1e-5f);
+    check_launch("in_finalize2");
 }
 
 void run_norm_act(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, const float* resid,
@@ -770,7 +786,8 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     for (int i = 0; i < 4; ++i) { want(&ab[i][0], NB * 2 * C); want(&ab[i][1], NB * 2 * C); }
     want(&bbox_copy, NB * H * W);
     float* part_f = nullptr;
-    want(&part_f, NB * 64 * 2 * C * 2 * 2);   // doubles: N*S*C*2, as floats x2
+    // InstanceNorm partials (doubles, 2 floats each): stand-alone pass N*64*C*2, conv-epilogue N*(HW/64)*C*2
+    want(&part_f, 2 * std::max(NB * 64 * 2 * C * 2, NB * (size_t)H * W * cfg.ngf / 32 + 1024));
     size_t total = 0;
     for (auto& r : req) total += r.second;
     arena_floats = total;
@@ -783,15 +800,15 @@ void tsnet_engine::alloc_all(hipStream_t s) {
 // one ResnetBlock on a materialised NHWC tensor Xs (in place): Xs += IN(conv2(relu(IN(conv1(Xs)))))
 void tsnet_engine::resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww) {
     const int Cc = c1.cout, HW = hh * ww;
-    ConvCall a; a.x = Xs; a.N = N; a.H = hh; a.W = ww; a.y = y1;
+    ConvCall a; a.x = Xs; a.N = N; a.H = hh; a.W = ww; a.y = y1; a.stat_part = part;
     run_conv(ctx, c1, a);
     auto s1 = next_ab();
-    run_stats(ctx, y1, N, HW, Cc, part, s1.first, s1.second);
-    ConvCall b; b.x = y1; b.N = N; b.H = hh; b.W = ww; b.y = y2;
+    finish_stats(ctx, a, y1, N, HW, Cc, part, s1.first, s1.second);
+    ConvCall b; b.x = y1; b.N = N; b.H = hh; b.W = ww; b.y = y2; b.stat_part = part;
     norm_input(ctx, y1, s1.first, s1.second, N, HW, Cc, b);
     run_conv(ctx, c2, b);
     auto s2 = next_ab();
-    run_stats(ctx, y2, N, HW, Cc, part, s2.first, s2.second);
+    finish_stats(ctx, b, y2, N, HW, Cc, part, s2.first, s2.second);
     run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs);
 }
 
@@ -799,17 +816,17 @@ void tsnet_engine::resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, 
 void tsnet_engine::encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin, int N, int cp, std::vector<float*>& raw, float* out_fea, int nblocks) {
     (void)cp;
     int hh = cfg.height, ww = cfg.width;
-    ConvCall a; a.x = xin; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
+    ConvCall a; a.x = xin; a.N = N; a.H = hh; a.W = ww; a.y = raw[0]; a.stat_part = part;
     run_conv(ctx, L[0], a);
     auto st = next_ab();
-    run_stats(ctx, raw[0], N, hh * ww, L[0].cout, part, st.first, st.second);
+    finish_stats(ctx, a, raw[0], N, hh * ww, L[0].cout, part, st.first, st.second);
     for (int l = 1; l <= cfg.n_downsampling; ++l) {
-        ConvCall d; d.x = raw[l - 1]; d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
+        ConvCall d; d.x = raw[l - 1]; d.N = N; d.H = hh; d.W = ww; d.y = raw[l]; d.stat_part = part;
         norm_input(ctx, raw[l - 1], st.first, st.second, N, hh * ww, L[l].cin_pad, d);
         run_conv(ctx, L[l], d);
         hh /= 2; ww /= 2;
         st = next_ab();
-        run_stats(ctx, raw[l], N, hh * ww, L[l].cout, part, st.first, st.second);
+        finish_stats(ctx, d, raw[l], N, hh * ww, L[l].cout, part, st.first, st.second);
     }
     run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea);
     for (int i = 0; i < nblocks; ++i)
@@ -861,15 +878,15 @@ void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* t
 
     // ---- synthesis branch (FuseNet), cat(src_fea, tar_fea) formed inside the conv loader
     {
-        ConvCall a; a.x = X; a.x2 = tar_fea; a.csplit = C; a.x2_nmod = B; a.N = NB; a.H = h; a.W = w; a.y = F1;
+        ConvCall a; a.x = X; a.x2 = tar_fea; a.csplit = C; a.x2_nmod = B; a.N = NB; a.H = h; a.W = w; a.y = F1; a.stat_part = part;
         run_conv(ctx, fuse_c1, a);
         auto s1 = next_ab();
-        run_stats(ctx, F1, NB, P, 2 * C, part, s1.first, s1.second);
-        ConvCall b; b.x = F1; b.N = NB; b.H = h; b.W = w; b.y = F2;
+        finish_stats(ctx, a, F1, NB, P, 2 * C, part, s1.first, s1.second);
+        ConvCall b; b.x = F1; b.N = NB; b.H = h; b.W = w; b.y = F2; b.stat_part = part;
         norm_input(ctx, F1, s1.first, s1.second, NB, P, 2 * C, b);
         run_conv(ctx, fuse_c2, b);
         auto s2 = next_ab();
-        run_stats(ctx, F2, NB, P, 2 * C, part, s2.first, s2.second);
+        finish_stats(ctx, b, F2, NB, P, 2 * C, part, s2.first, s2.second);
         {
             TimeScope ts(ctx, TSNET_T_ELEMWISE);
             FuseTailArgs t{X, tar_fea, F2, s2.first, s2.second, zbar, B, K, P, C};
@@ -891,11 +908,11 @@ void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* t
     for (int i = 0; i < cfg.n_downsampling; ++i) {
         run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, U[i]);
         hh *= 2; ww *= 2;
-        ConvCall a; a.x = U[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
+        ConvCall a; a.x = U[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i]; a.stat_part = part;
         run_conv(ctx, dec_up[i], a);
         cc /= 2;
         auto st = next_ab();
-        run_stats(ctx, R[i], B, hh * ww, cc, part, st.first, st.second);
+        finish_stats(ctx, a, R[i], B, hh * ww, cc, part, st.first, st.second);
         cur = R[i]; cal = st.first; cbe = st.second;
     }
     ConvCall hd; hd.x = cur; hd.N = B; hd.H = hh; hd.W = ww;

@@ -90,6 +90,33 @@ __global__ void in_finalize_kernel(const double* __restrict__ part, float* __res
     beta[i] = -((float)mean) * al;
 }
 
+// stage 2 for many partials (conv-epilogue statistics: S = tiles per image, up to 1024):
+// block = (image n, 64 channels); 4 thread groups split the S partials, fixed-order LDS combine.
+__global__ __launch_bounds__(256) void in_finalize2_kernel(const double* __restrict__ part, float* __restrict__ alpha,
+                                                            float* __restrict__ beta, int C, int S, int HW, float eps) {
+    __shared__ double red[256 * 2];
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    double sm = 0, sq = 0;
+    if (c < C) {
+        for (int s = g; s < S; s += 4) {
+            const double* p = part + (((size_t)n * S + s) * C + c) * 2;
+            sm += p[0];
+            sq += p[1];
+        }
+    }
+    red[threadIdx.x * 2] = sm; red[threadIdx.x * 2 + 1] = sq;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        for (int k = 1; k < 4; ++k) { sm += red[(k * 64 + threadIdx.x) * 2]; sq += red[(k * 64 + threadIdx.x) * 2 + 1]; }
+        const double mean = sm / HW;
+        double var = sq / HW - mean * mean;
+        if (var < 0) var = 0;
+        const float al = 1.0f / sqrtf((float)var + eps);
+        alpha[(size_t)n * C + c] = al;
+        beta[(size_t)n * C + c] = -((float)mean) * al;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // y = alpha*x + beta (optionally ReLU) (+ resid).  alpha==null -> y = x (+resid).  In-place safe.
 struct NormActArgs {
