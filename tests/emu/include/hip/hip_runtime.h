@@ -61,6 +61,11 @@ void buf_dma16(const unsigned char* base, unsigned bytes, unsigned voff, unsigne
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<unsigned char*>(emu::g_dyn_smem);
 static inline void __syncthreads() { emu::syncthreads(); }
 static inline float __shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }
+static inline double __shfl_xor(double v, int mask) {
+    union { double d; float f[2]; } u, r; u.d = v;
+    r.f[0] = emu::shfl_xor(u.f[0], mask); r.f[1] = emu::shfl_xor(u.f[1], mask);
+    return r.d;
+}
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
 // LDS-DMA: destination = the wave's FIRST lane's LDS pointer + lane*size (the per-lane pointers of the
 // other lanes are ignored, exactly the hardware's M0 semantics), source address per lane.

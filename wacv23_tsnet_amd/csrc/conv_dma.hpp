@@ -246,13 +246,13 @@ void conv_dma_kernel(GldsArgs a) {
     // ---- epilogue: bias, activation, store.  D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
     // With a.stat_part the InstanceNorm statistics of the output are produced here as well (the host
     // only asks for it when every row of a tile belongs to one image, Ho*Wo % BM == 0): per column the
-    // wave sums its WM rows in fp32 (64 values at most), the WARPS_M waves combine in fp64 through LDS
+    // wave sums its WM rows in fp64 (so the statistics do not depend on the tile shape), the WARPS_M waves combine through LDS
     // in a fixed order, one (sum, sumsq) pair per (image, tile, channel) goes to HBM; in_finalize2_kernel
     // reduces the tiles.  This removes the separate read pass over every conv output.
     const int hw = a.Ho * a.Wo;
-    float csum[NTL], csq[NTL];
+    double csum[NTL], csq[NTL];
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+    for (int j = 0; j < NTL; ++j) { csum[j] = 0.0; csq[j] = 0.0; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -264,7 +264,11 @@ void conv_dma_kernel(GldsArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = tot[i][j][r] + bv;
-                if (m < a.M) { csum[j] += v; csq[j] = __builtin_fmaf(v, v, csq[j]); }
+                if (a.addend && nok && m < a.M) {
+                    const int img = m / hw;
+                    v += a.addend[((size_t)(img % a.add_nmod) * hw + (m - img * hw)) * a.Cout + n];
+                }
+                if (a.stat_part && m < a.M) { csum[j] += (double)v; csq[j] += (double)v * (double)v; }
                 if (!nok || m >= a.M) continue;
                 if (a.act == 1) v = tanhf(v);
                 if (a.out_nchw) {
@@ -286,11 +290,11 @@ void conv_dma_kernel(GldsArgs a) {
         double* red = reinterpret_cast<double*>(smem_raw);   // [WARPS_M][BN][2]
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
-            const float s2 = csum[j] + __shfl_xor(csum[j], 32);   // the other 4-row groups of the same column
-            const float q2 = csq[j] + __shfl_xor(csq[j], 32);
+            const double s2 = csum[j] + __shfl_xor(csum[j], 32);   // the other 4-row groups of the same column
+            const double q2 = csq[j] + __shfl_xor(csq[j], 32);
             if (lh == 0) {
                 double* o = red + ((size_t)(wave / WARPS_N) * BN + wn0 + j * 32 + li) * 2;
-                o[0] = (double)s2; o[1] = (double)q2;
+                o[0] = s2; o[1] = q2;
             }
         }
         __syncthreads();

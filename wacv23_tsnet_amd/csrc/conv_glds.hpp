@@ -34,6 +34,8 @@ struct GldsArgs {
     const float* bias;
     float* y;
     double* stat_part;      // null, or (N, tiles_per_img, Cout, 2) per-tile sum / sum-of-squares of y (conv_dma only)
+    const float* addend;    // null, or NHWC (add_nmod, Ho, Wo, Cout) added to y before statistics (conv_dma only)
+    int add_nmod;           // image index into addend = img % add_nmod
     int N, H, W, Cin, cin_log2, Csplit, x2_nmod;
     int Ho, Wo, Cout, Npad;
     int stride, pad, reflect, taps, nchunks, M;
@@ -486,8 +488,10 @@ void conv_glds_ws_kernel(GldsArgs a) {
 }
 
 // OIHW -> [K/16][Npad][4 physical quads][4], physical quad p of column n holds logical quad p ^ ((n>>2)&3)
+// The packed layer may take a window [cin_off, cin_off+cin_real) of the parameter's cin_total input channels
+// (FuseNet's first conv is split into its source half and its shared target half).
 __global__ void pack_weights_glds_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                         int cout, int cin_real, int cin_pad, int ks, int kpad, int npad) {
+                                         int cout, int cin_real, int cin_pad, int ks, int kpad, int npad, int cin_total, int cin_off) {
     const size_t total = (size_t)kpad * npad;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = idx & 3;
@@ -500,7 +504,7 @@ __global__ void pack_weights_glds_kernel(const float* __restrict__ w, float* __r
         float v = 0.f;
         if (tap < ks * ks && c < cin_real && n < cout) {
             const int ky = tap / ks, kx = tap - ky * ks;
-            v = w[(((size_t)n * cin_real + c) * ks + ky) * ks + kx];
+            v = w[(((size_t)n * cin_total + cin_off + c) * ks + ky) * ks + kx];
         }
         out[idx] = v;
     }

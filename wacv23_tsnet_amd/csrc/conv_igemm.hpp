@@ -283,7 +283,7 @@ void conv_igemm_kernel(ConvArgs a) {
 // Channels c >= cin_real and couts >= cout are zero (channel padding of the 8/32-wide stems and
 // of the 3-wide RGB head).
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                    int cout, int cin_real, int cin_pad, int ks, int kpad, int npad) {
+                                    int cout, int cin_real, int cin_pad, int ks, int kpad, int npad, int cin_total, int cin_off) {
     const size_t total = (size_t)kpad * npad;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = idx & 3;
@@ -294,7 +294,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         float v = 0.f;
         if (tap < ks * ks && c < cin_real && n < cout) {
             const int ky = tap / ks, kx = tap - ky * ks;
-            v = w[(((size_t)n * cin_real + c) * ks + ky) * ks + kx];
+            v = w[(((size_t)n * cin_total + cin_off + c) * ks + ky) * ks + kx];
         }
         out[idx] = v;
     }

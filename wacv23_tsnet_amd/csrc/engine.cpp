@@ -119,7 +119,9 @@ inline int ew_grid(size_t total, int block = 256) {
 // convolution layer description + launch
 struct ConvLayer {
     std::string name;       // state_dict prefix, e.g. "img_enc.model.1"
+    std::string wparam, bparam;   // parameter names feeding this layer (bparam empty = no bias)
     int cin_real = 0, cin_pad = 0, cout = 0, ks = 1, stride = 1, pad = 0, reflect = 0;
+    int cin_total = 0, cin_off = 0;   // window of the parameter's input channels this layer consumes
     int kpad = 0, npad = 0;
     size_t w_off = 0, w2_off = 0, b_off = 0;  // offsets (floats) into the packed buffer
     const float* w = nullptr;     // device, packed for conv_igemm_kernel  [K/4][Npad][4]
@@ -141,6 +143,7 @@ struct ConvCall {
     float* y = nullptr; int act = 0; int out_nchw = 0;
     int composite = 0; float bg[3] = {0, 0, 0};
     int variant = -1;      // -1 = heuristic; else tile index + 8*(BK==32)   (bench / test hook)
+    const float* addend = nullptr; int add_nmod = 1;   // y += addend[img % add_nmod] (conv_dma only)
     double* stat_part = nullptr;   // in: where the conv epilogue may leave InstanceNorm partials of y
     mutable int stat_S = 0;        // out: partials per image actually written (0 = none: run the stats kernel)
 };
@@ -366,7 +369,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
     if (use_glds_path(L, c)) {
         GldsArgs g{};
         g.x = c.x; g.x2 = c.x2; g.zero_page = zero_page(); g.w = L.w2; g.bias = L.bias; g.y = c.y;
-        g.stat_part = nullptr; c.stat_S = 0;
+        g.stat_part = nullptr; c.stat_S = 0; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
         g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
         g.Csplit = c.x2 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
         g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
@@ -404,6 +407,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
             ++g_launch_counters[2];
             return;
         }
+        if (c.addend) throw ArgError("conv: an epilogue addend needs the conv_dma kernel");
         int ws_tile = -1;
         if (c.variant >= 0) { if (c.variant & 128) ws_tile = forced; }
         else {
@@ -456,6 +460,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         ++g_launch_counters[0];
         return;
     }
+    if (c.addend) throw ArgError("conv: an epilogue addend needs the conv_dma kernel");
     ConvArgs a{};
     a.x = c.x; a.x2 = c.x2; a.in_alpha = c.alpha; a.in_beta = c.beta;
     a.w = L.w; a.bias = L.bias; a.y = c.y;
@@ -555,12 +560,13 @@ void run_warp(Ctx& ctx, const float* src, const float* flow, float* out, int B, 
 
 void pack_layer_weights(const float* w_oihw_dev, float* out_dev, float* out2_dev, const ConvLayer& L, hipStream_t s) {
     const size_t total = (size_t)L.kpad * L.npad;
+    const int ct = L.cin_total > 0 ? L.cin_total : L.cin_real;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw_dev, out_dev,
-                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad);
+                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, ct, L.cin_off);
     check_launch("pack_weights");
     if (out2_dev) {
         hipLaunchKernelGGL(pack_weights_glds_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw_dev, out2_dev,
-                           L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad);
+                           L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, ct, L.cin_off);
         check_launch("pack_weights_glds");
     }
 }
@@ -610,6 +616,8 @@ struct tsnet_engine {
     // layers
     std::vector<ConvLayer> img_enc, lbl_enc;            // stem, downs, then 2 per resblock
     ConvLayer fuse_c1, fuse_c2, fuse_out, dec_map, dec_head;
+    ConvLayer fuse_c1_src, fuse_c1_tar;   // fuse_c1 split at the channel concat: per-source half / shared target half
+    float* FT = nullptr;                  // (B,P,2C) target half of fuse_c1, computed once per forward
     std::vector<ConvLayer> dec_res, dec_up;
     std::vector<ConvLayer*> all_layers;
 
@@ -647,8 +655,9 @@ struct tsnet_engine {
         ConvLayer L; L.name = name; L.cin_real = cin_real; L.cin_pad = cin_pad; L.cout = cout; L.ks = ks;
         L.stride = stride; L.pad = pad; L.reflect = reflect;
         L.kpad = conv_kpad(ks, cin_pad); L.npad = conv_npad(cout);
-        add_param(name + ".weight", {cout, cin_real, ks, ks});
-        add_param(name + ".bias", {cout});
+        L.wparam = name + ".weight"; L.bparam = name + ".bias"; L.cin_total = cin_real; L.cin_off = 0;
+        add_param(L.wparam, {cout, cin_real, ks, ks});
+        add_param(L.bparam, {cout});
         return L;
     }
     void build_layers();
@@ -660,6 +669,7 @@ struct tsnet_engine {
     // A conv whose input is ReLU(IN(raw)): materialise it in place (one HBM-bound pass; required by the
     // LDS-DMA conv kernel, which cannot transform data in flight) or, on the legacy register-staged
     // kernel (TSNET_CONV_LEGACY=1), apply it inside the loader.
+    bool split_fuse = true;           // needs conv_dma's epilogue addend; off with the legacy kernels
     bool fuse_norm_in_loader = false;
     void norm_input(Ctx& ctx, float* raw, const float* alpha, const float* beta, int N, int HW, int Cc, ConvCall& call) {
         if (fuse_norm_in_loader) { call.alpha = alpha; call.beta = beta; call.in_relu = 1; return; }
@@ -692,6 +702,11 @@ void tsnet_engine::build_layers() {
     const int fc = 2 * C;   // FuseNet width: cat of two feature maps (1024 in the reference, TSNet.py:227)
     fuse_c1 = make_conv("fuse_net.model.0.conv_block.1", fc, fc, fc, 3, 1, 1, 1);
     fuse_c2 = make_conv("fuse_net.model.0.conv_block.5", fc, fc, fc, 3, 1, 1, 1);
+    // conv(cat(src, tar)) = conv_src(src) + conv_tar(tar): the target half is shared by the K sources
+    // (SURVEY.md 7.2, -9.66 GMAC/frame).  Both halves read windows of the same OIHW parameter.
+    fuse_c1_src = fuse_c1; fuse_c1_src.name += "[src]"; fuse_c1_src.cin_real = fuse_c1_src.cin_pad = C; fuse_c1_src.cin_off = 0;
+    fuse_c1_src.kpad = conv_kpad(3, C);
+    fuse_c1_tar = fuse_c1_src; fuse_c1_tar.name = fuse_c1.name + "[tar]"; fuse_c1_tar.cin_off = C; fuse_c1_tar.bparam.clear();
     fuse_out = make_conv("fuse_net.conv", fc, fc, fc / 2, 1, 1, 0, 0);
     dec_map = make_conv("dec.map_conv", 2 * C, 2 * C, C, 1, 1, 0, 0);
     int n = 0;
@@ -708,7 +723,8 @@ void tsnet_engine::build_layers() {
     dec_head = make_conv("dec.model" + std::to_string(n) + ".1", c.ngf, c.ngf, 3, 7, 1, 3, 1);
     for (auto& L : img_enc) all_layers.push_back(&L);
     for (auto& L : lbl_enc) all_layers.push_back(&L);
-    all_layers.push_back(&fuse_c1); all_layers.push_back(&fuse_c2); all_layers.push_back(&fuse_out);
+    all_layers.push_back(&fuse_c1); all_layers.push_back(&fuse_c1_src); all_layers.push_back(&fuse_c1_tar);
+    all_layers.push_back(&fuse_c2); all_layers.push_back(&fuse_out);
     all_layers.push_back(&dec_map);
     for (auto& L : dec_res) all_layers.push_back(&L);
     for (auto& L : dec_up) all_layers.push_back(&L);
@@ -727,19 +743,21 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     HIP_TRY(hipMalloc((void**)&wpack, wpack_floats * sizeof(float)));
     HIP_TRY(hipMemsetAsync(wpack, 0, wpack_floats * sizeof(float), s));
     size_t max_w = 0;
-    for (ConvLayer* L : all_layers) max_w = std::max(max_w, (size_t)L->cout * L->cin_real * L->ks * L->ks);
+    for (ConvLayer* L : all_layers) max_w = std::max(max_w, (size_t)L->cout * L->cin_total * L->ks * L->ks);
     float* stage = nullptr;
     HIP_TRY(hipMalloc((void**)&stage, max_w * sizeof(float)));
     for (ConvLayer* L : all_layers) {
-        const Param& pw = params[pindex[L->name + ".weight"]];
-        const Param& pb = params[pindex[L->name + ".bias"]];
+        const Param& pw = params[pindex[L->wparam]];
         HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
         pack_layer_weights(stage, wpack + L->w_off, wpack + L->w2_off, *L, s);
-        HIP_TRY(hipMemcpyAsync(wpack + L->b_off, pb.host.data(), pb.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        if (!L->bparam.empty()) {
+            const Param& pb = params[pindex[L->bparam]];
+            HIP_TRY(hipMemcpyAsync(wpack + L->b_off, pb.host.data(), pb.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        }
         HIP_TRY(hipStreamSynchronize(s));   // host vectors / staging buffer reused next iteration
         L->w = wpack + L->w_off;
         L->w2 = wpack + L->w2_off;
-        L->bias = wpack + L->b_off;
+        L->bias = L->bparam.empty() ? nullptr : wpack + L->b_off;
     }
     HIP_TRY(hipFree(stage));
     for (auto& p : params) { std::vector<float>().swap(p.host); }   // host copies no longer needed
@@ -775,7 +793,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     const size_t fe = (size_t)P * C;
     want(&X, NB * fe); want(&Y1, NB * fe); want(&Y2, NB * fe);
     want(&tar_fea, B * fe); want(&that, B * fe); want(&shat, NB * fe); want(&flow, NB * P * 2); want(&pg, B * fe);
-    want(&F1, NB * fe * 2); want(&F2, NB * fe * 2); want(&zbar, B * fe * 2); want(&sg, B * fe);
+    want(&F1, NB * fe * 2); want(&F2, NB * fe * 2); want(&zbar, B * fe * 2); want(&sg, B * fe); want(&FT, B * fe * 2);
     want(&D, B * fe); want(&DY1, B * fe); want(&DY2, B * fe);
     U.assign(cfg.n_downsampling, nullptr); R.assign(cfg.n_downsampling, nullptr);
     for (int i = 0; i < cfg.n_downsampling; ++i) {
@@ -878,8 +896,16 @@ void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* t
 
     // ---- synthesis branch (FuseNet), cat(src_fea, tar_fea) formed inside the conv loader
     {
-        ConvCall a; a.x = X; a.x2 = tar_fea; a.csplit = C; a.x2_nmod = B; a.N = NB; a.H = h; a.W = w; a.y = F1; a.stat_part = part;
-        run_conv(ctx, fuse_c1, a);
+        ConvCall a; a.N = NB; a.H = h; a.W = w; a.y = F1; a.stat_part = part;
+        if (split_fuse) {
+            ConvCall t; t.x = tar_fea; t.N = B; t.H = h; t.W = w; t.y = FT;          // shared target half, once per batch item
+            run_conv(ctx, fuse_c1_tar, t);
+            a.x = X; a.addend = FT; a.add_nmod = B;                                   // per-source half + bias + target half
+            run_conv(ctx, fuse_c1_src, a);
+        } else {
+            a.x = X; a.x2 = tar_fea; a.csplit = C; a.x2_nmod = B;                     // cat formed inside the conv loader
+            run_conv(ctx, fuse_c1, a);
+        }
         auto s1 = next_ab();
         finish_stats(ctx, a, F1, NB, P, 2 * C, part, s1.first, s1.second);
         ConvCall b; b.x = F1; b.N = NB; b.H = h; b.W = w; b.y = F2; b.stat_part = part;
@@ -965,6 +991,8 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
         e->h = cfg->height / ds; e->w = cfg->width / ds; e->P = e->h * e->w;
         e->build_layers();
         { const char* lg = getenv("TSNET_CONV_LEGACY"); e->fuse_norm_in_loader = lg && atoi(lg); }
+        { const char* k = getenv("TSNET_CONV_KERNEL"); const char* sf = getenv("TSNET_SPLIT_FUSE");
+          e->split_fuse = !e->fuse_norm_in_loader && (!k || !strcmp(k, "dma")) && !(sf && !atoi(sf)); }
         *out = e;
     } catch (const std::exception& ex) { g_create_error = ex.what(); return TSNET_ERR_NOMEM; }
     return TSNET_OK;
@@ -1145,7 +1173,7 @@ int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w
     if (Cin < 4 || (Cin & (Cin - 1))) throw ArgError("conv2d op: Cin must be a power of two >= 4 (pad channels with zeros)");
     hipStream_t s = (hipStream_t)stream;
     Ctx ctx; ctx.stream = s;
-    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
+    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
     L.reflect = pad_mode; L.kpad = conv_kpad(ksize, Cin); L.npad = conv_npad(Cout);
     const size_t wn = (size_t)Cout * Cin * ksize * ksize;
     float *wd = nullptr, *wp = nullptr, *wp2 = nullptr, *bd = nullptr;
@@ -1237,7 +1265,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     if (Cin < 4 || (Cin & (Cin - 1)) || iters < 1 || !ms_out) throw ArgError("bench_conv: bad argument");
     hipStream_t s = (hipStream_t)stream;
     Ctx ctx; ctx.stream = s;
-    ConvLayer L; L.name = "bench"; L.cin_real = Cin; L.cin_pad = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
+    ConvLayer L; L.name = "bench"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
     L.reflect = pad_mode; L.kpad = conv_kpad(ksize, Cin); L.npad = conv_npad(Cout);
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const size_t xn = (size_t)N * H * W * Cin, yn = (size_t)N * Ho * Wo * Cout, wn = (size_t)L.kpad * L.npad;
