@@ -84,3 +84,21 @@ def test_conv_epilogue_statistics_path(emu_lib):
     rec, _ = Hh.run_engine(eng, inp, "cpu", return_flow=False)
     assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
     eng.close()
+
+
+@pytest.mark.parametrize("pose", [False, True])
+def test_vector_rgb_head(emu_lib, pose):
+    """ngf=16 is the narrowest width the dedicated RGB-head kernel (head_conv.hpp) accepts; ragged 48x40
+    frames exercise its partial tiles and reflection, the pose case (256x256) its composite epilogue."""
+    H, W = (256, 256) if pose else (48, 40)
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=1, ngf=16, enc_blocks=0, fuse_ngf=256, pose=pose)
+    sd = O.synth_state_dict(cfg, seed=8, bias_std=0.02)
+    sd = {k: (v * 3 if k.endswith("weight") else v) for k, v in sd.items()}
+    inp = O.synth_inputs(cfg, 1, H, W, seed=9, mask_mode="box")
+    ref = O.tsnet_forward(sd, cfg, *inp)["rec_tar_img"]
+    eng = Hh.make_engine(cfg, sd, H, W, 1, "cpu", lib=emu_lib)
+    rec, _ = Hh.run_engine(eng, inp, "cpu", return_flow=False)
+    assert (rec - ref).abs().max().item() < 5e-4
+    if pose:
+        assert torch.equal(rec[..., :64], ref[..., :64])
+    eng.close()

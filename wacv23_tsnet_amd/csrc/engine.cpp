@@ -31,6 +31,7 @@
 #include "conv_glds.hpp"
 #include "conv_igemm.hpp"
 #include "flow_warp.hpp"
+#include "head_conv.hpp"
 #include "norm_elementwise.hpp"
 
 using namespace tsnet;
@@ -618,6 +619,8 @@ struct tsnet_engine {
     ConvLayer fuse_c1, fuse_c2, fuse_out, dec_map, dec_head;
     ConvLayer fuse_c1_src, fuse_c1_tar;   // fuse_c1 split at the channel concat: per-source half / shared target half
     float* FT = nullptr;                  // (B,P,2C) target half of fuse_c1, computed once per forward
+    float* head_w = nullptr;              // [49][ngf][4] weights of the RGB head for head_conv_kernel
+    bool vector_head = true;              // head_conv_kernel (VALU) instead of the N-padded MFMA conv
     std::vector<ConvLayer> dec_res, dec_up;
     std::vector<ConvLayer*> all_layers;
 
@@ -758,6 +761,16 @@ void tsnet_engine::alloc_all(hipStream_t s) {
         L->w = wpack + L->w_off;
         L->w2 = wpack + L->w2_off;
         L->bias = L->bparam.empty() ? nullptr : wpack + L->b_off;
+    }
+    if (cfg.ngf % kHeadCh == 0) {          // RGB head weights for the vector kernel (else the MFMA path is used)
+        const Param& pw = params[pindex[dec_head.wparam]];
+        HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMalloc((void**)&head_w, (size_t)49 * cfg.ngf * 4 * sizeof(float)));
+        hipLaunchKernelGGL(pack_head_weights_kernel, dim3(64), dim3(256), 0, s, stage, head_w, cfg.ngf);
+        check_launch("pack_head_weights");
+        HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        vector_head = false;
     }
     HIP_TRY(hipFree(stage));
     for (auto& p : params) { std::vector<float>().swap(p.host); }   // host copies no longer needed
@@ -941,6 +954,19 @@ void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* t
         finish_stats(ctx, a, R[i], B, hh * ww, cc, part, st.first, st.second);
         cur = R[i]; cal = st.first; cbe = st.second;
     }
+    if (vector_head) {
+        TimeScope ts(ctx, TSNET_T_OTHER);
+        HeadArgs ha{};
+        ha.x = cur; ha.alpha = cal; ha.beta = cbe; ha.w = head_w; ha.bias = dec_head.bias; ha.y = out_rgb;
+        ha.N = B; ha.H = hh; ha.W = ww; ha.C = cc;
+        ha.composite = cfg.pose_composite; ha.fore_x0 = 64; ha.fore_x1 = 192;          // TSNet_pose.py:279
+        for (int c = 0; c < 3; ++c) ha.bg[c] = (-cfg.pose_mean[c]) / 255.0f;             // TSNet_pose.py:276
+        const int tiles = ((ww + kHeadT - 1) / kHeadT) * ((hh + kHeadT - 1) / kHeadT);
+        hipLaunchKernelGGL(head_conv_kernel, dim3(tiles, B), dim3(256), 0, ctx.stream, ha);
+        check_launch("head_conv");
+        last_B = B;
+        return;
+    }
     ConvCall hd; hd.x = cur; hd.N = B; hd.H = hh; hd.W = ww;
     norm_input(ctx, R[cfg.n_downsampling - 1], cal, cbe, B, hh * ww, cc, hd);
     hd.y = out_rgb; hd.act = 1; hd.out_nchw = 1;
@@ -991,6 +1017,7 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
         e->h = cfg->height / ds; e->w = cfg->width / ds; e->P = e->h * e->w;
         e->build_layers();
         { const char* lg = getenv("TSNET_CONV_LEGACY"); e->fuse_norm_in_loader = lg && atoi(lg); }
+        { const char* vh = getenv("TSNET_VECTOR_HEAD"); e->vector_head = !(vh && !atoi(vh)); }
         { const char* k = getenv("TSNET_CONV_KERNEL"); const char* sf = getenv("TSNET_SPLIT_FUSE");
           e->split_fuse = !e->fuse_norm_in_loader && (!k || !strcmp(k, "dma")) && !(sf && !atoi(sf)); }
         *out = e;
@@ -1048,7 +1075,7 @@ int tsnet_finalize(tsnet_handle h, void* stream) {
 
 void tsnet_destroy(tsnet_handle h) {
     if (!h) return;
-    (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
+    (void)hipFree(h->head_w); (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
     delete h;
 }
 
