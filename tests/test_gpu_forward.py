@@ -133,3 +133,50 @@ def test_error_behaviour(cfg0):
     with pytest.raises(RuntimeError, match="max_batch"):
         eng.forward(big, [torch.zeros(5, 2, 256, 256, device=DEV)] * 3, [torch.zeros(5, 256, 256, device=DEV)] * 3,
                     torch.zeros(5, 2, 256, 256, device=DEV), torch.zeros(5, 256, 256, device=DEV))
+
+
+# ---- the other BASELINE.json configs as parity cases (fp32 path; compared with the oracle run on this host)
+def _oracle_case(cfg, B, H, W, wseed, iseed, bias_std=0.02, mask="box"):
+    sd = O.synth_state_dict(cfg, seed=wseed, bias_std=bias_std)
+    inp = O.synth_inputs(cfg, B, H, W, seed=iseed, mask_mode=mask)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = O.tsnet_forward(sd, cfg, *inp)
+    return sd, inp, ref
+
+
+def test_cfg2_shape_face_checkpoint_schema_b8():
+    """configs[2] shape: face model with n_blocks=4 (demo_face.py:30-33), B=8, synthetic checkpoint incl. biases."""
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=4, n_source=3)
+    sd, inp, ref = _oracle_case(cfg, 8, 256, 256, 21, 22)
+    eng = Hh.make_engine(cfg, sd, 256, 256, 8, DEV)
+    rec, flows = Hh.run_engine(eng, inp, DEV)
+    d = (rec - ref["rec_tar_img"]).abs().max().item()
+    df = max((a - b).abs().max().item() for a, b in zip(flows, ref["flows"]))
+    print(f"[cfg2-shape] d_rec={d:.2e} d_flow={df:.2e}")
+    assert d <= TOL_REC and df <= TOL_FLOW
+    eng.close()
+
+
+def test_cfg3_shape_pose_l25():
+    """configs[3] per-GPU shard: TSNet_pose shape (L=25, n_blocks=4, use_mask), B=4 per GPU."""
+    cfg = O.TSNetConfig(label_nc=25, n_blocks=4, n_source=3, pose=True)
+    sd, inp, ref = _oracle_case(cfg, 4, 256, 256, 23, 24)
+    eng = Hh.make_engine(cfg, sd, 256, 256, 4, DEV)
+    rec, _ = Hh.run_engine(eng, inp, DEV, return_flow=False)
+    d = (rec - ref["rec_tar_img"]).abs().max().item()
+    print(f"[cfg3-shape] d_rec={d:.2e}")
+    assert d <= TOL_REC
+    eng.close()
+
+
+def test_cfg4_shape_512_k5():
+    """configs[4] shape: 512x512, n_source=5 (P=4096 positions: the fused flow kernel never builds P x P)."""
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=5)
+    sd, inp, ref = _oracle_case(cfg, 1, 512, 512, 25, 26, mask="bernoulli")
+    eng = Hh.make_engine(cfg, sd, 512, 512, 1, DEV)
+    rec, flows = Hh.run_engine(eng, inp, DEV)
+    d = (rec - ref["rec_tar_img"]).abs().max().item()
+    df = max((a - b).abs().max().item() for a, b in zip(flows, ref["flows"]))
+    print(f"[cfg4-shape] d_rec={d:.2e} d_flow={df:.2e}")
+    assert d <= TOL_REC and df <= TOL_FLOW
+    eng.close()

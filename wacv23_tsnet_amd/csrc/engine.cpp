@@ -955,7 +955,7 @@ void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* t
         cur = R[i]; cal = st.first; cbe = st.second;
     }
     if (vector_head) {
-        TimeScope ts(ctx, TSNET_T_OTHER);
+        TimeScope ts(ctx, TSNET_T_CONV);     // it is a convolution: keep it in the conv class for the roofline accounting
         HeadArgs ha{};
         ha.x = cur; ha.alpha = cal; ha.beta = cbe; ha.w = head_w; ha.bias = dec_head.bias; ha.y = out_rgb;
         ha.N = B; ha.H = hh; ha.W = ww; ha.C = cc;
