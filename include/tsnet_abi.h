@@ -140,6 +140,10 @@ int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin,
                     const float* w_oihw, const float* bias, int Cout, int ksize, int stride, int pad, int pad_mode,
                     const float* in_alpha, const float* in_beta, int in_relu, int act,
                     float* y, void* stream);
+/* Same convolution on the bf16x3 kernel (conv_x3.hpp): x and w are split into three bf16 planes on the
+ * device first; tile = -1 (heuristic) or an index into the kernel's tile table.  No input transform. */
+int tsnet_op_conv2d_x3(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
+                       int ksize, int stride, int pad, int pad_mode, int tile, float* y, void* stream);
 int tsnet_op_instnorm_stats(const float* x, int N, int HW, int C, float* alpha, float* beta, void* stream);
 int tsnet_op_norm_act(const float* x, const float* alpha, const float* beta, int relu, const float* resid,
                       int N, int HW, int C, float* y, void* stream);
@@ -157,7 +161,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
                      int variant, int iters, float* ms_out, void* stream);
 
 /* Conv launch counters since the last reset: out[0] = conv_glds kernels, out[1] = conv_igemm (register-staged),
- * out[2] = conv_dma (default, buffer-descriptor LDS-DMA); out[3] reserved.  Diagnostic. */
+ * out[2] = conv_dma (buffer-descriptor LDS-DMA, fp32 MFMA); out[3] = conv_x3 (bf16x3).  Diagnostic. */
 void tsnet_debug_counters(int64_t out[4], int reset);
 
 /* Host-side constant tables, exported so CPU tests can pin them against torch:

@@ -51,7 +51,7 @@ const char* g_error = nullptr;
 // block barrier
 int g_bar_count = 0; unsigned g_bar_gen = 0;
 // wave rendezvous
-struct WaveState { int count = 0; unsigned gen = 0; float a[2][64], b[2][64]; const void* gp[2][64]; void* lp[2][64]; int alive = 0; };
+struct WaveState { int count = 0; unsigned gen = 0; float a[2][64], b[2][64]; const void* gp[2][64]; void* lp[2][64]; unsigned short ha[2][64][8], hb[2][64][8]; int alive = 0; };
 std::vector<WaveState> g_waves;
 
 void yield() { emu_switch(&g_fibers[g_cur].sp, g_sched_sp); }
@@ -122,6 +122,26 @@ void global_load_lds(const void* g, void* lds, int size) {
     wave_rendezvous(w);
     // every lane copies its own element to (lane 0's LDS pointer) + lane*size
     memcpy(static_cast<unsigned char*>(w.lp[par][0]) + (size_t)lane * size, w.gp[par][lane], size);
+}
+
+f32x16_t mfma_bf16_32x32x16(const void* a16, const void* b16, f32x16_t c) {
+    // lane l holds A[i = l&31][k = 8*(l>>5) + 0..7] and B[k = 8*(l>>5) + 0..7][j = l&31] as bf16; products are
+    // exact in fp32, accumulated in k order (the hardware's internal order may differ: same error class)
+    WaveState& w = g_waves[g_cur / 64];
+    const int lane = g_cur & 63, par = w.gen & 1;
+    memcpy(w.ha[par][lane], a16, 16);
+    memcpy(w.hb[par][lane], b16, 16);
+    wave_rendezvous(w);
+    const int j = lane & 31, hi = lane >> 5;
+    auto bf = [](unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    f32x16_t d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float t = d[r];
+        for (int k = 0; k < 16; ++k) t = fmaf(bf(w.ha[par][i + 32 * (k >> 3)][k & 7]), bf(w.hb[par][j + 32 * (k >> 3)][k & 7]), t);
+        d[r] = t;
+    }
+    return d;
 }
 
 void buf_dma16(const unsigned char* base, unsigned bytes, unsigned voff, unsigned soff, unsigned char* lds) {

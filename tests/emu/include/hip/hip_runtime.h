@@ -31,6 +31,8 @@ struct dim3 {
 };
 struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+struct uint2 { unsigned x, y; } __attribute__((aligned(8)));
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 
 typedef int hipError_t;
 typedef struct emu_stream* hipStream_t;
@@ -50,6 +52,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 f32x16_t mfma_32x32x2(float a, float b, f32x16_t c);
 void global_load_lds(const void* g, void* lds, int size);
 void buf_dma16(const unsigned char* base, unsigned bytes, unsigned voff, unsigned soff, unsigned char* lds);
+f32x16_t mfma_bf16_32x32x16(const void* a16, const void* b16, f32x16_t c);
 }  // namespace emu
 
 #define threadIdx (emu::g_threadIdx)
@@ -80,6 +83,8 @@ static inline tsnet_rsrc_t tsnet_make_rsrc(const void* p, unsigned bytes) { tsne
 #define TSNET_LDS_BASE(p) ((unsigned char*)(p))
 #define TSNET_BUF_DMA16(rsrc, voff, soff, lds) emu::buf_dma16((rsrc).base, (rsrc).bytes, (voff), (soff), (lds))
 #define TSNET_UNIFORM(x) (x)
+// hook of conv_x3.hpp: v_mfma_f32_32x32x16_bf16 on raw 16-byte operands (8 bf16 per lane)
+#define TSNET_MFMA_BF16(a, b, c) emu::mfma_bf16_32x32x16(&(a), &(b), (c))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

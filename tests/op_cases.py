@@ -147,3 +147,22 @@ def warp_case(lib, dev, B, h, w, C, seed=0):
     assert rc == 0, lib.tsnet_op_last_error().decode()
     _sync(dev)
     return (nchw(out.cpu()) - ref).abs().max().item()
+
+
+def conv_x3_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, tile=-1, bias=True, seed=0):
+    """nn.Conv2d (+padding) on the bf16x3 kernel (3-way bf16 operand split on the bf16 MFMA) vs PyTorch fp32."""
+    x = F.relu(_rand(seed, "x", (N, Cin, H, W), -1.0, 2.0))
+    w = _rand(seed, "w", (Cout, Cin, k, k)) * (2.0 / (Cin * k * k) ** 0.5)
+    b = _rand(seed, "b", (Cout,)) if bias else None
+    if reflect:
+        ref = F.conv2d(F.pad(x, (pad,) * 4, mode="reflect"), w, b, stride=stride)
+    else:
+        ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    Ho, Wo = ref.shape[2:]
+    xd = nhwc(x).to(dev)
+    y = torch.full((N, Ho, Wo, Cout), float("nan"), device=dev)
+    wd, bd = w.to(dev), (b.to(dev) if bias else None)
+    rc = lib.tsnet_op_conv2d_x3(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), _p(bd), Cout, k, stride, pad, int(reflect), tile, y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    return (nchw(y.cpu()) - ref).abs().max().item()

@@ -1,0 +1,378 @@
+// conv_x3.hpp -- fp32-accurate implicit-GEMM convolution on the bf16 MFMA via a 3-way operand split.
+//
+// Every fp32 operand x is stored as three bf16 planes with x == hi + mid + lo EXACTLY (each plane takes
+// the next 8 mantissa bits by truncation).  A product a*b is evaluated as the six bf16 products
+//   lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi          (dropped terms are <= 2^-24 |a||b|)
+// on v_mfma_f32_32x32x16_bf16 (exact bf16 products, fp32 accumulate), 6 MFMAs per 16-deep k-group:
+// 12 matrix-pipe cycles per k instead of 32 on the fp32 MFMA, i.e. a 2.67x higher ceiling (417 TF
+// fp32-equivalent).  tools/probes/bf16x3_probe.hip measured the accuracy on gfx950: mean |err| vs fp64
+// 7.8e-7 against 6.5e-7 for the fp32 MFMA chain at K=4608 -- the same error class, which the 1e-3
+// parity budget needs.  Accumulation is two-level exactly like conv_dma.hpp (fold every 64 products).
+//
+// Structure = conv_dma.hpp: buffer-descriptor LDS-DMA (hardware zero fill for padding), ring of LDS
+// stages with counted vmcnt, one barrier per chunk, source-side swizzle.  Differences: the planes are
+// separate tensors (3 DMAs where the fp32 kernel has 1, but 2-byte elements), an LDS row of a plane is
+// 32 B per 16 k (two 16-byte octets, swizzled by (row>>3)&1), and a wave instruction covers 32 rows.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_dma.hpp"
+
+namespace tsnet {
+
+struct X3Args {
+    const unsigned short* x;    // source 0 planes: (3, N,H,W,Csplit) bf16
+    const unsigned short* x2;   // source 1 planes or null: (3, x2_nmod,H,W,Cin-Csplit)
+    const unsigned short* w;    // packed planes: [3][K/16][Npad][2 swizzled octets][8] bf16
+    const float* bias;
+    float* y;                   // fp32 NHWC output (raw conv result)
+    unsigned short* y3;         // null, or split planes of y (3, N,Ho,Wo,Cout) for a conv that feeds a conv directly
+    double* stat_part;
+    const float* addend; int add_nmod;
+    int N, H, W, Cin, cin_log2, Csplit, x2_nmod;
+    int Ho, Wo, Cout, Npad;
+    int stride, pad, reflect, taps, nchunks, M;   // nchunks in units of 16 k
+    int tiles_m, tiles_n;
+};
+
+#ifndef TSNET_MFMA_BF16
+typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
+#define TSNET_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tsnet_bf16x8, a), __builtin_bit_cast(tsnet_bf16x8, b), c, 0, 0, 0)
+#endif
+
+// exact 3-way split of 4 floats into 3 x 4 bf16 (truncation: every plane holds the next 8 mantissa bits)
+__device__ __forceinline__ void split3_store(float4 v, unsigned short* hi, unsigned short* mid, unsigned short* lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned u = __builtin_bit_cast(unsigned, f[e]);
+        const unsigned uh = u & 0xFFFF0000u;
+        const float r1 = f[e] - __builtin_bit_cast(float, uh);
+        const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, um);
+        h[e] = (unsigned short)(uh >> 16); m[e] = (unsigned short)(um >> 16);
+        l[e] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    }
+    *reinterpret_cast<uint2*>(hi) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(mid) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+    *reinterpret_cast<uint2*>(lo) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+}
+
+// KC = 16-deep k-groups per ring stage (1 or 2); NSTAGE = ring depth
+template <int KS, int BM, int BN, int WARPS_M, int WARPS_N, int KC, int NSTAGE, bool SMALL_CIN>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N)
+void conv_x3_kernel(X3Args a) {
+    constexpr int NW = WARPS_M * WARPS_N;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 32, NTL = WN / 32;
+    // DMA list of one stage: for each k-group g, plane p: BM/32 A instructions then BN/32 B instructions (1 KiB each)
+    constexpr int TA = BM / 32, TB = BN / 32;
+    constexpr int TOT = (TA + TB) * 3 * KC;
+    constexpr int LPC = (TOT + NW - 1) / NW;              // per wave; surplus slots issue an out-of-range (zero) DMA
+    static_assert(LPC * (NSTAGE - 1) < 64, "vmcnt is 6 bits");
+    constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32;   // bytes of one plane of one k-group
+    constexpr int GROUP_BYTES = 3 * (PLANE_A + PLANE_B);
+    constexpr int STAGE_BYTES = KC * GROUP_BYTES + 1024;  // + scratch slot for surplus DMAs
+
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = TSNET_UNIFORM(tid >> 6);
+    const int wm0 = (wave / WARPS_N) * WM;
+    const int wn0 = (wave % WARPS_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nst = (a.nchunks + KC - 1) / KC;            // ring steps
+
+    const int C2 = a.Cin - a.Csplit;
+    const size_t plane1 = (size_t)a.N * a.H * a.W * a.Csplit, plane2 = (size_t)a.x2_nmod * a.H * a.W * C2;
+    const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
+    tsnet_rsrc_t rs1[3], rs2[3], rsw[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        rs1[p] = tsnet_make_rsrc(a.x + p * plane1, (unsigned)(plane1 * 2));
+        rs2[p] = tsnet_make_rsrc(a.x2 ? a.x2 + p * plane2 : a.x, a.x2 ? (unsigned)(plane2 * 2) : 0u);
+        rsw[p] = tsnet_make_rsrc(a.w + p * planew, (unsigned)(planew * 2));
+    }
+    const tsnet_lds_t lds0 = TSNET_LDS_BASE(smem_raw);
+
+    // ---- DMA slots of this wave: slot s = list index s*NW + wave.  A slot's (group, plane, A/B, 32-row block)
+    //      is wave-uniform; per lane only the row (lane>>1) and the physical octet (lane&1) differ.
+    const int row_in = lane >> 1;
+    const int oct_phys = lane & 1;
+    const int oct_log = oct_phys ^ ((row_in >> 3) & 1);    // swizzle: rows r and r+8 of a 16-lane group take different slots
+    int g_pix[TA], g_pix2[TA], g_oy[TA], g_ox[TA];
+    bool g_ok[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {                          // geometry of row block t (every wave may serve any block)
+        const int m = m0 + t * 32 + row_in;
+        g_ok[t] = m < a.M;
+        const int mm = g_ok[t] ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int img = mm / hw;
+        const int rem = mm - img * hw;
+        const int oy = rem / a.Wo;
+        g_pix[t] = img * a.H * a.W;
+        g_pix2[t] = (img % a.x2_nmod) * a.H * a.W;
+        g_oy[t] = oy * a.stride - a.pad;
+        g_ox[t] = (rem - oy * a.Wo) * a.stride - a.pad;
+    }
+    unsigned vA1[TA], vA2[TA];
+    const int cpt_log2 = SMALL_CIN ? 0 : a.cin_log2 - 4;
+    int cur_tap = -1;
+    auto tap_offsets = [&](int tap) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            int iy = g_oy[t] + ky, ix = g_ox[t] + kx;
+            bool ok = g_ok[t] && tap < a.taps;
+            if (a.reflect) {
+                iy = iy < 0 ? -iy : iy;
+                iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+            } else {
+                ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            }
+            const int pix = iy * a.W + ix;
+            vA1[t] = ok ? (unsigned)(((g_pix[t] + pix) * a.Csplit + oct_log * 8) * 2) : kOOB;
+            vA2[t] = ok ? (unsigned)(((g_pix2[t] + pix) * C2 + oct_log * 8) * 2) : kOOB;
+        }
+    };
+    const unsigned vB = (unsigned)((row_in * 2 + oct_phys) * 16);   // weights are packed in image order already
+
+    // issue all DMAs of ring step `st` (k-groups st*KC .. st*KC+KC-1) into ring stage `stage`
+    auto issue_step = [&](int st, int stage) {
+        const tsnet_lds_t ls = lds0 + stage * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < LPC; ++s) {
+            const int idx = s * NW + wave;                  // wave-uniform list index
+            if (idx >= TOT) {                               // surplus slot: zero-fill DMA into the scratch KiB
+                TSNET_BUF_DMA16(rsw[0], kOOB, 0u, ls + KC * GROUP_BYTES);
+                continue;
+            }
+            const int g = idx / ((TA + TB) * 3);
+            const int r1 = idx - g * ((TA + TB) * 3);
+            const int p = r1 / (TA + TB);
+            const int t = r1 - p * (TA + TB);
+            const int kc = st * KC + g;                     // 16-deep k-group index (may run past the end: reads zeros)
+            const tsnet_lds_t lg = ls + g * GROUP_BYTES;
+            if (t < TA) {
+                const tsnet_lds_t dst = lg + p * PLANE_A + t * 1024;
+                if (SMALL_CIN) {
+                    const int k = kc * 16 + oct_log * 8;
+                    const int tap = k >> a.cin_log2, c = k & (a.Cin - 1);
+                    const int ky = tap / KS, kx = tap - ky * KS;
+                    // static block index t: select this lane's geometry by unrolled compare
+                    unsigned v = kOOB;
+#pragma unroll
+                    for (int tt = 0; tt < TA; ++tt) if (tt == t) {
+                        int iy = g_oy[tt] + ky, ix = g_ox[tt] + kx;
+                        bool ok = g_ok[tt] && tap < a.taps;
+                        if (a.reflect) {
+                            iy = iy < 0 ? -iy : iy; iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+                            ix = ix < 0 ? -ix : ix; ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+                        } else {
+                            ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                        }
+                        if (ok) v = (unsigned)(((g_pix[tt] + iy * a.W + ix) * a.Csplit + c) * 2);
+                    }
+                    TSNET_BUF_DMA16(rs1[p], v, 0u, dst);
+                } else {
+                    const int tap = kc >> cpt_log2;
+                    const int c0 = (kc << 4) & (a.Cin - 1);
+                    if (tap != cur_tap) { cur_tap = tap; tap_offsets(tap); }
+                    unsigned v1 = kOOB, v2 = kOOB;
+#pragma unroll
+                    for (int tt = 0; tt < TA; ++tt) if (tt == t) { v1 = vA1[tt]; v2 = vA2[tt]; }
+                    if (c0 < a.Csplit) TSNET_BUF_DMA16(rs1[p], v1, (unsigned)(c0 * 2), dst);
+                    else TSNET_BUF_DMA16(rs2[p], v2, (unsigned)((c0 - a.Csplit) * 2), dst);
+                }
+            } else {
+                const int tb = t - TA;
+                const tsnet_lds_t dst = lg + 3 * PLANE_A + p * PLANE_B + tb * 1024;
+                const unsigned so = (unsigned)(((size_t)kc * a.Npad + n0 + tb * 32) * 32);
+                TSNET_BUF_DMA16(rsw[p], vB, so, dst);
+            }
+        }
+    };
+
+    f32x16 acc[MT][NTL], tot[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+    // read side: lane (li, lh) needs octet lh (k = 8*lh .. 8*lh+7) of row/col w?0 + t*32 + li
+    const int oct_r = lh ^ ((li >> 3) & 1);
+    const int a_off = (wm0 + li) * 32 + oct_r * 16;         // byte offset inside a plane
+    const int b_off = (wn0 + li) * 32 + oct_r * 16;
+
+    // kept as a lambda inlined at 4 call sites so stage indices and the fold flag are constants
+    auto step = [&](int st, int stage, int refill_stage, bool first, bool do_refill) {
+        TSNET_VMCNT(LPC * (NSTAGE - 2));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned char* sbase = smem_raw + stage * STAGE_BYTES;
+#pragma unroll
+        for (int g = 0; g < KC; ++g) {
+            const unsigned char* gb = sbase + g * GROUP_BYTES;
+            F4 af[3][MT], bf[3][NTL];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[p][i] = *reinterpret_cast<const F4*>(gb + p * PLANE_A + i * 1024 + a_off);
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) bf[p][j] = *reinterpret_cast<const F4*>(gb + 3 * PLANE_A + p * PLANE_B + j * 1024 + b_off);
+            }
+            if (g == 0 && do_refill) issue_step(st + NSTAGE - 1, refill_stage);
+            // six products per tile, small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        if (first && g == 0 && q == 0) {
+                            f32x16 z;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                            acc[i][j] = TSNET_MFMA_BF16(af[PA[q]][i], bf[PB[q]][j], z);
+                        } else {
+                            acc[i][j] = TSNET_MFMA_BF16(af[PA[q]][i], bf[PB[q]][j], acc[i][j]);
+                        }
+                    }
+        }
+    };
+
+    // The loop is unrolled by NSTAGE ring steps (stage indices become constants); the fmaf chain is folded
+    // into the running total once per unrolled group, i.e. every NSTAGE*KC*16 = 48..128 products.
+    static_assert(NSTAGE == 3 || NSTAGE == 4, "ring depth");
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) issue_step(s, s);     // steps past the end read zeros (OOB / K-padded weights)
+    for (int st = 0; st < nst; st += NSTAGE) {
+        step(st, 0, NSTAGE - 1, true, true);
+        if (st + 1 < nst) step(st + 1, 1, 0, false, true);
+        if (st + 2 < nst) step(st + 2, 2, 1, false, true);
+        if (NSTAGE == 4 && st + 3 < nst) step(st + 3, 3, 2, false, true);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];
+    }
+    TSNET_VMCNT(0);
+
+    // ---- epilogue (as conv_dma.hpp, plus the optional split-plane copy of the output)
+    const int hw = a.Ho * a.Wo;
+    double csum[NTL], csq[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) { csum[j] = 0.0; csq[j] = 0.0; }
+    const size_t yplane = (size_t)a.M * a.Cout;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int n = n0 + wn0 + j * 32 + li;
+            const bool nok = n < a.Cout;
+            const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = tot[i][j][r] + bv;
+                if (a.addend && nok && m < a.M) {
+                    const int img = m / hw;
+                    v += a.addend[((size_t)(img % a.add_nmod) * hw + (m - img * hw)) * a.Cout + n];
+                }
+                if (a.stat_part && m < a.M) { csum[j] += (double)v; csq[j] += (double)v * (double)v; }
+                if (!nok || m >= a.M) continue;
+                if (a.y) a.y[(size_t)m * a.Cout + n] = v;
+                if (a.y3) {
+                    const unsigned u = __builtin_bit_cast(unsigned, v);
+                    const unsigned uh = u & 0xFFFF0000u;
+                    const float r1 = v - __builtin_bit_cast(float, uh);
+                    const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+                    const float r2 = r1 - __builtin_bit_cast(float, um);
+                    const size_t o = (size_t)m * a.Cout + n;
+                    a.y3[o] = (unsigned short)(uh >> 16);
+                    a.y3[yplane + o] = (unsigned short)(um >> 16);
+                    a.y3[2 * yplane + o] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+                }
+            }
+        }
+    }
+    if (a.stat_part) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem_raw);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const double s2 = csum[j] + __shfl_xor(csum[j], 32);
+            const double q2 = csq[j] + __shfl_xor(csq[j], 32);
+            if (lh == 0) {
+                double* o = red + ((size_t)(wave / WARPS_N) * BN + wn0 + j * 32 + li) * 2;
+                o[0] = s2; o[1] = q2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Cout) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int wmi = 0; wmi < WARPS_M; ++wmi) { s += red[((size_t)wmi * BN + tid) * 2]; q += red[((size_t)wmi * BN + tid) * 2 + 1]; }
+            const int img = m0 / hw;
+            const int tile_in_img = (m0 - img * hw) / BM;
+            const int tiles_per_img = hw / BM;
+            double* o = a.stat_part + (((size_t)img * tiles_per_img + tile_in_img) * a.Cout + n0 + tid) * 2;
+            o[0] = s; o[1] = q;
+        }
+    }
+}
+
+// OIHW fp32 -> three bf16 planes in image order: plane p, k-group kc, column n, physical octet o, element e:
+//   out[p][((kc*Npad + n)*2 + o)*8 + e] = part_p( W[k = kc*16 + (o ^ ((n>>3)&1))*8 + e][n] )
+__global__ void pack_weights_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                       int cout, int cin_real, int cin_pad, int ks, int kpad, int npad, int cin_total, int cin_off) {
+    const size_t plane = (size_t)kpad * npad;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 7;
+        const int o = (idx >> 3) & 1;
+        const size_t rest = idx >> 4;
+        const int n = (int)(rest % npad);
+        const int kc = (int)(rest / npad);
+        const int k = kc * 16 + (o ^ ((n >> 3) & 1)) * 8 + e;
+        const int tap = k / cin_pad, c = k - tap * cin_pad;
+        float v = 0.f;
+        if (tap < ks * ks && c < cin_real && n < cout) {
+            const int ky = tap / ks, kx = tap - ky * ks;
+            v = w[(((size_t)n * cin_total + cin_off + c) * ks + ky) * ks + kx];
+        }
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const unsigned uh = u & 0xFFFF0000u;
+        const float r1 = v - __builtin_bit_cast(float, uh);
+        const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, um);
+        out[idx] = (unsigned short)(uh >> 16);
+        out[plane + idx] = (unsigned short)(um >> 16);
+        out[2 * plane + idx] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    }
+}
+
+// fp32 NHWC tensor -> three bf16 planes (stand-alone converter; producers normally write planes directly)
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, size_t total4) {
+    const size_t plane = total4 * 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x)
+        split3_store(reinterpret_cast<const float4*>(x)[i], out + i * 4, out + plane + i * 4, out + 2 * plane + i * 4);
+}
+
+}  // namespace tsnet

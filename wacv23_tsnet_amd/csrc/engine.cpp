@@ -30,6 +30,7 @@
 #include "conv_dma.hpp"
 #include "conv_glds.hpp"
 #include "conv_igemm.hpp"
+#include "conv_x3.hpp"
 #include "flow_warp.hpp"
 #include "head_conv.hpp"
 #include "norm_elementwise.hpp"
@@ -127,6 +128,7 @@ struct ConvLayer {
     size_t w_off = 0, w2_off = 0, b_off = 0;  // offsets (floats) into the packed buffer
     const float* w = nullptr;     // device, packed for conv_igemm_kernel  [K/4][Npad][4]
     const float* w2 = nullptr;    // device, packed for conv_glds_kernel   [K/16][Npad][4 swizzled quads][4]
+    const unsigned short* w3 = nullptr;   // device, bf16x3 planes for conv_x3_kernel [3][K/16][Npad][2 octets][8]
     const float* bias = nullptr;  // device (cout)
 };
 
@@ -357,6 +359,97 @@ void launch_glds_ks(GldsArgs a, int forced_tile, hipStream_t s) {
         case 4: launch_glds_t<KS, 128, 128, 4, 2>(a, s); break;
         default: launch_glds_t<KS, 128, 128, 2, 4>(a, s); break;
     }
+}
+
+// ---- bf16x3 kernel (conv_x3.hpp)
+struct XTileCfg { int bm, bn, wm, wn, kc, nstage; double eff; };
+const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, 1.0}, {128, 128, 2, 2, 1, 4, 0.0}, {128, 128, 2, 2, 2, 3, 0.0},
+                            {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, 0.95}, {64, 64, 2, 2, 1, 4, 0.9}};
+constexpr int kNumXTiles = 6;
+
+template <int KS, int BM, int BN, int WM_, int WN_, int KC, int NST>
+void launch_x3_t(const X3Args& a, hipStream_t s) {
+    const size_t lds = (size_t)NST * ((size_t)KC * 3 * (BM + BN) * 32 + 1024);
+    const bool small = a.Cin < 16;
+    auto kern = small ? conv_x3_kernel<KS, BM, BN, WM_, WN_, KC, NST, true> : conv_x3_kernel<KS, BM, BN, WM_, WN_, KC, NST, false>;
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
+}
+
+template <int KS>
+int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stats partials per image (0 = none)
+    int best = forced_tile;
+    if (best < 0) {
+        const char* e_tile = getenv("TSNET_X3_TILE");
+        double best_cost = 0;
+        for (int i = 0; i < kNumXTiles; ++i) {
+            if (a.Npad % kXTiles[i].bn) continue;
+            if (e_tile && atoi(e_tile) == i) { best = i; break; }
+            if (kXTiles[i].eff <= 0 || (kXTiles[i].bn > 32 && a.Cout <= kXTiles[i].bn / 2)) continue;
+            const long tm = (a.M + kXTiles[i].bm - 1) / kXTiles[i].bm, tn = (a.Cout + kXTiles[i].bn - 1) / kXTiles[i].bn;
+            const double cost = (double)((tm * tn + 255) / 256) * kXTiles[i].bm * kXTiles[i].bn / kXTiles[i].eff;
+            if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+        }
+    }
+    if (best < 0 || best >= kNumXTiles || a.Npad % kXTiles[best].bn) throw ArgError("conv(x3): no tile configuration");
+    a.tiles_m = (a.M + kXTiles[best].bm - 1) / kXTiles[best].bm;
+    a.tiles_n = (a.Cout + kXTiles[best].bn - 1) / kXTiles[best].bn;
+    const int hw = a.Ho * a.Wo;
+    if (hw % kXTiles[best].bm) a.stat_part = nullptr;
+    switch (best) {
+        case 0: launch_x3_t<KS, 128, 128, 2, 2, 1, 3>(a, s); break;
+        case 1: launch_x3_t<KS, 128, 128, 2, 2, 1, 4>(a, s); break;
+        case 2: launch_x3_t<KS, 128, 128, 2, 2, 2, 3>(a, s); break;
+        case 3: launch_x3_t<KS, 128, 128, 4, 2, 2, 3>(a, s); break;
+        case 4: launch_x3_t<KS, 128, 64, 2, 2, 1, 4>(a, s); break;
+        default: launch_x3_t<KS, 64, 64, 2, 2, 1, 4>(a, s); break;
+    }
+    return a.stat_part ? hw / kXTiles[best].bm : 0;
+}
+
+struct X3Call {
+    const unsigned short* x3 = nullptr; const unsigned short* x23 = nullptr;   // split planes of the input(s)
+    int N = 0, H = 0, W = 0, csplit = 0, x2_nmod = 1;
+    float* y = nullptr; unsigned short* y3 = nullptr;
+    const float* addend = nullptr; int add_nmod = 1;
+    double* stat_part = nullptr; mutable int stat_S = 0;
+    int variant = -1;
+};
+
+void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
+    X3Args g{};
+    g.x = c.x3; g.x2 = c.x23; g.w = L.w3; g.bias = L.bias; g.y = c.y; g.y3 = c.y3;
+    g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
+    g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
+    g.Csplit = c.x23 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
+    g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
+    g.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
+    g.Cout = L.cout; g.Npad = L.npad;
+    g.stride = L.stride; g.pad = L.pad; g.reflect = L.reflect;
+    g.taps = L.ks * L.ks; g.nchunks = (g.taps * g.Cin + 15) / 16;
+    g.M = c.N * g.Ho * g.Wo;
+    if (!L.w3) throw ArgError("conv(x3): layer has no bf16x3 weights");
+    if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
+    if ((g.Csplit & 15) && c.x23) throw ArgError("conv(x3): channel split must be a multiple of 16");
+    if ((double)c.N * c.H * c.W * L.cin_pad * 2 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
+        throw ArgError("conv(x3): tensor too large for 32-bit buffer offsets");
+    TimeScope ts(ctx, TSNET_T_CONV);
+    const int forced = c.variant >= 0 ? (c.variant & 7) : -1;
+    switch (L.ks) {
+        case 1: c.stat_S = launch_x3_ks<1>(g, forced, ctx.stream); break;
+        case 3: c.stat_S = launch_x3_ks<3>(g, forced, ctx.stream); break;
+        case 7: c.stat_S = launch_x3_ks<7>(g, forced, ctx.stream); break;
+        default: throw ArgError("conv: kernel size must be 1, 3 or 7");
+    }
+    check_launch("conv_x3");
+    ++g_launch_counters[3];
+}
+
+void run_split3(Ctx& ctx, const float* x, unsigned short* out, size_t elems) {
+    if (elems & 3) throw ArgError("split3: element count must be a multiple of 4");
+    TimeScope ts(ctx, TSNET_T_ELEMWISE);
+    hipLaunchKernelGGL(split3_kernel, dim3(ew_grid(elems / 4)), dim3(256), 0, ctx.stream, x, out, elems / 4);
+    check_launch("split3");
 }
 
 bool use_glds_path(const ConvLayer& L, const ConvCall& c) {
@@ -1221,6 +1314,37 @@ int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w
     OP_END
 }
 
+int tsnet_op_conv2d_x3(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
+                       int ksize, int stride, int pad, int pad_mode, int tile, float* y, void* stream) {
+    OP_BEGIN
+    if (!x || !w_oihw || !y) throw ArgError("null tensor");
+    if (Cin < 8 || (Cin & (Cin - 1))) throw ArgError("conv2d_x3 op: Cin must be a power of two >= 8");
+    hipStream_t s = (hipStream_t)stream;
+    Ctx ctx; ctx.stream = s;
+    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
+    L.reflect = pad_mode; L.kpad = conv_kpad(ksize, Cin); L.npad = conv_npad(Cout);
+    const size_t wn = (size_t)Cout * Cin * ksize * ksize, xn = (size_t)N * H * W * Cin;
+    float *wd = nullptr, *bd = nullptr; unsigned short *w3 = nullptr, *x3 = nullptr;
+    HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&w3, (size_t)L.kpad * L.npad * 6));
+    HIP_TRY(hipMalloc((void**)&x3, xn * 6));
+    HIP_TRY(hipMemcpy(wd, w_oihw, wn * sizeof(float), hipMemcpyDefault));
+    hipLaunchKernelGGL(pack_weights_x3_kernel, dim3(ew_grid((size_t)L.kpad * L.npad)), dim3(256), 0, s, wd, w3,
+                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, Cin, 0);
+    check_launch("pack_weights_x3");
+    if (bias) {
+        HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
+        HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
+    }
+    run_split3(ctx, x, x3, xn);
+    L.w3 = w3; L.bias = bd;
+    X3Call c; c.x3 = x3; c.N = N; c.H = H; c.W = W; c.y = y; c.variant = tile;
+    run_conv_x3(ctx, L, c);
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(wd); (void)hipFree(w3); (void)hipFree(x3); (void)hipFree(bd);
+    OP_END
+}
+
 int tsnet_op_instnorm_stats(const float* x, int N, int HW, int C, float* alpha, float* beta, void* stream) {
     OP_BEGIN
     if (!x || !alpha || !beta) throw ArgError("null tensor");
@@ -1309,6 +1433,26 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     };
     fill(x, xn, 2.f, 0.f); fill(w, wn, 0.1f, 0.f); fill(al, (size_t)N * Cin, 1.f, 1.f); fill(be, (size_t)N * Cin, 0.5f, 0.f);
     L.w = w; L.w2 = w; L.bias = nullptr;   // timing only: both kernels stream the same random buffer
+    if (variant >= 0 && (variant & 8192)) {        // bf16x3 kernel: split the same random operands into planes
+        unsigned short *x3 = nullptr, *w3 = nullptr;
+        HIP_TRY(hipMalloc((void**)&x3, xn * 6)); HIP_TRY(hipMalloc((void**)&w3, wn * 6));
+        run_split3(ctx, x, x3, xn); run_split3(ctx, w, w3, wn);
+        L.w3 = w3;
+        X3Call xc; xc.x3 = x3; xc.N = N; xc.H = H; xc.W = W; xc.y = y; xc.variant = variant;
+        for (int i = 0; i < 2; ++i) run_conv_x3(ctx, L, xc);
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) run_conv_x3(ctx, L, xc);
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(al); (void)hipFree(be); (void)hipFree(x3); (void)hipFree(w3);
+        return TSNET_OK;
+    }
     ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.variant = variant;
     if (norm) { c.alpha = al; c.beta = be; c.in_relu = 1; }
     for (int i = 0; i < 2; ++i) run_conv(ctx, L, c);
