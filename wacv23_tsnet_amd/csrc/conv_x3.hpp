@@ -66,10 +66,13 @@ void conv_x3_kernel(X3Args a) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 32, NTL = WN / 32;
-    // DMA list of one stage: for each k-group g, plane p: BM/32 A instructions then BN/32 B instructions (1 KiB each)
-    constexpr int TA = BM / 32, TB = BN / 32;
-    constexpr int TOT = (TA + TB) * 3 * KC;
-    constexpr int LPC = (TOT + NW - 1) / NW;              // per wave; surplus slots issue an out-of-range (zero) DMA
+    // DMA list of one (k-group, plane): TA = BM/32 A blocks then TB = BN/32 B blocks, 1 KiB each.  Wave w serves
+    // entries e = r*NW + w, r < R; entries past the list are zero-fill DMAs into a scratch KiB so that every wave
+    // issues the same, compile-time number of loads per ring step (the vmcnt arithmetic needs that).
+    constexpr int TA = BM / 32, TB = BN / 32, E = TA + TB;
+    constexpr int R = (E + NW - 1) / NW;
+    constexpr int RA = (TA + NW - 1) / NW;                // entries r < RA may be A blocks
+    constexpr int LPC = R * 3 * KC;
     static_assert(LPC * (NSTAGE - 1) < 64, "vmcnt is 6 bits");
     constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32;   // bytes of one plane of one k-group
     constexpr int GROUP_BYTES = 3 * (PLANE_A + PLANE_B);
@@ -105,36 +108,37 @@ void conv_x3_kernel(X3Args a) {
     }
     const tsnet_lds_t lds0 = TSNET_LDS_BASE(smem_raw);
 
-    // ---- DMA slots of this wave: slot s = list index s*NW + wave.  A slot's (group, plane, A/B, 32-row block)
-    //      is wave-uniform; per lane only the row (lane>>1) and the physical octet (lane&1) differ.
+    // ---- per-lane geometry of the A row blocks this wave serves (block t = r*NW + wave; row = lane>>1,
+    //      physical octet = lane&1, logical octet swizzled so rows r and r+8 of a 16-lane read group differ)
     const int row_in = lane >> 1;
     const int oct_phys = lane & 1;
-    const int oct_log = oct_phys ^ ((row_in >> 3) & 1);    // swizzle: rows r and r+8 of a 16-lane group take different slots
-    int g_pix[TA], g_pix2[TA], g_oy[TA], g_ox[TA];
-    bool g_ok[TA];
+    const int oct_log = oct_phys ^ ((row_in >> 3) & 1);
+    int g_pix[RA], g_pix2[RA], g_oy[RA], g_ox[RA];
+    bool g_ok[RA];
 #pragma unroll
-    for (int t = 0; t < TA; ++t) {                          // geometry of row block t (every wave may serve any block)
-        const int m = m0 + t * 32 + row_in;
-        g_ok[t] = m < a.M;
-        const int mm = g_ok[t] ? m : 0;
+    for (int r = 0; r < RA; ++r) {
+        const int m = m0 + (r * NW + wave) * 32 + row_in;
+        g_ok[r] = m < a.M && (r * NW + wave) < TA;
+        const int mm = g_ok[r] ? m : 0;
         const int hw = a.Ho * a.Wo;
         const int img = mm / hw;
         const int rem = mm - img * hw;
         const int oy = rem / a.Wo;
-        g_pix[t] = img * a.H * a.W;
-        g_pix2[t] = (img % a.x2_nmod) * a.H * a.W;
-        g_oy[t] = oy * a.stride - a.pad;
-        g_ox[t] = (rem - oy * a.Wo) * a.stride - a.pad;
+        g_pix[r] = img * a.H * a.W;
+        g_pix2[r] = (img % a.x2_nmod) * a.H * a.W;
+        g_oy[r] = oy * a.stride - a.pad;
+        g_ox[r] = (rem - oy * a.Wo) * a.stride - a.pad;
     }
-    unsigned vA1[TA], vA2[TA];
+    unsigned vA1[RA], vA2[RA];
     const int cpt_log2 = SMALL_CIN ? 0 : a.cin_log2 - 4;
     int cur_tap = -1;
-    auto tap_offsets = [&](int tap) {
+    // byte offsets of (row, tap) inside one plane of source 0 / source 1; kOOB = read zeros
+    auto tap_offsets = [&](int tap, int c_lane) {
         const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            int iy = g_oy[t] + ky, ix = g_ox[t] + kx;
-            bool ok = g_ok[t] && tap < a.taps;
+        for (int r = 0; r < RA; ++r) {
+            int iy = g_oy[r] + ky, ix = g_ox[r] + kx;
+            bool ok = g_ok[r] && tap < a.taps;
             if (a.reflect) {
                 iy = iy < 0 ? -iy : iy;
                 iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
@@ -144,64 +148,50 @@ void conv_x3_kernel(X3Args a) {
                 ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             }
             const int pix = iy * a.W + ix;
-            vA1[t] = ok ? (unsigned)(((g_pix[t] + pix) * a.Csplit + oct_log * 8) * 2) : kOOB;
-            vA2[t] = ok ? (unsigned)(((g_pix2[t] + pix) * C2 + oct_log * 8) * 2) : kOOB;
+            vA1[r] = ok ? (unsigned)(((g_pix[r] + pix) * a.Csplit + c_lane) * 2) : kOOB;
+            vA2[r] = ok ? (unsigned)(((g_pix2[r] + pix) * C2 + c_lane) * 2) : kOOB;
         }
     };
-    const unsigned vB = (unsigned)((row_in * 2 + oct_phys) * 16);   // weights are packed in image order already
+    const unsigned vB = (unsigned)(lane * 16);              // weights are packed in image order already
 
     // issue all DMAs of ring step `st` (k-groups st*KC .. st*KC+KC-1) into ring stage `stage`
     auto issue_step = [&](int st, int stage) {
         const tsnet_lds_t ls = lds0 + stage * STAGE_BYTES;
 #pragma unroll
-        for (int s = 0; s < LPC; ++s) {
-            const int idx = s * NW + wave;                  // wave-uniform list index
-            if (idx >= TOT) {                               // surplus slot: zero-fill DMA into the scratch KiB
-                TSNET_BUF_DMA16(rsw[0], kOOB, 0u, ls + KC * GROUP_BYTES);
-                continue;
-            }
-            const int g = idx / ((TA + TB) * 3);
-            const int r1 = idx - g * ((TA + TB) * 3);
-            const int p = r1 / (TA + TB);
-            const int t = r1 - p * (TA + TB);
-            const int kc = st * KC + g;                     // 16-deep k-group index (may run past the end: reads zeros)
+        for (int g = 0; g < KC; ++g) {
+            const int kc = st * KC + g;                     // 16-deep k-group (past the end: everything reads zeros)
             const tsnet_lds_t lg = ls + g * GROUP_BYTES;
-            if (t < TA) {
-                const tsnet_lds_t dst = lg + p * PLANE_A + t * 1024;
-                if (SMALL_CIN) {
-                    const int k = kc * 16 + oct_log * 8;
-                    const int tap = k >> a.cin_log2, c = k & (a.Cin - 1);
-                    const int ky = tap / KS, kx = tap - ky * KS;
-                    // static block index t: select this lane's geometry by unrolled compare
-                    unsigned v = kOOB;
-#pragma unroll
-                    for (int tt = 0; tt < TA; ++tt) if (tt == t) {
-                        int iy = g_oy[tt] + ky, ix = g_ox[tt] + kx;
-                        bool ok = g_ok[tt] && tap < a.taps;
-                        if (a.reflect) {
-                            iy = iy < 0 ? -iy : iy; iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
-                            ix = ix < 0 ? -ix : ix; ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
-                        } else {
-                            ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                        }
-                        if (ok) v = (unsigned)(((g_pix[tt] + iy * a.W + ix) * a.Csplit + c) * 2);
-                    }
-                    TSNET_BUF_DMA16(rs1[p], v, 0u, dst);
-                } else {
-                    const int tap = kc >> cpt_log2;
-                    const int c0 = (kc << 4) & (a.Cin - 1);
-                    if (tap != cur_tap) { cur_tap = tap; tap_offsets(tap); }
-                    unsigned v1 = kOOB, v2 = kOOB;
-#pragma unroll
-                    for (int tt = 0; tt < TA; ++tt) if (tt == t) { v1 = vA1[tt]; v2 = vA2[tt]; }
-                    if (c0 < a.Csplit) TSNET_BUF_DMA16(rs1[p], v1, (unsigned)(c0 * 2), dst);
-                    else TSNET_BUF_DMA16(rs2[p], v2, (unsigned)((c0 - a.Csplit) * 2), dst);
-                }
+            unsigned so_a = 0;
+            bool second = false;
+            if (SMALL_CIN) {                                // Cin = 8: the two octets of a row are two different taps
+                const int k = kc * 16 + oct_log * 8;
+                tap_offsets(k >> a.cin_log2, k & (a.Cin - 1));
             } else {
-                const int tb = t - TA;
-                const tsnet_lds_t dst = lg + 3 * PLANE_A + p * PLANE_B + tb * 1024;
-                const unsigned so = (unsigned)(((size_t)kc * a.Npad + n0 + tb * 32) * 32);
-                TSNET_BUF_DMA16(rsw[p], vB, so, dst);
+                const int tap = kc >> cpt_log2;             // wave-uniform
+                const int c0 = (kc << 4) & (a.Cin - 1);
+                if (tap != cur_tap) { cur_tap = tap; tap_offsets(tap, oct_log * 8); }
+                second = c0 >= a.Csplit;
+                so_a = (unsigned)((second ? c0 - a.Csplit : c0) * 2);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = r * NW + wave;            // wave-uniform list entry
+                    if (r < RA && e < TA) {
+                        const tsnet_lds_t dst = lg + p * PLANE_A + e * 1024;
+                        if (second) TSNET_BUF_DMA16(rs2[p], vA2[r < RA ? r : 0], so_a, dst);
+                        else TSNET_BUF_DMA16(rs1[p], vA1[r < RA ? r : 0], so_a, dst);
+                    } else if (e < E) {
+                        const int tb = e - TA;
+                        const tsnet_lds_t dst = lg + 3 * PLANE_A + p * PLANE_B + tb * 1024;
+                        const unsigned so = (unsigned)((kc * a.Npad + n0 + tb * 32) * 32);
+                        TSNET_BUF_DMA16(rsw[p], vB, so, dst);
+                    } else {
+                        const unsigned oob = kOOB;
+                        TSNET_BUF_DMA16(rsw[p], oob, 0u, ls + KC * GROUP_BYTES);     // surplus slot: zero fill into the scratch KiB
+                    }
+                }
             }
         }
     };
