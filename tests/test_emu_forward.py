@@ -102,3 +102,36 @@ def test_vector_rgb_head(emu_lib, pose):
     if pose:
         assert torch.equal(rec[..., :64], ref[..., :64])
     eng.close()
+
+
+def test_bf16x3_schedule(emu_lib, monkeypatch):
+    """ngf=16 selects the bf16x3 schedule (conv_x3.hpp: every conv input as three bf16 planes, written by the
+    producers).  Every conv must run on it, the result must match the oracle like the fp32-MFMA schedule does,
+    and the two schedules must agree closely with each other."""
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=1, n_source=2, ngf=16, enc_blocks=1, fuse_ngf=256)
+    sd = O.synth_state_dict(cfg, seed=12, bias_std=0.02)
+    sd = {k: (v * 3 if k.endswith("weight") else v) for k, v in sd.items()}
+    inp = O.synth_inputs(cfg, 2, 32, 32, seed=13, mask_mode="box")
+    ref = O.tsnet_forward(sd, cfg, *inp, want_stages=True)
+    eng = Hh.make_engine(cfg, sd, 32, 32, 2, "cpu", lib=emu_lib)
+    emu_lib.tsnet_debug_counters(None, 1)
+    rec, flows = Hh.run_engine(eng, inp, "cpu")
+    cnt = (C.c_int64 * 4)()
+    emu_lib.tsnet_debug_counters(cnt, 1)
+    assert cnt[3] > 0 and cnt[2] == 0 and cnt[1] == 0 and cnt[0] == 0
+    assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
+    rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, 2, "cpu")
+    assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4
+    # clip mode on the x3 schedule
+    eng.set_sources(inp[0], inp[1], inp[2])
+    r2, _ = eng.forward_target(inp[3], inp[4])
+    assert torch.equal(rec, r2)
+    eng.close()
+    monkeypatch.setenv("TSNET_X3", "0")
+    eng32 = Hh.make_engine(cfg, sd, 32, 32, 2, "cpu", lib=emu_lib)
+    emu_lib.tsnet_debug_counters(None, 1)
+    rec32, _ = Hh.run_engine(eng32, inp, "cpu")
+    emu_lib.tsnet_debug_counters(cnt, 1)
+    assert cnt[2] > 0 and cnt[3] == 0
+    assert (rec - rec32).abs().max().item() < 2e-4
+    eng32.close()

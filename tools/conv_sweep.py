@@ -24,7 +24,7 @@ LAYERS = [
     ("lbl_down3",   4,  64,  64, 256,  512, 3, 2, 1, 0, 1),
 ]
 TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (96, 128)}
-XT = {0: (128, 128), 1: (128, 128), 2: (128, 128), 3: (128, 128), 4: (128, 64), 5: (64, 64)}
+XT = {0: (128, 128), 1: (128, 128), 2: (128, 128), 3: (128, 128), 4: (128, 64), 5: (64, 64), 6: (64, 128), 7: (96, 128)}
 WT = {0: (128, 128), 1: (128, 64), 2: (128, 128), 3: (64, 64)}
 GT = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (128, 128), 5: (128, 128)}
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
@@ -33,9 +33,9 @@ for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
     flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
     npad = (Cout + 127) // 128 * 128 if Cout >= 128 else (Cout + 31) // 32 * 32
     res = []
-    for v in ([4096 + 64, 4097 + 64, 4098 + 64] + [8192 + t for t in range(6)] if quick else [0, 1, 4, 8 + 4, 64, 65, 66, 67, 192, 193, 194, 195, 4096 + 64, 4097 + 64, 4098 + 64, 4099 + 64]):
+    for v in ([4096 + 64, 4097 + 64, 4098 + 64] + [8192 + t for t in (0, 4, 5, 6, 7)] if quick else [0, 1, 4, 8 + 4, 64, 65, 66, 67, 192, 193, 194, 195, 4096 + 64, 4097 + 64, 4098 + 64, 4099 + 64]):
         tl = XT if v & 8192 else (WT if v & 128 else (GT if v & 64 else TILES))
-        if npad % tl[v & 7][1] or (tl[v & 7][1] > 32 and Cout <= tl[v & 7][1] // 2):
+        if npad % tl[v & 15][1] or (tl[v & 15][1] > 32 and Cout <= tl[v & 15][1] // 2):
             continue
         ms = C.c_float()
         iters = 5 if flops > 5e10 else 10
@@ -46,4 +46,4 @@ for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
     if not res: continue
     best = max(r[2] for r in res)
     print(f"{name:10s} M={N*Ho*Wo:7d} N={Cout:5d} K={Cin*k*k:5d} GF={flops/1e9:7.1f} | " +
-          " ".join(f"{('h' if v < 0 else ('%s%d%s' % ('X' if v & 8192 else 'D' if v & 4096 else ('W' if v & 128 else ('G' if v & 64 else 't')), v & 7, 'k32' if v & 8 else '')))}:{ms:.3f}ms/{tf:.0f}TF{'*' if tf == best else ''}" for v, ms, tf in res), flush=True)
+          " ".join(f"{('h' if v < 0 else ('%s%d%s' % ('X' if v & 8192 else 'D' if v & 4096 else ('W' if v & 128 else ('G' if v & 64 else 't')), v & 15, 'k32' if v & 8 else '')))}:{ms:.3f}ms/{tf:.0f}TF{'*' if tf == best else ''}" for v, ms, tf in res), flush=True)

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "conv_dma.hpp"
+#include "split3.hpp"
 
 namespace tsnet {
 
@@ -39,25 +40,6 @@ struct X3Args {
 typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
 #define TSNET_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tsnet_bf16x8, a), __builtin_bit_cast(tsnet_bf16x8, b), c, 0, 0, 0)
 #endif
-
-// exact 3-way split of 4 floats into 3 x 4 bf16 (truncation: every plane holds the next 8 mantissa bits)
-__device__ __forceinline__ void split3_store(float4 v, unsigned short* hi, unsigned short* mid, unsigned short* lo) {
-    const float f[4] = {v.x, v.y, v.z, v.w};
-    unsigned short h[4], m[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const unsigned u = __builtin_bit_cast(unsigned, f[e]);
-        const unsigned uh = u & 0xFFFF0000u;
-        const float r1 = f[e] - __builtin_bit_cast(float, uh);
-        const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-        const float r2 = r1 - __builtin_bit_cast(float, um);
-        h[e] = (unsigned short)(uh >> 16); m[e] = (unsigned short)(um >> 16);
-        l[e] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
-    }
-    *reinterpret_cast<uint2*>(hi) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
-    *reinterpret_cast<uint2*>(mid) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
-    *reinterpret_cast<uint2*>(lo) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
-}
 
 // KC = 16-deep k-groups per ring stage (1 or 2); NSTAGE = ring depth
 template <int KS, int BM, int BN, int WARPS_M, int WARPS_N, int KC, int NSTAGE, bool SMALL_CIN>

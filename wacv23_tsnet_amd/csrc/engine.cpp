@@ -363,9 +363,11 @@ void launch_glds_ks(GldsArgs a, int forced_tile, hipStream_t s) {
 
 // ---- bf16x3 kernel (conv_x3.hpp)
 struct XTileCfg { int bm, bn, wm, wn, kc, nstage; double eff; };
+// eff: per-tile efficiency relative to 128x128 measured by tools/conv_sweep.py (profiles/round1_notes.md); 0 = sweep only
 const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, 1.0}, {128, 128, 2, 2, 1, 4, 0.0}, {128, 128, 2, 2, 2, 3, 0.0},
-                            {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, 0.95}, {64, 64, 2, 2, 1, 4, 0.9}};
-constexpr int kNumXTiles = 6;
+                            {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, 0.55}, {64, 64, 2, 2, 1, 4, 0.52},
+                            {64, 128, 2, 2, 1, 4, 0.62}, {96, 128, 1, 4, 1, 3, 0.81}, {128, 32, 4, 1, 1, 4, 0.3}};
+constexpr int kNumXTiles = 9;
 
 template <int KS, int BM, int BN, int WM_, int WN_, int KC, int NST>
 void launch_x3_t(const X3Args& a, hipStream_t s) {
@@ -402,7 +404,10 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         case 2: launch_x3_t<KS, 128, 128, 2, 2, 2, 3>(a, s); break;
         case 3: launch_x3_t<KS, 128, 128, 4, 2, 2, 3>(a, s); break;
         case 4: launch_x3_t<KS, 128, 64, 2, 2, 1, 4>(a, s); break;
-        default: launch_x3_t<KS, 64, 64, 2, 2, 1, 4>(a, s); break;
+        case 5: launch_x3_t<KS, 64, 64, 2, 2, 1, 4>(a, s); break;
+        case 6: launch_x3_t<KS, 64, 128, 2, 2, 1, 4>(a, s); break;
+        case 7: launch_x3_t<KS, 96, 128, 1, 4, 1, 3>(a, s); break;
+        default: launch_x3_t<KS, 128, 32, 4, 1, 1, 4>(a, s); break;
     }
     return a.stat_part ? hw / kXTiles[best].bm : 0;
 }
@@ -434,7 +439,7 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
     if ((double)c.N * c.H * c.W * L.cin_pad * 2 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
         throw ArgError("conv(x3): tensor too large for 32-bit buffer offsets");
     TimeScope ts(ctx, TSNET_T_CONV);
-    const int forced = c.variant >= 0 ? (c.variant & 7) : -1;
+    const int forced = c.variant >= 0 ? (c.variant & 15) : -1;
     switch (L.ks) {
         case 1: c.stat_S = launch_x3_ks<1>(g, forced, ctx.stream); break;
         case 3: c.stat_S = launch_x3_ks<3>(g, forced, ctx.stream); break;
@@ -612,18 +617,19 @@ void finish_stats(Ctx& ctx, const ConvCall& c, const float* y, int N, int HW, in
 }
 
 void run_norm_act(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, const float* resid,
-                  int N, int HW, int C, float* y) {
+                  int N, int HW, int C, float* y, unsigned short* y3 = nullptr) {
     if (C & 3) throw ArgError("norm_act: C must be a multiple of 4");
     TimeScope ts(ctx, TSNET_T_ELEMWISE);
-    NormActArgs a{x, alpha, beta, resid, y, HW, C, relu, (size_t)N * HW * C / 4};
+    NormActArgs a{x, alpha, beta, resid, y, HW, C, relu, (size_t)N * HW * C / 4, y3};
     hipLaunchKernelGGL(norm_act_kernel, dim3(ew_grid(a.total4)), dim3(256), 0, ctx.stream, a);
     check_launch("norm_act");
 }
 
-void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, int N, int H, int W, int C, float* y) {
+void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, int N, int H, int W, int C, float* y,
+                  unsigned short* y3 = nullptr) {
     if (C & 3) throw ArgError("upsample: C must be a multiple of 4");
     TimeScope ts(ctx, TSNET_T_UPSAMPLE);
-    UpsampleArgs a{x, alpha, beta, y, N, H, W, C, relu};
+    UpsampleArgs a{x, alpha, beta, y, N, H, W, C, relu, y3};
     hipLaunchKernelGGL(upsample2x_kernel, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, ctx.stream, a);
     check_launch("upsample2x");
 }
@@ -645,9 +651,9 @@ void run_flow(Ctx& ctx, FlowArgs a, int NB) {
     check_launch("flow");
 }
 
-void run_warp(Ctx& ctx, const float* src, const float* flow, float* out, int B, int K, int h, int w, int C) {
+void run_warp(Ctx& ctx, const float* src, const float* flow, float* out, int B, int K, int h, int w, int C, unsigned short* out3 = nullptr) {
     TimeScope ts(ctx, TSNET_T_WARP);
-    WarpArgs a{src, flow, out, B, K, h, w, C};
+    WarpArgs a{src, flow, out, B, K, h, w, C, out3};
     hipLaunchKernelGGL(warp_mean_kernel, dim3(ew_grid((size_t)B * h * w * C / 4)), dim3(256), 0, ctx.stream, a);
     check_launch("warp_mean");
 }
@@ -712,6 +718,13 @@ struct tsnet_engine {
     ConvLayer fuse_c1, fuse_c2, fuse_out, dec_map, dec_head;
     ConvLayer fuse_c1_src, fuse_c1_tar;   // fuse_c1 split at the channel concat: per-source half / shared target half
     float* FT = nullptr;                  // (B,P,2C) target half of fuse_c1, computed once per forward
+    // ---- bf16x3 mode (conv_x3.hpp): every conv input exists as three bf16 planes
+    bool x3 = true;
+    unsigned short* wpack3 = nullptr; size_t wpack3_elems = 0;
+    unsigned short* arena3 = nullptr;
+    unsigned short *x_img3 = nullptr, *x_lbl3 = nullptr, *X3 = nullptr, *T3 = nullptr, *tar3 = nullptr, *zbar3 = nullptr,
+                   *pg3 = nullptr, *sg3 = nullptr, *D3 = nullptr;
+    std::vector<unsigned short*> raw3_img, raw3_lbl, U3;
     float* head_w = nullptr;              // [49][ngf][4] weights of the RGB head for head_conv_kernel
     bool vector_head = true;              // head_conv_kernel (VALU) instead of the N-padded MFMA conv
     std::vector<ConvLayer> dec_res, dec_up;
@@ -759,6 +772,21 @@ struct tsnet_engine {
     void build_layers();
     void alloc_all(hipStream_t s);
     void encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin, int N, int cp, std::vector<float*>& raw, float* out_fea, int nblocks);
+    void encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned short* xin3, int N, std::vector<float*>& raw,
+                   std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks);
+    void resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float* y1, float* y2, int N, int hh, int ww);
+    void forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
+    void conv_stats_x3(Ctx& ctx, const ConvLayer& L, X3Call& c, int N, int HW, float* alpha, float* beta) {
+        c.stat_part = part;
+        run_conv_x3(ctx, L, c);
+        if (c.stat_S > 0) {
+            TimeScope ts(ctx, TSNET_T_STATS);
+            hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + 63) / 64, N), dim3(256), 0, ctx.stream, part, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
+            check_launch("in_finalize2");
+        } else {
+            run_stats(ctx, c.y, N, HW, L.cout, part, alpha, beta);
+        }
+    }
     void resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww);
     void set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B);
     void forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
@@ -855,6 +883,24 @@ void tsnet_engine::alloc_all(hipStream_t s) {
         L->w2 = wpack + L->w2_off;
         L->bias = L->bparam.empty() ? nullptr : wpack + L->b_off;
     }
+    if (x3) {                              // bf16x3 planes of every layer's weights
+        size_t o3 = 0;
+        std::vector<size_t> offs;
+        for (ConvLayer* L : all_layers) { offs.push_back(o3); o3 += 3 * (size_t)L->kpad * L->npad; }
+        wpack3_elems = o3;
+        HIP_TRY(hipMalloc((void**)&wpack3, o3 * sizeof(unsigned short)));
+        size_t li = 0;
+        for (ConvLayer* L : all_layers) {
+            const Param& pw = params[pindex[L->wparam]];
+            HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(pack_weights_x3_kernel, dim3(ew_grid((size_t)L->kpad * L->npad)), dim3(256), 0, s, stage, wpack3 + offs[li],
+                               L->cout, L->cin_real, L->cin_pad, L->ks, L->kpad, L->npad, L->cin_total > 0 ? L->cin_total : L->cin_real, L->cin_off);
+            check_launch("pack_weights_x3");
+            HIP_TRY(hipStreamSynchronize(s));
+            L->w3 = wpack3 + offs[li];
+            ++li;
+        }
+    }
     if (cfg.ngf % kHeadCh == 0) {          // RGB head weights for the vector kernel (else the MFMA path is used)
         const Param& pw = params[pindex[dec_head.wparam]];
         HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
@@ -919,6 +965,139 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     size_t o = 0;
     for (auto& r : req) { *r.first = arena + o; o += r.second; }
     part = reinterpret_cast<double*>(part_f);
+
+    if (x3) {    // ---- bf16x3 planes of every conv input (3 planes x 2 bytes per element)
+        std::vector<std::pair<unsigned short**, size_t>> rq;
+        auto want3 = [&](unsigned short** p, size_t elems) { rq.emplace_back(p, (3 * elems + 63) & ~(size_t)63); };
+        want3(&x_img3, NB * H * W * cp_img);
+        want3(&x_lbl3, B * H * W * cp_lbl);
+        raw3_img.assign(cfg.n_downsampling, nullptr);
+        raw3_lbl.assign(cfg.n_downsampling, nullptr);
+        for (int l = 0; l < cfg.n_downsampling; ++l) {
+            const size_t e = (size_t)(H >> l) * (W >> l) * (cfg.ngf << l);
+            want3(&raw3_img[l], NB * e);
+            want3(&raw3_lbl[l], B * e);
+        }
+        want3(&X3, NB * fe); want3(&T3, NB * fe * 2); want3(&tar3, B * fe); want3(&zbar3, B * fe * 2);
+        want3(&pg3, B * fe); want3(&sg3, B * fe); want3(&D3, B * fe);
+        U3.assign(cfg.n_downsampling, nullptr);
+        for (int i = 0; i < cfg.n_downsampling; ++i) want3(&U3[i], B * (size_t)(h << (i + 1)) * (w << (i + 1)) * (C >> i));
+        size_t tot3 = 0;
+        for (auto& r : rq) tot3 += r.second;
+        HIP_TRY(hipMalloc((void**)&arena3, tot3 * sizeof(unsigned short)));
+        size_t o3 = 0;
+        for (auto& r : rq) { *r.first = arena3 + o3; o3 += r.second; }
+    }
+}
+
+// ---- bf16x3 schedule: same graph as the fp32 one; every conv reads planes, producers write planes
+void tsnet_engine::resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float* y1, float* y2, int N, int hh, int ww) {
+    const int Cc = c1.cout, HW = hh * ww;
+    X3Call a; a.x3 = Xs3; a.N = N; a.H = hh; a.W = ww; a.y = y1;
+    auto s1 = next_ab();
+    conv_stats_x3(ctx, c1, a, N, HW, s1.first, s1.second);
+    run_norm_act(ctx, y1, s1.first, s1.second, 1, nullptr, N, HW, Cc, nullptr, T3);            // relu(IN(y1)) -> planes only
+    X3Call b; b.x3 = T3; b.N = N; b.H = hh; b.W = ww; b.y = y2;
+    auto s2 = next_ab();
+    conv_stats_x3(ctx, c2, b, N, HW, s2.first, s2.second);
+    run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs, Xs3);                       // X += IN(y2): fp32 + planes
+}
+
+void tsnet_engine::encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned short* xin3, int N, std::vector<float*>& raw,
+                             std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks) {
+    int hh = cfg.height, ww = cfg.width;
+    X3Call a; a.x3 = xin3; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
+    auto st = next_ab();
+    conv_stats_x3(ctx, L[0], a, N, hh * ww, st.first, st.second);
+    for (int l = 1; l <= cfg.n_downsampling; ++l) {
+        run_norm_act(ctx, raw[l - 1], st.first, st.second, 1, nullptr, N, hh * ww, L[l].cin_pad, nullptr, raw3[l - 1]);
+        X3Call d; d.x3 = raw3[l - 1]; d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
+        hh /= 2; ww /= 2;
+        st = next_ab();
+        conv_stats_x3(ctx, L[l], d, N, hh * ww, st.first, st.second);
+    }
+    run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea, out_fea3);
+    for (int i = 0; i < nblocks; ++i)
+        resblock_x3(ctx, L[cfg.n_downsampling + 1 + 2 * i], L[cfg.n_downsampling + 2 + 2 * i], out_fea, out_fea3, Y1, Y2, N, hh, ww);
+}
+
+void tsnet_engine::forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
+    const int H = cfg.height, W = cfg.width, NB = K * B;
+    {
+        TimeScope ts(ctx, TSNET_T_PACK);
+        PackArgs p{};
+        p.img[0] = nullptr; p.lbl[0] = tar_lbl;
+        p.coords = cfg.addcoords ? d_coords : nullptr;
+        p.out = nullptr; p.out3 = x_lbl3; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
+        hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ctx.stream, p);
+        check_launch("pack_input(lbl)");
+    }
+    encode_x3(ctx, lbl_enc, x_lbl3, B, raw_lbl, raw3_lbl, tar_fea, tar3, 0);
+
+    // ---- transformation branch (fp32 features; unchanged kernels)
+    run_l2norm(ctx, tar_fea, that, B * P, C);
+    FlowArgs fa{};
+    fa.that = that; fa.shat = shat; fa.tar_bbox = tar_bbox;
+    for (int s = 0; s < K; ++s) fa.src_bbox[s] = bbox_copy + (size_t)s * Bmax * H * W;
+    fa.gx = d_gx; fa.gy = d_gy; fa.flow = flow;
+    fa.B = B; fa.P = P; fa.C = C; fa.h = h; fa.w = w; fa.H = H; fa.W = W; fa.sy = H / h; fa.sx = W / w;
+    run_flow(ctx, fa, NB);
+    if (out_flow)
+        HIP_TRY(hipMemcpyAsync(out_flow, flow, (size_t)NB * P * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
+    run_warp(ctx, X, flow, pg, B, K, h, w, C, pg3);
+
+    // ---- synthesis branch
+    {
+        X3Call t; t.x3 = tar3; t.N = B; t.H = h; t.W = w; t.y = FT;                    // shared target half of fuse conv1
+        run_conv_x3(ctx, fuse_c1_tar, t);
+        X3Call a; a.x3 = X3; a.N = NB; a.H = h; a.W = w; a.y = F1; a.addend = FT; a.add_nmod = B;
+        auto s1 = next_ab();
+        conv_stats_x3(ctx, fuse_c1_src, a, NB, P, s1.first, s1.second);
+        run_norm_act(ctx, F1, s1.first, s1.second, 1, nullptr, NB, P, 2 * C, nullptr, T3);
+        X3Call b; b.x3 = T3; b.N = NB; b.H = h; b.W = w; b.y = F2;
+        auto s2 = next_ab();
+        conv_stats_x3(ctx, fuse_c2, b, NB, P, s2.first, s2.second);
+        {
+            TimeScope ts(ctx, TSNET_T_ELEMWISE);
+            FuseTailArgs t2{X, tar_fea, F2, s2.first, s2.second, nullptr, B, K, P, C, zbar3};
+            hipLaunchKernelGGL(fuse_resid_mean_kernel, dim3(ew_grid((size_t)B * P * 2 * C / 4)), dim3(256), 0, ctx.stream, t2);
+            check_launch("fuse_resid_mean");
+        }
+        X3Call c; c.x3 = zbar3; c.N = B; c.H = h; c.W = w; c.y = sg; c.y3 = sg3;
+        run_conv_x3(ctx, fuse_out, c);
+    }
+
+    // ---- decoder
+    {
+        X3Call a; a.x3 = pg3; a.x23 = sg3; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
+        a.y3 = cfg.n_blocks > 0 ? D3 : nullptr;
+        run_conv_x3(ctx, dec_map, a);
+    }
+    for (int i = 0; i < cfg.n_blocks; ++i) resblock_x3(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, DY1, DY2, B, h, w);
+    const float* cur = D; const float* cal = nullptr; const float* cbe = nullptr;
+    int hh = h, ww = w, cc = C;
+    for (int i = 0; i < cfg.n_downsampling; ++i) {
+        run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, nullptr, U3[i]);
+        hh *= 2; ww *= 2;
+        X3Call a; a.x3 = U3[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
+        cc /= 2;
+        auto st = next_ab();
+        conv_stats_x3(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
+        cur = R[i]; cal = st.first; cbe = st.second;
+    }
+    if (!vector_head) throw ArgError("bf16x3 mode needs the vector RGB head (ngf % 16 == 0)");
+    {
+        TimeScope ts(ctx, TSNET_T_CONV);
+        HeadArgs ha{};
+        ha.x = cur; ha.alpha = cal; ha.beta = cbe; ha.w = head_w; ha.bias = dec_head.bias; ha.y = out_rgb;
+        ha.N = B; ha.H = hh; ha.W = ww; ha.C = cc;
+        ha.composite = cfg.pose_composite; ha.fore_x0 = 64; ha.fore_x1 = 192;
+        for (int c = 0; c < 3; ++c) ha.bg[c] = (-cfg.pose_mean[c]) / 255.0f;
+        const int tiles = ((ww + kHeadT - 1) / kHeadT) * ((hh + kHeadT - 1) / kHeadT);
+        hipLaunchKernelGGL(head_conv_kernel, dim3(tiles, B), dim3(256), 0, ctx.stream, ha);
+        check_launch("head_conv");
+    }
+    last_B = B;
 }
 
 // one ResnetBlock on a materialised NHWC tensor Xs (in place): Xs += IN(conv2(relu(IN(conv1(Xs)))))
@@ -964,18 +1143,21 @@ void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const floa
         PackArgs p{};
         for (int s = 0; s < K; ++s) { p.img[s] = src_img[s]; p.lbl[s] = src_lbl[s]; }
         p.coords = cfg.addcoords ? d_coords : nullptr;
-        p.out = x_img; p.S = K; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 3; p.Cp = cp_img;
+        p.out = x3 ? nullptr : x_img; p.out3 = x3 ? x_img3 : nullptr;
+        p.S = K; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 3; p.Cp = cp_img;
         hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)K * B * H * W)), dim3(256), 0, ctx.stream, p);
         check_launch("pack_input(img)");
         for (int s = 0; s < K; ++s)
             HIP_TRY(hipMemcpyAsync(bbox_copy + (size_t)s * Bmax * H * W, src_bbox[s], (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
     }
-    encode(ctx, img_enc, x_img, K * B, cp_img, raw_img, X, cfg.enc_blocks);
+    if (x3) encode_x3(ctx, img_enc, x_img3, K * B, raw_img, raw3_img, X, X3, cfg.enc_blocks);
+    else encode(ctx, img_enc, x_img, K * B, cp_img, raw_img, X, cfg.enc_blocks);
     run_l2norm(ctx, X, shat, K * B * P, C);
     cached_B = B;
 }
 
 void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
+    if (x3) { forward_target_x3(ctx, tar_lbl, tar_bbox, out_rgb, out_flow, B); return; }
     const int H = cfg.height, W = cfg.width, NB = K * B;
     {
         TimeScope ts(ctx, TSNET_T_PACK);
@@ -1111,6 +1293,9 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
         e->build_layers();
         { const char* lg = getenv("TSNET_CONV_LEGACY"); e->fuse_norm_in_loader = lg && atoi(lg); }
         { const char* vh = getenv("TSNET_VECTOR_HEAD"); e->vector_head = !(vh && !atoi(vh)); }
+        { const char* x = getenv("TSNET_X3"); const char* k = getenv("TSNET_CONV_KERNEL");
+          // bf16x3 convs (conv_x3.hpp): needs 16-channel granularity everywhere except the stems, and the vector head
+          e->x3 = !(x && !atoi(x)) && (cfg->ngf % 16 == 0) && !k && e->vector_head && !e->fuse_norm_in_loader; }
         { const char* k = getenv("TSNET_CONV_KERNEL"); const char* sf = getenv("TSNET_SPLIT_FUSE");
           e->split_fuse = !e->fuse_norm_in_loader && (!k || !strcmp(k, "dma")) && !(sf && !atoi(sf)); }
         *out = e;
@@ -1168,6 +1353,7 @@ int tsnet_finalize(tsnet_handle h, void* stream) {
 
 void tsnet_destroy(tsnet_handle h) {
     if (!h) return;
+    (void)hipFree(h->wpack3); (void)hipFree(h->arena3);
     (void)hipFree(h->head_w); (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
     delete h;
 }

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_igemm.hpp"
+#include "split3.hpp"
 
 namespace tsnet {
 
@@ -143,6 +144,7 @@ struct WarpArgs {
     const float* flow;   // (K*B, P, 2)
     float* out;          // (B, P, C)
     int B, K, h, w, C;
+    unsigned short* out3;  // null, or bf16x3 planes of out
 };
 
 __global__ __launch_bounds__(256) void warp_mean_kernel(WarpArgs a) {
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(256) void warp_mean_kernel(WarpArgs a) {
         const float kf = (float)a.K;
         sum.x /= kf; sum.y /= kf; sum.z /= kf; sum.w /= kf;
         *reinterpret_cast<float4*>(a.out + ((size_t)b * P + p) * a.C + c) = sum;
+        if (a.out3) split3_store_at(sum, a.out3, total * 4, i * 4);
     }
 }
 

@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "split3.hpp"
+
 namespace tsnet {
 
 #ifndef TSNET_F4_DEFINED
@@ -124,9 +126,10 @@ struct NormActArgs {
     const float* alpha;
     const float* beta;
     const float* resid;
-    float* y;
+    float* y;              // fp32 output or null
     int HW, C, relu;
     size_t total4;   // N*HW*C/4
+    unsigned short* y3;    // null, or bf16x3 planes of the output (conv_x3 operand format)
 };
 
 __global__ __launch_bounds__(256) void norm_act_kernel(NormActArgs a) {
@@ -152,7 +155,8 @@ __global__ __launch_bounds__(256) void norm_act_kernel(NormActArgs a) {
             const float4 r = reinterpret_cast<const float4*>(a.resid)[i];
             v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
         }
-        reinterpret_cast<float4*>(a.y)[i] = v;
+        if (a.y) reinterpret_cast<float4*>(a.y)[i] = v;
+        if (a.y3) split3_store_at(v, a.y3, a.total4 * 4, i * 4);
     }
 }
 
@@ -166,8 +170,9 @@ struct FuseTailArgs {
     const float* y2;        // (K*B, P, 2*C1)
     const float* alpha;     // (K*B * 2*C1)
     const float* beta;
-    float* zbar;            // (B, P, 2*C1)
+    float* zbar;            // (B, P, 2*C1) fp32 or null
     int B, K, P, C1;
+    unsigned short* zbar3;  // null, or bf16x3 planes of zbar
 };
 
 __global__ __launch_bounds__(256) void fuse_resid_mean_kernel(FuseTailArgs a) {
@@ -195,7 +200,8 @@ __global__ __launch_bounds__(256) void fuse_resid_mean_kernel(FuseTailArgs a) {
         }
         const float kf = (float)a.K;
         acc.x /= kf; acc.y /= kf; acc.z /= kf; acc.w /= kf;
-        *reinterpret_cast<float4*>(a.zbar + ((size_t)b * a.P + p) * C + c) = acc;
+        if (a.zbar) *reinterpret_cast<float4*>(a.zbar + ((size_t)b * a.P + p) * C + c) = acc;
+        if (a.zbar3) split3_store_at(acc, a.zbar3, total * 4, i * 4);
     }
 }
 
@@ -207,8 +213,9 @@ struct UpsampleArgs {
     const float* x;       // (N,H,W,C)
     const float* alpha;   // (N*C) or null
     const float* beta;
-    float* y;             // (N,2H,2W,C)
+    float* y;             // (N,2H,2W,C) fp32 or null
     int N, H, W, C, relu;
+    unsigned short* y3;   // null, or bf16x3 planes of the output
 };
 
 __device__ __forceinline__ float4 na4(float4 v, const float4& al, const float4& be, bool norm, bool relu) {
@@ -254,7 +261,8 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(UpsampleArgs a) {
         o.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
         o.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
         o.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
-        reinterpret_cast<float4*>(a.y)[i] = o;
+        if (a.y) reinterpret_cast<float4*>(a.y)[i] = o;
+        if (a.y3) split3_store_at(o, a.y3, total * 4, i * 4);
     }
 }
 
@@ -265,8 +273,9 @@ struct PackArgs {
     const float* img[8];   // per source: (B,3,H,W) or null (label encoder input)
     const float* lbl[8];   // per source: (B,L,H,W)
     const float* coords;   // (H,W,3) table or null
-    float* out;            // (S*B, H, W, Cp)
+    float* out;            // (S*B, H, W, Cp) fp32 or null
     int S, B, H, W, L, nimg, Cp;
+    unsigned short* out3;  // null, or bf16x3 planes of the packed input
 };
 
 __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
@@ -289,7 +298,9 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
                 else if (c < creal) t = a.coords[pix * 3 + (c - a.nimg - a.L)];
                 v[e] = t;
             }
-            *reinterpret_cast<float4*>(o + c0) = make_float4(v[0], v[1], v[2], v[3]);
+            const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.out) *reinterpret_cast<float4*>(o + c0) = v4;
+            if (a.out3) split3_store_at(v4, a.out3, total * a.Cp, i * a.Cp + c0);
         }
     }
 }
