@@ -1,7 +1,7 @@
 // conv_x3.hpp -- fp32-accurate implicit-GEMM convolution on the bf16 MFMA via a 3-way operand split.
 //
-// Every fp32 operand x is stored as three bf16 planes with x == hi + mid + lo EXACTLY (each plane takes
-// the next 8 mantissa bits by truncation).  A product a*b is evaluated as the six bf16 products
+// Every fp32 operand x is stored as three bf16 planes with x = hi + mid + lo to 2^-27 (round-to-nearest
+// residual split, split3.hpp).  A product a*b is evaluated as the six bf16 products
 //   lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi          (dropped terms are <= 2^-24 |a||b|)
 // on v_mfma_f32_32x32x16_bf16 (exact bf16 products, fp32 accumulate), 6 MFMAs per 16-deep k-group:
 // 12 matrix-pipe cycles per k instead of 32 on the fp32 MFMA, i.e. a 2.67x higher ceiling (417 TF
@@ -191,8 +191,10 @@ void conv_x3_kernel(X3Args a) {
     const int a_off = (wm0 + li) * 32 + oct_r * 16;         // byte offset inside a plane
     const int b_off = (wn0 + li) * 32 + oct_r * 16;
 
-    // kept as a lambda inlined at 4 call sites so stage indices and the fold flag are constants
-    auto step = [&](int st, int stage, int refill_stage, bool first, bool do_refill) {
+    // one ring step; inlined at NSTAGE call sites so the stage indices are constants.  The fmaf chain is folded
+    // into the running total every 4 k-groups (64 products) counted from k = 0 -- the SAME fold points for every
+    // tile shape and ring depth, so a layer's result does not depend on which tile the heuristic picked.
+    auto step = [&](int st, int stage, int refill_stage) {
         TSNET_VMCNT(LPC * (NSTAGE - 2));
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -209,7 +211,7 @@ void conv_x3_kernel(X3Args a) {
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) bf[p][j] = *reinterpret_cast<const F4*>(gb + 3 * PLANE_A + p * PLANE_B + j * 1024 + b_off);
             }
-            if (g == 0 && do_refill) issue_step(st + NSTAGE - 1, refill_stage);
+            if (g == 0) issue_step(st + NSTAGE - 1, refill_stage);
             // six products per tile, small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -217,34 +219,34 @@ void conv_x3_kernel(X3Args a) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NTL; ++j) {
-                        if (first && g == 0 && q == 0) {
-                            f32x16 z;
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] = TSNET_MFMA_BF16(af[PA[q]][i], bf[PB[q]][j], acc[i][j]);
+            if ((((st * KC + g) + 1) & 3) == 0) {          // wave-uniform
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                            acc[i][j] = TSNET_MFMA_BF16(af[PA[q]][i], bf[PB[q]][j], z);
-                        } else {
-                            acc[i][j] = TSNET_MFMA_BF16(af[PA[q]][i], bf[PB[q]][j], acc[i][j]);
-                        }
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        tot[i][j] += acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
                     }
+            }
         }
     };
 
-    // The loop is unrolled by NSTAGE ring steps (stage indices become constants); the fmaf chain is folded
-    // into the running total once per unrolled group, i.e. every NSTAGE*KC*16 = 48..128 products.
     static_assert(NSTAGE == 3 || NSTAGE == 4, "ring depth");
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) issue_step(s, s);     // steps past the end read zeros (OOB / K-padded weights)
     for (int st = 0; st < nst; st += NSTAGE) {
-        step(st, 0, NSTAGE - 1, true, true);
-        if (st + 1 < nst) step(st + 1, 1, 0, false, true);
-        if (st + 2 < nst) step(st + 2, 2, 1, false, true);
-        if (NSTAGE == 4 && st + 3 < nst) step(st + 3, 3, 2, false, true);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];
+        step(st, 0, NSTAGE - 1);
+        if (st + 1 < nst) step(st + 1, 1, 0);
+        if (st + 2 < nst) step(st + 2, 2, 1);
+        if (NSTAGE == 4 && st + 3 < nst) step(st + 3, 3, 2);
     }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];    // the last, partial chain
     TSNET_VMCNT(0);
 
     // ---- epilogue (as conv_dma.hpp, plus the optional split-plane copy of the output)
@@ -272,15 +274,10 @@ void conv_x3_kernel(X3Args a) {
                 if (!nok || m >= a.M) continue;
                 if (a.y) a.y[(size_t)m * a.Cout + n] = v;
                 if (a.y3) {
-                    const unsigned u = __builtin_bit_cast(unsigned, v);
-                    const unsigned uh = u & 0xFFFF0000u;
-                    const float r1 = v - __builtin_bit_cast(float, uh);
-                    const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-                    const float r2 = r1 - __builtin_bit_cast(float, um);
+                    unsigned short sh, sm, sl;
+                    split3_scalar(v, sh, sm, sl);
                     const size_t o = (size_t)m * a.Cout + n;
-                    a.y3[o] = (unsigned short)(uh >> 16);
-                    a.y3[yplane + o] = (unsigned short)(um >> 16);
-                    a.y3[2 * yplane + o] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+                    a.y3[o] = sh; a.y3[yplane + o] = sm; a.y3[2 * yplane + o] = sl;
                 }
             }
         }
@@ -329,14 +326,9 @@ __global__ void pack_weights_x3_kernel(const float* __restrict__ w, unsigned sho
             const int ky = tap / ks, kx = tap - ky * ks;
             v = w[(((size_t)n * cin_total + cin_off + c) * ks + ky) * ks + kx];
         }
-        const unsigned u = __builtin_bit_cast(unsigned, v);
-        const unsigned uh = u & 0xFFFF0000u;
-        const float r1 = v - __builtin_bit_cast(float, uh);
-        const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-        const float r2 = r1 - __builtin_bit_cast(float, um);
-        out[idx] = (unsigned short)(uh >> 16);
-        out[plane + idx] = (unsigned short)(um >> 16);
-        out[2 * plane + idx] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+        unsigned short sh, sm, sl;
+        split3_scalar(v, sh, sm, sl);
+        out[idx] = sh; out[plane + idx] = sm; out[2 * plane + idx] = sl;
     }
 }
 

@@ -389,7 +389,8 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
             if (e_tile && atoi(e_tile) == i) { best = i; break; }
             if (kXTiles[i].eff <= 0 || (kXTiles[i].bn > 32 && a.Cout <= kXTiles[i].bn / 2)) continue;
             const long tm = (a.M + kXTiles[i].bm - 1) / kXTiles[i].bm, tn = (a.Cout + kXTiles[i].bn - 1) / kXTiles[i].bn;
-            const double cost = (double)((tm * tn + 255) / 256) * kXTiles[i].bm * kXTiles[i].bn / kXTiles[i].eff;
+            double cost = (double)((tm * tn + 255) / 256) * kXTiles[i].bm * kXTiles[i].bn / kXTiles[i].eff;
+            if (a.stat_part && (a.Ho * a.Wo) % kXTiles[i].bm) cost *= 1.12;   // tile straddles images: statistics need their own pass
             if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
         }
     }

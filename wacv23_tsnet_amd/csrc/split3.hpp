@@ -1,24 +1,32 @@
-// split3.hpp -- exact 3-way bf16 split of fp32 values (operand format of conv_x3.hpp).
-// x == hi + mid + lo exactly: hi = top 8 mantissa bits of x (truncation), mid = top 8 bits of x-hi,
-// lo = top 8 bits of x-hi-mid.  Planes are stored as separate bf16 tensors (plane stride = element count).
+// split3.hpp -- 3-way bf16 split of fp32 values (operand format of conv_x3.hpp).
+// hi = rne_bf16(x), mid = rne_bf16(x - hi), lo = rne_bf16(x - hi - mid); both subtractions are exact, so
+// x = hi + mid + lo up to 2^-27 |x|.  Round-to-nearest (not truncation) matters: truncated residuals all carry
+// the sign of x, which biases the dropped cross terms mid*lo of a long dot product in one direction; rounded
+// residuals have random signs and are one bit smaller.  Planes are separate bf16 tensors (plane stride = elements).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace tsnet {
 
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);     // finite inputs only (activations / weights)
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+
+__device__ __forceinline__ void split3_scalar(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    hi = bf16_rne(x);
+    const float r1 = x - bf16_to_f32(hi);
+    mid = bf16_rne(r1);
+    const float r2 = r1 - bf16_to_f32(mid);
+    lo = bf16_rne(r2);
+}
+
 __device__ __forceinline__ void split3_store(float4 v, unsigned short* hi, unsigned short* mid, unsigned short* lo) {
     const float f[4] = {v.x, v.y, v.z, v.w};
     unsigned short h[4], m[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const unsigned u = __builtin_bit_cast(unsigned, f[e]);
-        const unsigned uh = u & 0xFFFF0000u;
-        const float r1 = f[e] - __builtin_bit_cast(float, uh);
-        const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-        const float r2 = r1 - __builtin_bit_cast(float, um);
-        h[e] = (unsigned short)(uh >> 16); m[e] = (unsigned short)(um >> 16);
-        l[e] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
-    }
+    for (int e = 0; e < 4; ++e) split3_scalar(f[e], h[e], m[e], l[e]);
     *reinterpret_cast<uint2*>(hi) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
     *reinterpret_cast<uint2*>(mid) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
     *reinterpret_cast<uint2*>(lo) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
