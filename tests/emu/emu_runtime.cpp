@@ -113,17 +113,6 @@ f32x16_t mfma_32x32x2(float a, float b, f32x16_t c) {
     return d;
 }
 
-void global_load_lds(const void* g, void* lds, int size) {
-    WaveState& w = g_waves[g_cur / 64];
-    const int lane = g_cur & 63, par = w.gen & 1;
-    w.gp[par][lane] = g;
-    w.lp[par][lane] = lds;
-    if (w.alive != 64) throw std::runtime_error("emu: global_load_lds needs a full, converged wave");
-    wave_rendezvous(w);
-    // every lane copies its own element to (lane 0's LDS pointer) + lane*size
-    memcpy(static_cast<unsigned char*>(w.lp[par][0]) + (size_t)lane * size, w.gp[par][lane], size);
-}
-
 f32x16_t mfma_bf16_32x32x16(const void* a16, const void* b16, f32x16_t c) {
     // lane l holds A[i = l&31][k = 8*(l>>5) + 0..7] and B[k = 8*(l>>5) + 0..7][j = l&31] as bf16; products are
     // exact in fp32, accumulated in k order (the hardware's internal order may differ: same error class)

@@ -50,7 +50,6 @@ void syncthreads();
 float shfl_xor(float v, int mask);
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 f32x16_t mfma_32x32x2(float a, float b, f32x16_t c);
-void global_load_lds(const void* g, void* lds, int size);
 void buf_dma16(const unsigned char* base, unsigned bytes, unsigned voff, unsigned soff, unsigned char* lds);
 f32x16_t mfma_bf16_32x32x16(const void* a16, const void* b16, f32x16_t c);
 }  // namespace emu
@@ -70,12 +69,6 @@ static inline double __shfl_xor(double v, int mask) {
     return r.d;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2((a), (b), (c))
-// LDS-DMA: destination = the wave's FIRST lane's LDS pointer + lane*size (the per-lane pointers of the
-// other lanes are ignored, exactly the hardware's M0 semantics), source address per lane.
-#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::global_load_lds((const void*)(g), (void*)(l), (size))
-// the one hook the kernels expose for their inline-asm LDS-DMA (conv_glds.hpp)
-#define TSNET_GLDS16(g, lds) emu::global_load_lds((const void*)(g), (void*)(lds), 16)
-#define TSNET_LDS_ADDR(p) (p)
 // hooks of conv_dma.hpp (buffer_load ... lds): descriptor = (base, bytes), out-of-range lanes read zeros
 struct tsnet_rsrc_t { const unsigned char* base; unsigned bytes; };
 typedef unsigned char* tsnet_lds_t;

@@ -8,19 +8,15 @@ import op_cases as oc
 TOL = 2e-5
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("bk32", [0, 1])
-def test_conv_tiles(emu_lib, tile, bk32, monkeypatch):
-    """every (tile, BK) instantiation of the implicit-GEMM kernel, forced through the tuning hook"""
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_conv_tiles(emu_lib, tile, monkeypatch):
+    """every tile of the fp32 LDS-DMA kernel (conv_dma) and, with the in-loader IN+ReLU, of the register-staged one"""
+    monkeypatch.setenv("TSNET_DMA_TILE", str(tile))
     monkeypatch.setenv("TSNET_CONV_TILE", str(tile))
-    monkeypatch.setenv("TSNET_CONV_BK32", str(bk32))
-    assert oc.conv_case(emu_lib, "cpu", 2, 11, 13, 16, 256, 3, 1, 1, True, norm=True) < TOL
-    assert oc.conv_case(emu_lib, "cpu", 1, 20, 13, 32, 128, 3, 2, 1, False) < TOL
-    assert oc.conv_case(emu_lib, "cpu", 1, 9, 9, 8, 128, 7, 1, 3, True) < TOL
-
-
-def test_conv_dual_source_forward_is_covered_by_test_emu_forward():
-    pass
+    for norm in (False, True):
+        assert oc.conv_case(emu_lib, "cpu", 2, 11, 13, 16, 256, 3, 1, 1, True, norm=norm) < TOL
+        assert oc.conv_case(emu_lib, "cpu", 1, 20, 13, 32, 128, 3, 2, 1, False, norm=norm) < TOL
+        assert oc.conv_case(emu_lib, "cpu", 1, 9, 9, 8, 128, 7, 1, 3, True, norm=norm) < TOL
 
 
 @pytest.mark.parametrize("k,stride,pad,reflect", [(7, 1, 3, True), (3, 2, 1, False), (3, 1, 1, True), (1, 1, 0, False)])
@@ -72,3 +68,16 @@ def test_flow_many_tiles(emu_lib):
 
 def test_warp_out_of_range(emu_lib):
     assert oc.warp_case(emu_lib, "cpu", 2, 5, 6, 16) < TOL
+
+
+@pytest.mark.parametrize("tile", [0, 2, 3, 4, 5, 6, 7, 8])
+def test_conv_x3_tiles(emu_lib, tile):
+    """bf16x3 kernel (3-way bf16 split on the bf16 MFMA), every tile / ring configuration"""
+    assert oc.conv_x3_case(emu_lib, "cpu", 2, 11, 13, 16, 256, 3, 1, 1, True, tile=tile) < TOL
+    assert oc.conv_x3_case(emu_lib, "cpu", 1, 20, 13, 32, 128, 3, 2, 1, False, tile=tile) < TOL
+    assert oc.conv_x3_case(emu_lib, "cpu", 1, 9, 9, 8, 128, 7, 1, 3, True, tile=tile) < TOL
+
+
+def test_conv_x3_1x1_and_ragged(emu_lib):
+    assert oc.conv_x3_case(emu_lib, "cpu", 3, 6, 5, 128, 160, 1, 1, 0, False) < TOL
+    assert oc.conv_x3_case(emu_lib, "cpu", 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL

@@ -78,3 +78,21 @@ def test_flow_ragged_positions(lib):
 
 def test_warp_out_of_range(lib):
     assert oc.warp_case(lib, DEV, 2, 16, 12, 128) < TOL
+
+
+# ---- bf16x3 conv kernel (conv_x3.hpp): same cases, same fp32-class tolerance as the fp32-MFMA kernel
+@pytest.mark.parametrize("tile", [0, 4, 5, 6, 7, 8])
+def test_conv_x3_tiles(lib, tile):
+    assert oc.conv_x3_case(lib, DEV, 4, 32, 32, 64, 256, 3, 1, 1, True, tile=tile) < TOL
+    assert oc.conv_x3_case(lib, DEV, 2, 24, 20, 32, 128, 3, 2, 1, False, tile=tile) < TOL
+
+
+@pytest.mark.parametrize("k,stride,pad,reflect,cin", [(7, 1, 3, True, 8), (7, 1, 3, True, 32), (1, 1, 0, False, 128), (3, 1, 1, True, 16)])
+def test_conv_x3_kinds(lib, k, stride, pad, reflect, cin):
+    assert oc.conv_x3_case(lib, DEV, 2, 24, 20, cin, 64, k, stride, pad, reflect) < TOL
+
+
+def test_conv_x3_big_layers(lib):
+    assert oc.conv_x3_case(lib, DEV, 12, 32, 32, 512, 512, 3, 1, 1, True) < TOL
+    assert oc.conv_x3_case(lib, DEV, 2, 16, 16, 1024, 1024, 3, 1, 1, True) < 1e-4
+    assert oc.conv_x3_case(lib, DEV, 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL

@@ -23,27 +23,26 @@ LAYERS = [
     ("lbl_stem",    4, 256, 256,   8,   64, 7, 1, 3, 1, 0),
     ("lbl_down3",   4,  64,  64, 256,  512, 3, 2, 1, 0, 1),
 ]
-TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (96, 128)}
-XT = {0: (128, 128), 1: (128, 128), 2: (128, 128), 3: (128, 128), 4: (128, 64), 5: (64, 64), 6: (64, 128), 7: (96, 128)}
-WT = {0: (128, 128), 1: (128, 64), 2: (128, 128), 3: (64, 64)}
-GT = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (128, 128), 5: (128, 128)}
+TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32)}
+DT = TILES
+XT = {0: (128, 128), 1: (128, 128), 2: (128, 128), 3: (128, 128), 4: (128, 64), 5: (64, 64), 6: (64, 128), 7: (96, 128), 8: (128, 32)}
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
     npad = (Cout + 127) // 128 * 128 if Cout >= 128 else (Cout + 31) // 32 * 32
     res = []
-    for v in ([4096 + 64, 4097 + 64, 4098 + 64] + [8192 + t for t in (0, 4, 5, 6, 7)] if quick else [0, 1, 4, 8 + 4, 64, 65, 66, 67, 192, 193, 194, 195, 4096 + 64, 4097 + 64, 4098 + 64, 4099 + 64]):
-        tl = XT if v & 8192 else (WT if v & 128 else (GT if v & 64 else TILES))
+    for v in ([0, 1, 2] + [4096 + t for t in (0, 1, 2, 3)] + [8192 + t for t in (0, 4, 5, 6, 7, 8)]):
+        tl = XT if v & 8192 else (DT if v & 4096 else TILES)
         if npad % tl[v & 15][1] or (tl[v & 15][1] > 32 and Cout <= tl[v & 15][1] // 2):
             continue
         ms = C.c_float()
         iters = 5 if flops > 5e10 else 10
-        rc = lib.tsnet_bench_conv(N, H, W, Cin, Cout, k, s, p, refl, 0 if v & (64 | 8192) else norm, v, iters, C.byref(ms), None)
+        rc = lib.tsnet_bench_conv(N, H, W, Cin, Cout, k, s, p, refl, 0 if v & (4096 | 8192) else norm, v, iters, C.byref(ms), None)
         if rc != 0:
             print(name, v, "ERR", lib.tsnet_op_last_error().decode()); continue
         res.append((v, ms.value, flops / ms.value / 1e9))
     if not res: continue
     best = max(r[2] for r in res)
     print(f"{name:10s} M={N*Ho*Wo:7d} N={Cout:5d} K={Cin*k*k:5d} GF={flops/1e9:7.1f} | " +
-          " ".join(f"{('h' if v < 0 else ('%s%d%s' % ('X' if v & 8192 else 'D' if v & 4096 else ('W' if v & 128 else ('G' if v & 64 else 't')), v & 15, 'k32' if v & 8 else '')))}:{ms:.3f}ms/{tf:.0f}TF{'*' if tf == best else ''}" for v, ms, tf in res), flush=True)
+          " ".join(f"{('h' if v < 0 else ('%s%d' % ('X' if v & 8192 else 'D' if v & 4096 else 't', v & 15)))}:{ms:.3f}ms/{tf:.0f}TF{'*' if tf == best else ''}" for v, ms, tf in res), flush=True)

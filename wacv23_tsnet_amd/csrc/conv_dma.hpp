@@ -2,7 +2,7 @@
 //
 // Third generation of the conv kernel (history and measurements: profiles/round1_notes.md):
 //   conv_igemm.hpp  register-staged loads                      ~90 TF   (global-load latency exposed)
-//   conv_glds.hpp   global_load_lds ring, per-lane 64-bit math ~100 TF  (MFMA pipe 70 % busy: the DMA
+//   (removed)       global_load_lds ring, per-lane 64-bit math ~100 TF  (MFMA pipe 70 % busy: the DMA
 //                   path doubled the VALU instruction count; ~6 non-MFMA instructions per MFMA)
 //   this file       buffer_load ... lds with a buffer descriptor: the hardware adds
 //                   base + voffset(VGPR, per lane, changes once per filter tap) + soffset(SGPR, the
@@ -18,9 +18,29 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "conv_glds.hpp"
+#include "conv_igemm.hpp"
 
 namespace tsnet {
+
+struct DmaArgs {
+    const float* x;         // source 0, NHWC (N,H,W,Csplit)
+    const float* x2;        // source 1 (channels >= Csplit) or null
+    const float* w;         // packed [K/16][Npad][4 k-quads (swizzled)][4]
+    const float* bias;
+    float* y;
+    double* stat_part;      // null, or (N, tiles_per_img, Cout, 2) per-tile sum / sum-of-squares of y (conv_dma only)
+    const float* addend;    // null, or NHWC (add_nmod, Ho, Wo, Cout) added to y before statistics (conv_dma only)
+    int add_nmod;           // image index into addend = img % add_nmod
+    int N, H, W, Cin, cin_log2, Csplit, x2_nmod;
+    int Ho, Wo, Cout, Npad;
+    int stride, pad, reflect, taps, nchunks, M;
+    int act, out_nchw, composite, fore_x0, fore_x1;
+    float bg[3];
+    int tiles_m, tiles_n;
+};
+
+// s_waitcnt vmcnt(n) only (expcnt / lgkmcnt left unconstrained); gfx9 simm16 encoding
+#define TSNET_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14))
 
 // ---- the hardware hook (tests/emu predefines these four names to run the kernel on the CPU) ----
 #ifndef TSNET_BUF_DMA16
@@ -47,7 +67,7 @@ constexpr unsigned kOOB = 0x80000000u;   // voffset of a lane that must read zer
 
 template <int KS, int BM, int BN, int WARPS_M, int WARPS_N, bool SMALL_CIN>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N)
-void conv_dma_kernel(GldsArgs a) {
+void conv_dma_kernel(DmaArgs a) {
     constexpr int KQ = 4, NSTAGE = 4;
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -308,6 +328,29 @@ void conv_dma_kernel(GldsArgs a) {
             double* o = a.stat_part + (((size_t)img * tiles_per_img + tile_in_img) * a.Cout + n0 + tid) * 2;
             o[0] = s; o[1] = q;
         }
+    }
+}
+
+// OIHW -> [K/16][Npad][4 physical quads][4], physical quad p of column n holds logical quad p ^ ((n>>2)&3)
+// The packed layer may take a window [cin_off, cin_off+cin_real) of the parameter's cin_total input channels
+// (FuseNet's first conv is split into its source half and its shared target half).
+__global__ void pack_weights_dma_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                         int cout, int cin_real, int cin_pad, int ks, int kpad, int npad, int cin_total, int cin_off) {
+    const size_t total = (size_t)kpad * npad;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 3;
+        const int p = (idx >> 2) & 3;
+        const size_t rest = idx >> 4;
+        const int n = (int)(rest % npad);
+        const int kc = (int)(rest / npad);
+        const int k = kc * 16 + (p ^ ((n >> 2) & 3)) * 4 + e;
+        const int tap = k / cin_pad, c = k - tap * cin_pad;
+        float v = 0.f;
+        if (tap < ks * ks && c < cin_real && n < cout) {
+            const int ky = tap / ks, kx = tap - ky * ks;
+            v = w[(((size_t)n * cin_total + cin_off + c) * ks + ky) * ks + kx];
+        }
+        out[idx] = v;
     }
 }
 

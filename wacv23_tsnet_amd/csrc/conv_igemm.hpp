@@ -57,9 +57,7 @@ struct alignas(16) F4 { float v[4]; };
 
 __device__ __forceinline__ F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
 
-// ABL (ablation, tools/conv_sweep.py only): 0 = real kernel; 1 = no global loads inside the K loop;
-// 2 = additionally no LDS stores / barriers (LDS-read + MFMA only).  ABL != 0 computes garbage.
-template <int KS, int BM, int BN, int BK, int WARPS_M, int WARPS_N, int FLUSH, int ABL = 0>
+template <int KS, int BM, int BN, int BK, int WARPS_M, int WARPS_N, int FLUSH>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N)
 void conv_igemm_kernel(ConvArgs a) {
     constexpr int NT = 64 * WARPS_M * WARPS_N;
@@ -211,7 +209,7 @@ void conv_igemm_kernel(ConvArgs a) {
     for (int kc = 0; kc < a.nchunks; ++kc) {
         const int buf = kc & 1;
         const bool more = kc + 1 < a.nchunks;
-        if (more && ABL == 0) load_chunk(kc + 1);
+        if (more) load_chunk(kc + 1);
 
         const F4* cA = sA + buf * KQ * LDA;
         const F4* cB = sB + buf * KQ * LDB;
@@ -242,10 +240,8 @@ void conv_igemm_kernel(ConvArgs a) {
                 }
         }
 
-        if (ABL < 2) {
-            if (more) store_chunk(buf ^ 1);
-            __syncthreads();
-        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
     }
 
     // ---- epilogue: bias, activation, store.  D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)

@@ -28,7 +28,6 @@
 
 #include "../../include/tsnet_abi.h"
 #include "conv_dma.hpp"
-#include "conv_glds.hpp"
 #include "conv_igemm.hpp"
 #include "conv_x3.hpp"
 #include "flow_warp.hpp"
@@ -40,7 +39,7 @@ using namespace tsnet;
 namespace {
 
 thread_local std::string g_op_error;
-int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] conv_glds(+ws), [1] conv_igemm, [2] conv_dma
+int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] unused, [1] conv_igemm, [2] conv_dma, [3] conv_x3
 std::string g_create_error;
 
 #define HIP_TRY(expr)                                                                               \
@@ -127,12 +126,12 @@ struct ConvLayer {
     int kpad = 0, npad = 0;
     size_t w_off = 0, w2_off = 0, b_off = 0;  // offsets (floats) into the packed buffer
     const float* w = nullptr;     // device, packed for conv_igemm_kernel  [K/4][Npad][4]
-    const float* w2 = nullptr;    // device, packed for conv_glds_kernel   [K/16][Npad][4 swizzled quads][4]
+    const float* w2 = nullptr;    // device, packed for conv_dma_kernel    [K/16][Npad][4 swizzled quads][4]
     const unsigned short* w3 = nullptr;   // device, bf16x3 planes for conv_x3_kernel [3][K/16][Npad][2 octets][8]
     const float* bias = nullptr;  // device (cout)
 };
 
-constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded so both BK=16 and BK=32 kernels can stream them
+constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded to an even number of 16-deep chunks (ring prefetch may run one past the end)
 constexpr int FLUSH_K = 64;      // fold the MFMA chain into the running total every 64 products (conv_igemm.hpp)
 
 inline int conv_kpad(int ks, int cin_pad) { return round_up(ks * ks * cin_pad, KPAD_ALIGN); }
@@ -152,113 +151,58 @@ struct ConvCall {
 };
 
 struct TileCfg { int bm, bn, wm, wn; double eff; };
-// eff: relative per-tile efficiency used by the selection heuristic (measured)
-const TileCfg kTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 4, 1, 0.7}, {96, 128, 1, 4, 0.97}};
-constexpr int kNumTiles = 5;
+// register-staged kernel (conv_igemm.hpp): kept for convs that apply IN+ReLU in the loader (op tests) and as the
+// fallback for tensors too large for 32-bit buffer offsets
+const TileCfg kTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 4, 1, 0.7}};
+constexpr int kNumTiles = 4;
+constexpr int BK = 16;
 
-template <int KS, int BM, int BN, int BK_, int WM_, int WN_>
+template <int KS, int BM, int BN, int WM_, int WN_>
 void launch_conv_t(const ConvArgs& a, hipStream_t s) {
-    constexpr int KQ = BK_ / 4, PAD = 8 / KQ;
+    constexpr int KQ = BK / 4, PAD = 8 / KQ;
     const size_t lds = (size_t)2 * KQ * ((BM + PAD) + (BN + PAD)) * 16;
-    auto kern = conv_igemm_kernel<KS, BM, BN, BK_, WM_, WN_, FLUSH_K / BK_>;
-    if (lds > 48 * 1024) {
-        static bool done = false;   // per instantiation
-        if (!done) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
-}
-
-template <int BM, int BN, int BK_, int WM_, int WN_, int ABL>
-void launch_conv_abl(const ConvArgs& a, hipStream_t s) {     // 3x3 only, diagnostic
-    constexpr int KQ = BK_ / 4, PAD = 8 / KQ;
-    const size_t lds = (size_t)2 * KQ * ((BM + PAD) + (BN + PAD)) * 16;
-    auto kern = conv_igemm_kernel<3, BM, BN, BK_, WM_, WN_, FLUSH_K / BK_, ABL>;
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
-}
-
-template <int KS, int BK_>
-void launch_conv_tile(const ConvArgs& a, int tile, hipStream_t s) {
-    switch (tile) {
-        case 0: launch_conv_t<KS, 128, 128, BK_, 2, 2>(a, s); break;
-        case 1: launch_conv_t<KS, 128, 64, BK_, 2, 2>(a, s); break;
-        case 2: launch_conv_t<KS, 64, 64, BK_, 2, 2>(a, s); break;
-        case 3: launch_conv_t<KS, 128, 32, BK_, 4, 1>(a, s); break;
-        default: launch_conv_t<KS, 96, 128, BK_, 1, 4>(a, s); break;
-    }
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, BM, BN, BK, WM_, WN_, FLUSH_K / BK>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
 }
 
 // Tile choice: minimise (sequential tiles per CU) x (tile area) / efficiency.  The 256 CUs each run
 // ceil(tiles/256) tiles back to back (co-resident blocks share the MFMA pipe, so residency does not
 // change this count), which makes tile-count quantisation the first-order term at B=4.
-int choose_variant(const ConvArgs& a, int forced) {
-    const char* e_tile = getenv("TSNET_CONV_TILE");   // test / tuning hooks
-    const char* e_bk32 = getenv("TSNET_CONV_BK32");
-    const int env_tile = e_tile ? atoi(e_tile) : -1, env_bk32 = e_bk32 ? atoi(e_bk32) : 0;
-    if (forced >= 0) return forced;
-    int best = -1; double best_cost = 0;
-    for (int i = 0; i < kNumTiles; ++i) {
-        if (a.Npad % kTiles[i].bn) continue;
-        if (env_tile >= 0 && env_tile < kNumTiles && a.Npad % kTiles[env_tile].bn == 0) { best = env_tile; break; }
-        if (kTiles[i].bn > 32 && a.Cout <= kTiles[i].bn / 2) continue;   // don't waste half the columns
-        const long tm = (a.M + kTiles[i].bm - 1) / kTiles[i].bm, tn = (a.Cout + kTiles[i].bn - 1) / kTiles[i].bn;
-        const long seq = (tm * tn + 255) / 256;
-        const double cost = (double)seq * kTiles[i].bm * kTiles[i].bn / kTiles[i].eff;
-        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
-    }
-    if (best < 0) throw std::runtime_error("conv: no tile configuration for Npad");
-    return best + (env_bk32 ? 8 : 0);
-}
-
 template <int KS>
 void launch_conv_ks(const ConvArgs& a0, int forced, hipStream_t s) {
     ConvArgs a = a0;
-    const int v = choose_variant(a, forced);
-    const int tile = v & 7, bk = (v & 8) ? 32 : 16, abl = (v >> 4) & 3;
-    if (tile >= kNumTiles || a.Npad % kTiles[tile].bn) throw ArgError("conv: tile variant does not divide the padded width");
-    a.tiles_m = (a.M + kTiles[tile].bm - 1) / kTiles[tile].bm;
-    a.tiles_n = (a.Cout + kTiles[tile].bn - 1) / kTiles[tile].bn;
-    a.nchunks = (a.taps * a.Cin + bk - 1) / bk;
-    if (abl && KS == 3) {
-        if (tile == 0 && bk == 16) { if (abl == 1) launch_conv_abl<128, 128, 16, 2, 2, 1>(a, s); else launch_conv_abl<128, 128, 16, 2, 2, 2>(a, s); return; }
-        if (tile == 4 && bk == 32) { if (abl == 1) launch_conv_abl<96, 128, 32, 1, 4, 1>(a, s); else launch_conv_abl<96, 128, 32, 1, 4, 2>(a, s); return; }
-        throw ArgError("conv: ablation variants exist for (tile0,BK16) and (tile4,BK32) only");
+    int best = forced >= 0 ? (forced & 7) : -1;
+    if (best < 0) {
+        const char* e_tile = getenv("TSNET_CONV_TILE");   // test / tuning hook
+        double best_cost = 0;
+        for (int i = 0; i < kNumTiles; ++i) {
+            if (a.Npad % kTiles[i].bn) continue;
+            if (e_tile && atoi(e_tile) == i) { best = i; break; }
+            if (kTiles[i].bn > 32 && a.Cout <= kTiles[i].bn / 2) continue;   // don't waste half the columns
+            const long tm = (a.M + kTiles[i].bm - 1) / kTiles[i].bm, tn = (a.Cout + kTiles[i].bn - 1) / kTiles[i].bn;
+            const double cost = (double)((tm * tn + 255) / 256) * kTiles[i].bm * kTiles[i].bn / kTiles[i].eff;
+            if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+        }
     }
-    if (bk == 32) launch_conv_tile<KS, 32>(a, tile, s); else launch_conv_tile<KS, 16>(a, tile, s);
+    if (best < 0 || best >= kNumTiles || a.Npad % kTiles[best].bn) throw ArgError("conv: no tile configuration for the padded width");
+    a.tiles_m = (a.M + kTiles[best].bm - 1) / kTiles[best].bm;
+    a.tiles_n = (a.Cout + kTiles[best].bn - 1) / kTiles[best].bn;
+    a.nchunks = (a.taps * a.Cin + BK - 1) / BK;
+    switch (best) {
+        case 0: launch_conv_t<KS, 128, 128, 2, 2>(a, s); break;
+        case 1: launch_conv_t<KS, 128, 64, 2, 2>(a, s); break;
+        case 2: launch_conv_t<KS, 64, 64, 2, 2>(a, s); break;
+        default: launch_conv_t<KS, 128, 32, 4, 1>(a, s); break;
+    }
 }
 
-// ---- LDS-DMA kernel (conv_glds.hpp): tiles whose A and B images split into whole wave DMAs
+// buffer-descriptor LDS-DMA kernel on the fp32 MFMA (conv_dma.hpp)
 struct GTileCfg { int bm, bn, wm, wn; double eff; };
-const GTileCfg kGTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 2, 1, 0.7}, {128, 128, 4, 2, 0.0}, {128, 128, 2, 4, 0.0}};
-constexpr int kNumGTiles = 6;   // 4,5: 8-wave experiments (eff 0 = never chosen by the heuristic)
-
-const float* zero_page() {
-    static float* zp = nullptr;
-    if (!zp) {
-        HIP_TRY(hipMalloc((void**)&zp, 256));
-        HIP_TRY(hipMemset(zp, 0, 256));
-    }
-    return zp;
-}
-
-template <int KS, int BM, int BN, int WM_, int WN_>
-void launch_glds_t(const GldsArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)4 * (BM + BN) * 4 * 16;     // NSTAGE x (A + B image)
-    auto kern = conv_glds_kernel<KS, BM, BN, WM_, WN_, FLUSH_K / 16>;
-    if (lds > 48 * 1024) {
-        static bool done = false;
-        if (!done) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
-}
-
-// lean buffer-descriptor LDS-DMA kernel (conv_dma.hpp): the default conv path
 // eff = measured per-tile efficiency relative to 128x128 (gpurun sweep4, profiles/round1_notes.md)
 const GTileCfg kDTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.99}, {64, 64, 2, 2, 0.96}, {128, 32, 2, 1, 0.7}};
 constexpr int kNumDTiles = 4;
 
 template <int KS, int BM, int BN, int WM_, int WN_>
-void launch_dma_t(const GldsArgs& a, hipStream_t s) {
+void launch_dma_t(const DmaArgs& a, hipStream_t s) {
     const size_t lds = (size_t)4 * (BM + BN) * 4 * 16;
     const bool small = a.Cin < 16;
     auto kern = small ? conv_dma_kernel<KS, BM, BN, WM_, WN_, true> : conv_dma_kernel<KS, BM, BN, WM_, WN_, false>;
@@ -267,7 +211,7 @@ void launch_dma_t(const GldsArgs& a, hipStream_t s) {
 }
 
 template <int KS>
-int launch_dma_ks(GldsArgs a, int forced_tile, hipStream_t s) {   // returns stats partials per image (0 = none)
+int launch_dma_ks(DmaArgs a, int forced_tile, hipStream_t s) {   // returns stats partials per image (0 = none)
     int best = forced_tile;
     if (best < 0) {
         const char* e_tile = getenv("TSNET_DMA_TILE");
@@ -293,72 +237,6 @@ int launch_dma_ks(GldsArgs a, int forced_tile, hipStream_t s) {   // returns sta
         default: launch_dma_t<KS, 128, 32, 2, 1>(a, s); break;
     }
     return a.stat_part ? hw / kDTiles[best].bm : 0;
-}
-
-// wave-specialised kernel: tile index 8.. in the glds variant space
-template <int KS, int BM, int BN, int WM_, int WN_, int NL>
-void launch_ws_t(const GldsArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)4 * (BM + BN) * 4 * 16;
-    const bool small = a.Cin < 16;
-    auto kern = small ? conv_glds_ws_kernel<KS, BM, BN, WM_, WN_, NL, FLUSH_K / 16, true>
-                      : conv_glds_ws_kernel<KS, BM, BN, WM_, WN_, NL, FLUSH_K / 16, false>;
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * (WM_ * WN_ + NL)), lds, s, a);
-}
-
-struct WTileCfg { int bm, bn, wm, wn, nl; double eff; };
-const WTileCfg kWTiles[] = {{128, 128, 2, 2, 1, 1.0}, {128, 64, 2, 2, 2, 0.93}, {128, 128, 2, 2, 2, 0.0}, {64, 64, 2, 2, 1, 0.8}};
-constexpr int kNumWTiles = 4;
-
-template <int KS>
-void launch_ws_ks(GldsArgs a, int tile, hipStream_t s) {
-    if (tile < 0 || tile >= kNumWTiles || a.Npad % kWTiles[tile].bn) throw ArgError("conv(ws): bad tile");
-    a.tiles_m = (a.M + kWTiles[tile].bm - 1) / kWTiles[tile].bm;
-    a.tiles_n = (a.Cout + kWTiles[tile].bn - 1) / kWTiles[tile].bn;
-    switch (tile) {
-        case 0: launch_ws_t<KS, 128, 128, 2, 2, 1>(a, s); break;
-        case 1: launch_ws_t<KS, 128, 64, 2, 2, 2>(a, s); break;
-        case 2: launch_ws_t<KS, 128, 128, 2, 2, 2>(a, s); break;
-        default: launch_ws_t<KS, 64, 64, 2, 2, 1>(a, s); break;
-    }
-}
-
-template <int ABL>
-void launch_glds_abl(const GldsArgs& a, hipStream_t s) {    // 3x3, 128x128 tile only; diagnostic
-    const size_t lds = (size_t)4 * (128 + 128) * 4 * 16;
-    auto kern = conv_glds_kernel<3, 128, 128, 2, 2, FLUSH_K / 16, ABL>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-}
-
-template <int KS>
-void launch_glds_ks(GldsArgs a, int forced_tile, hipStream_t s) {
-    int best = forced_tile;
-    if (best < 0) {
-        const char* e_tile = getenv("TSNET_GLDS_TILE");
-        const int env_tile = e_tile ? atoi(e_tile) : -1;
-        double best_cost = 0;
-        for (int i = 0; i < kNumGTiles; ++i) {
-            if (a.Npad % kGTiles[i].bn) continue;
-            if (env_tile >= 0 && env_tile < kNumGTiles && a.Npad % kGTiles[env_tile].bn == 0) { best = env_tile; break; }
-            if (kGTiles[i].eff <= 0 || (kGTiles[i].bn > 32 && a.Cout <= kGTiles[i].bn / 2)) continue;
-            const long tm = (a.M + kGTiles[i].bm - 1) / kGTiles[i].bm, tn = (a.Cout + kGTiles[i].bn - 1) / kGTiles[i].bn;
-            const long seq = (tm * tn + 255) / 256;
-            const double cost = (double)seq * kGTiles[i].bm * kGTiles[i].bn / kGTiles[i].eff;
-            if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
-        }
-    }
-    if (best < 0 || best >= kNumGTiles || a.Npad % kGTiles[best].bn) throw ArgError("conv(glds): no tile configuration");
-    a.tiles_m = (a.M + kGTiles[best].bm - 1) / kGTiles[best].bm;
-    a.tiles_n = (a.Cout + kGTiles[best].bn - 1) / kGTiles[best].bn;
-    switch (best) {
-        case 0: launch_glds_t<KS, 128, 128, 2, 2>(a, s); break;
-        case 1: launch_glds_t<KS, 128, 64, 2, 2>(a, s); break;
-        case 2: launch_glds_t<KS, 64, 64, 2, 2>(a, s); break;
-        case 3: launch_glds_t<KS, 128, 32, 2, 1>(a, s); break;
-        case 4: launch_glds_t<KS, 128, 128, 4, 2>(a, s); break;
-        default: launch_glds_t<KS, 128, 128, 2, 4>(a, s); break;
-    }
 }
 
 // ---- bf16x3 kernel (conv_x3.hpp)
@@ -458,22 +336,28 @@ void run_split3(Ctx& ctx, const float* x, unsigned short* out, size_t elems) {
     check_launch("split3");
 }
 
-bool use_glds_path(const ConvLayer& L, const ConvCall& c) {
-    if (c.alpha || !L.w2) return false;                 // the DMA cannot apply the IN+ReLU transform
-    if (c.variant >= 0) return (c.variant & 64) != 0;   // bench / test hook
+// fp32-MFMA path selection: conv_dma unless the call needs the in-loader IN+ReLU transform (op tests, TSNET_CONV_LEGACY=1)
+// or a tensor is too large for 32-bit buffer offsets / the out-of-range marker
+bool use_dma_path(const ConvLayer& L, const ConvCall& c, int Ho, int Wo) {
+    if (c.alpha || !L.w2) return false;
+    if (c.variant >= 0) return (c.variant & 4096) != 0;   // bench hook
     const char* e = getenv("TSNET_CONV_LEGACY");
-    return !(e && atoi(e));
+    if (e && atoi(e)) return false;
+    const int csplit = c.x2 ? c.csplit : L.cin_pad;
+    return (double)c.N * c.H * c.W * csplit * 4 < 2147483648.0 && (double)(c.x2_nmod > 0 ? c.x2_nmod : 1) * c.H * c.W * (L.cin_pad - csplit) * 4 < 2147483648.0 &&
+           (double)L.kpad * L.npad * 4 < 2147483648.0 && (double)c.N * Ho * Wo * L.cout < 2147483647.0;
 }
 
 void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
-    if (use_glds_path(L, c)) {
-        GldsArgs g{};
-        g.x = c.x; g.x2 = c.x2; g.zero_page = zero_page(); g.w = L.w2; g.bias = L.bias; g.y = c.y;
-        g.stat_part = nullptr; c.stat_S = 0; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
+    const int Ho_ = (c.H + 2 * L.pad - L.ks) / L.stride + 1, Wo_ = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
+    c.stat_S = 0;
+    if (use_dma_path(L, c, Ho_, Wo_)) {
+        DmaArgs g{};
+        g.x = c.x; g.x2 = c.x2; g.w = L.w2; g.bias = L.bias; g.y = c.y;
+        g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
         g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
         g.Csplit = c.x2 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
-        g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
-        g.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
+        g.Ho = Ho_; g.Wo = Wo_;
         g.Cout = L.cout; g.Npad = L.npad;
         g.stride = L.stride; g.pad = L.pad; g.reflect = L.reflect;
         g.taps = L.ks * L.ks; g.nchunks = (g.taps * g.Cin + 15) / 16;
@@ -481,83 +365,19 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         g.act = c.act; g.out_nchw = c.out_nchw;
         g.composite = c.composite; g.fore_x0 = 64; g.fore_x1 = 192;
         g.bg[0] = c.bg[0]; g.bg[1] = c.bg[1]; g.bg[2] = c.bg[2];
+        g.stat_part = (c.act == 0 && !c.out_nchw) ? c.stat_part : nullptr;
         if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
-        if ((g.Csplit & 15) && c.x2) throw ArgError("conv(glds): channel split must be a multiple of 16");
-        if ((double)c.N * c.H * c.W * L.cin_pad >= 2147483647.0 || (double)g.M * L.cout >= 2147483647.0)
-            throw ArgError("conv: tensor exceeds 2^31 elements");
+        if ((g.Csplit & 15) && c.x2) throw ArgError("conv(dma): channel split must be a multiple of 16");
         TimeScope ts(ctx, TSNET_T_CONV);
         const int forced = c.variant >= 0 ? (c.variant & 7) : -1;
-        const int abl = c.variant >= 0 ? (c.variant >> 8) & 15 : 0;
-        // kernel generation: default = conv_dma (buffer-descriptor LDS-DMA); TSNET_CONV_KERNEL=glds|ws select the
-        // two predecessors for A/B runs (bench variant bits: 4096 dma, 128 ws, else glds)
-        const char* e_kern = getenv("TSNET_CONV_KERNEL");
-        const bool tensor_small = (double)c.N * c.H * c.W * g.Csplit * 4 < 2147483648.0 &&
-                                  (double)g.x2_nmod * c.H * c.W * (g.Cin - g.Csplit) * 4 < 2147483648.0 &&
-                                  (double)L.kpad * L.npad * 4 < 2147483648.0;      // 32-bit buffer offsets / OOB marker
-        const bool want_dma = c.variant >= 0 ? (c.variant & 4096) != 0 : (!e_kern || !strcmp(e_kern, "dma"));
-        if (want_dma && tensor_small) {
-            g.stat_part = (c.act == 0 && !c.out_nchw) ? c.stat_part : nullptr;
-            switch (L.ks) {
-                case 1: c.stat_S = launch_dma_ks<1>(g, forced, ctx.stream); break;
-                case 3: c.stat_S = launch_dma_ks<3>(g, forced, ctx.stream); break;
-                case 7: c.stat_S = launch_dma_ks<7>(g, forced, ctx.stream); break;
-                default: throw ArgError("conv: kernel size must be 1, 3 or 7");
-            }
-            check_launch("conv_dma");
-            ++g_launch_counters[2];
-            return;
-        }
-        if (c.addend) throw ArgError("conv: an epilogue addend needs the conv_dma kernel");
-        int ws_tile = -1;
-        if (c.variant >= 0) { if (c.variant & 128) ws_tile = forced; }
-        else {
-            if (e_kern && !strcmp(e_kern, "ws")) {
-                const char* e_t = getenv("TSNET_WS_TILE");
-                double best_cost = 0;
-                for (int i = 0; i < kNumWTiles; ++i) {
-                    if (g.Npad % kWTiles[i].bn || kWTiles[i].eff <= 0) continue;
-                    if (e_t && atoi(e_t) == i) { ws_tile = i; break; }
-                    if (kWTiles[i].bn > 32 && g.Cout <= kWTiles[i].bn / 2) continue;
-                    const long tm = (g.M + kWTiles[i].bm - 1) / kWTiles[i].bm, tn = (g.Cout + kWTiles[i].bn - 1) / kWTiles[i].bn;
-                    const double cost = (double)((tm * tn + 255) / 256) * kWTiles[i].bm * kWTiles[i].bn / kWTiles[i].eff;
-                    if (ws_tile < 0 || cost < best_cost) { ws_tile = i; best_cost = cost; }
-                }
-            }
-        }
-        if (ws_tile >= 0) {     // wave-specialised kernel
-            switch (L.ks) {
-                case 1: launch_ws_ks<1>(g, ws_tile, ctx.stream); break;
-                case 3: launch_ws_ks<3>(g, ws_tile, ctx.stream); break;
-                case 7: launch_ws_ks<7>(g, ws_tile, ctx.stream); break;
-                default: throw ArgError("conv: kernel size must be 1, 3 or 7");
-            }
-            check_launch("conv_glds_ws");
-            ++g_launch_counters[0];
-            return;
-        }
-        if (abl && L.ks == 3) {
-            g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.Cout + 127) / 128;
-            switch (abl) {
-                case 1: launch_glds_abl<1>(g, ctx.stream); break;
-                case 2: launch_glds_abl<2>(g, ctx.stream); break;
-                case 3: launch_glds_abl<3>(g, ctx.stream); break;
-                case 4: launch_glds_abl<4>(g, ctx.stream); break;
-                case 7: launch_glds_abl<7>(g, ctx.stream); break;
-                case 11: launch_glds_abl<11>(g, ctx.stream); break;
-                case 15: launch_glds_abl<15>(g, ctx.stream); break;
-                default: throw ArgError("unsupported ablation mask");
-            }
-            check_launch("conv_glds(abl)");
-            return;
-        }
         switch (L.ks) {
-            case 1: launch_glds_ks<1>(g, forced, ctx.stream); break;
-            case 3: launch_glds_ks<3>(g, forced, ctx.stream); break;
-            case 7: launch_glds_ks<7>(g, forced, ctx.stream); break;
+            case 1: c.stat_S = launch_dma_ks<1>(g, forced, ctx.stream); break;
+            case 3: c.stat_S = launch_dma_ks<3>(g, forced, ctx.stream); break;
+            case 7: c.stat_S = launch_dma_ks<7>(g, forced, ctx.stream); break;
             default: throw ArgError("conv: kernel size must be 1, 3 or 7");
         }
-        check_launch("conv_glds");
-        ++g_launch_counters[0];
+        check_launch("conv_dma");
+        ++g_launch_counters[2];
         return;
     }
     if (c.addend) throw ArgError("conv: an epilogue addend needs the conv_dma kernel");
@@ -666,9 +486,9 @@ void pack_layer_weights(const float* w_oihw_dev, float* out_dev, float* out2_dev
                        L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, ct, L.cin_off);
     check_launch("pack_weights");
     if (out2_dev) {
-        hipLaunchKernelGGL(pack_weights_glds_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw_dev, out2_dev,
+        hipLaunchKernelGGL(pack_weights_dma_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw_dev, out2_dev,
                            L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, ct, L.cin_off);
-        check_launch("pack_weights_glds");
+        check_launch("pack_weights_dma");
     }
 }
 
@@ -1294,11 +1114,10 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
         e->build_layers();
         { const char* lg = getenv("TSNET_CONV_LEGACY"); e->fuse_norm_in_loader = lg && atoi(lg); }
         { const char* vh = getenv("TSNET_VECTOR_HEAD"); e->vector_head = !(vh && !atoi(vh)); }
-        { const char* x = getenv("TSNET_X3"); const char* k = getenv("TSNET_CONV_KERNEL");
+        { const char* x = getenv("TSNET_X3");
           // bf16x3 convs (conv_x3.hpp): needs 16-channel granularity everywhere except the stems, and the vector head
-          e->x3 = !(x && !atoi(x)) && (cfg->ngf % 16 == 0) && !k && e->vector_head && !e->fuse_norm_in_loader; }
-        { const char* k = getenv("TSNET_CONV_KERNEL"); const char* sf = getenv("TSNET_SPLIT_FUSE");
-          e->split_fuse = !e->fuse_norm_in_loader && (!k || !strcmp(k, "dma")) && !(sf && !atoi(sf)); }
+          e->x3 = !(x && !atoi(x)) && (cfg->ngf % 16 == 0) && e->vector_head && !e->fuse_norm_in_loader; }
+        { const char* sf = getenv("TSNET_SPLIT_FUSE"); e->split_fuse = !e->fuse_norm_in_loader && !(sf && !atoi(sf)); }
         *out = e;
     } catch (const std::exception& ex) { g_create_error = ex.what(); return TSNET_ERR_NOMEM; }
     return TSNET_OK;
@@ -1608,7 +1427,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const size_t xn = (size_t)N * H * W * Cin, yn = (size_t)N * Ho * Wo * Cout, wn = (size_t)L.kpad * L.npad;
     float *x = nullptr, *y = nullptr, *w = nullptr, *al = nullptr, *be = nullptr;
-    if (norm && variant >= 0 && (variant & 64)) throw ArgError("bench_conv: the LDS-DMA kernel takes no input transform");
+    if (norm && variant >= 0 && (variant & (4096 | 8192))) throw ArgError("bench_conv: the LDS-DMA kernels take no input transform");
     HIP_TRY(hipMalloc((void**)&x, xn * 4)); HIP_TRY(hipMalloc((void**)&y, yn * 4)); HIP_TRY(hipMalloc((void**)&w, wn * 4));
     HIP_TRY(hipMalloc((void**)&al, (size_t)N * Cin * 4)); HIP_TRY(hipMalloc((void**)&be, (size_t)N * Cin * 4));
     // pseudo-random fill (not zeros: MI355X clocks higher on zero operands, cdna_hip_programming.md rule 25)
