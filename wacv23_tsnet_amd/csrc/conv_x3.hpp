@@ -42,7 +42,9 @@ typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 
 // KC = 16-deep k-groups per ring stage (1 or 2); NSTAGE = ring depth
-template <int KS, int BM, int BN, int WARPS_M, int WARPS_N, int KC, int NSTAGE, bool SMALL_CIN>
+// ABL (tools/x3_ablate.py only; non-zero computes garbage): bit0 no DMA in the loop, bit1 no vmcnt/barrier,
+// bit2 no fold, bit3 no ds_reads (fragments loaded once).
+template <int KS, int BM, int BN, int WARPS_M, int WARPS_N, int KC, int NSTAGE, bool SMALL_CIN, int ABL = 0>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N)
 void conv_x3_kernel(X3Args a) {
     constexpr int NW = WARPS_M * WARPS_N;
@@ -195,11 +197,13 @@ void conv_x3_kernel(X3Args a) {
     // into the running total every 4 k-groups (64 products) counted from k = 0 -- the SAME fold points for every
     // tile shape and ring depth, so a layer's result does not depend on which tile the heuristic picked.
     auto step = [&](int st, int stage, int refill_stage) {
-        TSNET_VMCNT(LPC * (NSTAGE - 2));
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const unsigned char* sbase = smem_raw + stage * STAGE_BYTES;
+        if (!(ABL & 2)) {
+            TSNET_VMCNT(LPC * (NSTAGE - 2));
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        const unsigned char* sbase = smem_raw + ((ABL & 8) ? 0 : stage) * STAGE_BYTES;
 #pragma unroll
         for (int g = 0; g < KC; ++g) {
             const unsigned char* gb = sbase + g * GROUP_BYTES;
@@ -211,7 +215,7 @@ void conv_x3_kernel(X3Args a) {
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) bf[p][j] = *reinterpret_cast<const F4*>(gb + 3 * PLANE_A + p * PLANE_B + j * 1024 + b_off);
             }
-            if (g == 0) issue_step(st + NSTAGE - 1, refill_stage);
+            if (g == 0 && !(ABL & 1)) issue_step(st + NSTAGE - 1, refill_stage);
             // six products per tile, small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -221,7 +225,7 @@ void conv_x3_kernel(X3Args a) {
 #pragma unroll
                     for (int j = 0; j < NTL; ++j)
                         acc[i][j] = TSNET_MFMA_BF16(af[PA[q]][i], bf[PB[q]][j], acc[i][j]);
-            if ((((st * KC + g) + 1) & 3) == 0) {          // wave-uniform
+            if (!(ABL & 4) && (((st * KC + g) + 1) & 3) == 0) {          // wave-uniform
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll

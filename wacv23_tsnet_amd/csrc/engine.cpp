@@ -244,8 +244,9 @@ struct XTileCfg { int bm, bn, wm, wn, kc, nstage; double eff; };
 // eff: per-tile efficiency relative to 128x128 measured by tools/conv_sweep.py (profiles/round1_notes.md); 0 = sweep only
 const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, 1.0}, {128, 128, 2, 2, 1, 4, 0.0}, {128, 128, 2, 2, 2, 3, 0.0},
                             {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, 0.55}, {64, 64, 2, 2, 1, 4, 0.52},
-                            {64, 128, 2, 2, 1, 4, 0.62}, {96, 128, 1, 4, 1, 3, 0.81}, {128, 32, 4, 1, 1, 4, 0.3}};
-constexpr int kNumXTiles = 9;
+                            {64, 128, 2, 2, 1, 4, 0.62}, {96, 128, 1, 4, 1, 3, 0.81}, {128, 32, 4, 1, 1, 4, 0.3},
+                            {128, 128, 4, 2, 1, 3, 0.0}, {128, 128, 2, 4, 1, 3, 0.0}};
+constexpr int kNumXTiles = 11;
 
 template <int KS, int BM, int BN, int WM_, int WN_, int KC, int NST>
 void launch_x3_t(const X3Args& a, hipStream_t s) {
@@ -254,6 +255,15 @@ void launch_x3_t(const X3Args& a, hipStream_t s) {
     auto kern = small ? conv_x3_kernel<KS, BM, BN, WM_, WN_, KC, NST, true> : conv_x3_kernel<KS, BM, BN, WM_, WN_, KC, NST, false>;
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
+}
+
+template <int ABL>
+void launch_x3_abl(X3Args a, hipStream_t s) {     // diagnostic: 3x3, tile 0 (128x128, 4 waves, ring of 3)
+    a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.Cout + 127) / 128;
+    const size_t lds = (size_t)3 * ((size_t)3 * 256 * 32 + 1024);
+    auto kern = conv_x3_kernel<3, 128, 128, 2, 2, 1, 3, false, ABL>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
 template <int KS>
@@ -286,7 +296,9 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         case 5: launch_x3_t<KS, 64, 64, 2, 2, 1, 4>(a, s); break;
         case 6: launch_x3_t<KS, 64, 128, 2, 2, 1, 4>(a, s); break;
         case 7: launch_x3_t<KS, 96, 128, 1, 4, 1, 3>(a, s); break;
-        default: launch_x3_t<KS, 128, 32, 4, 1, 1, 4>(a, s); break;
+        case 8: launch_x3_t<KS, 128, 32, 4, 1, 1, 4>(a, s); break;
+        case 9: launch_x3_t<KS, 128, 128, 4, 2, 1, 3>(a, s); break;
+        default: launch_x3_t<KS, 128, 128, 2, 4, 1, 3>(a, s); break;
     }
     return a.stat_part ? hw / kXTiles[best].bm : 0;
 }
@@ -319,6 +331,21 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
         throw ArgError("conv(x3): tensor too large for 32-bit buffer offsets");
     TimeScope ts(ctx, TSNET_T_CONV);
     const int forced = c.variant >= 0 ? (c.variant & 15) : -1;
+    const int abl = c.variant >= 0 ? (c.variant >> 8) & 15 : 0;
+    if (abl && L.ks == 3) {
+        switch (abl) {
+            case 1: launch_x3_abl<1>(g, ctx.stream); break;
+            case 2: launch_x3_abl<2>(g, ctx.stream); break;
+            case 3: launch_x3_abl<3>(g, ctx.stream); break;
+            case 4: launch_x3_abl<4>(g, ctx.stream); break;
+            case 7: launch_x3_abl<7>(g, ctx.stream); break;
+            case 11: launch_x3_abl<11>(g, ctx.stream); break;
+            case 15: launch_x3_abl<15>(g, ctx.stream); break;
+            default: throw ArgError("unsupported ablation mask");
+        }
+        check_launch("conv_x3(abl)");
+        return;
+    }
     switch (L.ks) {
         case 1: c.stat_S = launch_x3_ks<1>(g, forced, ctx.stream); break;
         case 3: c.stat_S = launch_x3_ks<3>(g, forced, ctx.stream); break;
