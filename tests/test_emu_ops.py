@@ -78,6 +78,14 @@ def test_conv_x3_tiles(emu_lib, tile):
     assert oc.conv_x3_case(emu_lib, "cpu", 1, 9, 9, 8, 128, 7, 1, 3, True, tile=tile) < TOL
 
 
+def test_conv_x3_patch_kernel(emu_lib):
+    """conv_x3p.hpp: input patch resident in LDS, taps as shifted views (tile 11); reflection and zero padding,
+    one and several 16-channel slabs, several tiles per row / per image / per batch"""
+    assert oc.conv_x3_case(emu_lib, "cpu", 2, 8, 32, 16, 128, 3, 1, 1, True, tile=11) < TOL
+    assert oc.conv_x3_case(emu_lib, "cpu", 1, 4, 64, 64, 256, 3, 1, 1, False, tile=11) < TOL
+    assert oc.conv_x3_case(emu_lib, "cpu", 1, 4, 32, 32, 128, 3, 1, 1, False, tile=11, bias=False) < TOL
+
+
 def test_conv_x3_1x1_and_ragged(emu_lib):
     assert oc.conv_x3_case(emu_lib, "cpu", 3, 6, 5, 128, 160, 1, 1, 0, False) < TOL
     assert oc.conv_x3_case(emu_lib, "cpu", 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL

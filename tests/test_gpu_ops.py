@@ -92,6 +92,14 @@ def test_conv_x3_kinds(lib, k, stride, pad, reflect, cin):
     assert oc.conv_x3_case(lib, DEV, 2, 24, 20, cin, 64, k, stride, pad, reflect) < TOL
 
 
+def test_conv_x3_patch_kernel(lib):
+    """conv_x3p.hpp (tile 11): LDS-resident input patch; shapes of the residual, fusion and decoder layers"""
+    assert oc.conv_x3_case(lib, DEV, 12, 32, 32, 512, 512, 3, 1, 1, True, tile=11) < TOL
+    assert oc.conv_x3_case(lib, DEV, 4, 32, 32, 1024, 256, 3, 1, 1, False, tile=11) < 1e-4
+    assert oc.conv_x3_case(lib, DEV, 2, 128, 128, 256, 128, 3, 1, 1, False, tile=11) < TOL
+    assert oc.conv_x3_case(lib, DEV, 1, 4, 256, 16, 128, 3, 1, 1, True, tile=11, bias=False) < TOL
+
+
 def test_conv_x3_big_layers(lib):
     assert oc.conv_x3_case(lib, DEV, 12, 32, 32, 512, 512, 3, 1, 1, True) < TOL
     assert oc.conv_x3_case(lib, DEV, 2, 16, 16, 1024, 1024, 3, 1, 1, True) < 1e-4

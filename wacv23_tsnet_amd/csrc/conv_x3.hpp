@@ -41,9 +41,74 @@ typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
 #define TSNET_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tsnet_bf16x8, a), __builtin_bit_cast(tsnet_bf16x8, b), c, 0, 0, 0)
 #endif
 
+// Shared epilogue of the bf16x3 kernels: bias, optional per-pixel addend, fp64 InstanceNorm partial sums of the tile,
+// fp32 store and/or split-plane store.  m_of(l) maps the local row l of the tile to the output position m (or -1).
+template <int BN, int WARPS_M, int WARPS_N, int MT, int NTL, typename MOf>
+__device__ __forceinline__ void x3_epilogue(const X3Args& a, f32x16 (&tot)[MT][NTL], unsigned char* smem_raw, int tid, int wave, int n0,
+                                            size_t stat_tile, MOf m_of) {
+    constexpr int WM = MT * 32, WN = NTL * 32;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WARPS_N) * WM, wn0 = (wave % WARPS_N) * WN;
+    const int hw = a.Ho * a.Wo;
+    double csum[NTL], csq[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) { csum[j] = 0.0; csq[j] = 0.0; }
+    const size_t yplane = (size_t)a.M * a.Cout;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int n = n0 + wn0 + j * 32 + li;
+            const bool nok = n < a.Cout;
+            const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_of(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+                const bool mok = m >= 0;
+                float v = tot[i][j][r] + bv;
+                if (a.addend && nok && mok) {
+                    const int img = m / hw;
+                    v += a.addend[((size_t)(img % a.add_nmod) * hw + (m - img * hw)) * a.Cout + n];
+                }
+                if (a.stat_part && mok) { csum[j] += (double)v; csq[j] += (double)v * (double)v; }
+                if (!nok || !mok) continue;
+                if (a.y) a.y[(size_t)m * a.Cout + n] = v;
+                if (a.y3) {
+                    unsigned short sh, sm, sl;
+                    split3_scalar(v, sh, sm, sl);
+                    const size_t o = (size_t)m * a.Cout + n;
+                    a.y3[o] = sh; a.y3[yplane + o] = sm; a.y3[2 * yplane + o] = sl;
+                }
+            }
+        }
+    }
+    if (a.stat_part) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem_raw);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const double s2 = csum[j] + __shfl_xor(csum[j], 32);
+            const double q2 = csq[j] + __shfl_xor(csq[j], 32);
+            if (lh == 0) {
+                double* o = red + ((size_t)(wave / WARPS_N) * BN + wn0 + j * 32 + li) * 2;
+                o[0] = s2; o[1] = q2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Cout) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int wmi = 0; wmi < WARPS_M; ++wmi) { s += red[((size_t)wmi * BN + tid) * 2]; q += red[((size_t)wmi * BN + tid) * 2 + 1]; }
+            double* o = a.stat_part + (stat_tile * a.Cout + n0 + tid) * 2;
+            o[0] = s; o[1] = q;
+        }
+    }
+}
+
 // KC = 16-deep k-groups per ring stage (1 or 2); NSTAGE = ring depth
 // ABL (tools/x3_ablate.py only; non-zero computes garbage): bit0 no DMA in the loop, bit1 no vmcnt/barrier,
-// bit2 no fold, bit3 no ds_reads (fragments loaded once).
+// bit2 no fold, bit3 no ds_reads (fragments loaded once), bit4 no B-operand DMAs,
+// bit5 no A-operand DMAs, bit6 A DMAs read contiguous KiBs instead of gathering 32 B per row.
 template <int KS, int BM, int BN, int WARPS_M, int WARPS_N, int KC, int NSTAGE, bool SMALL_CIN, int ABL = 0>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N)
 void conv_x3_kernel(X3Args a) {
@@ -164,9 +229,12 @@ void conv_x3_kernel(X3Args a) {
                     const int e = r * NW + wave;            // wave-uniform list entry
                     if (r < RA && e < TA) {
                         const tsnet_lds_t dst = lg + p * PLANE_A + e * 1024;
+                        if (ABL & 32) continue;
+                        if (ABL & 64) { TSNET_BUF_DMA16(rs1[p], vB, so_a, dst); continue; }
                         if (second) TSNET_BUF_DMA16(rs2[p], vA2[r < RA ? r : 0], so_a, dst);
                         else TSNET_BUF_DMA16(rs1[p], vA1[r < RA ? r : 0], so_a, dst);
                     } else if (e < E) {
+                        if (ABL & 16) continue;
                         const int tb = e - TA;
                         const tsnet_lds_t dst = lg + 3 * PLANE_A + p * PLANE_B + tb * 1024;
                         const unsigned so = (unsigned)((kc * a.Npad + n0 + tb * 32) * 32);
@@ -255,61 +323,9 @@ void conv_x3_kernel(X3Args a) {
 
     // ---- epilogue (as conv_dma.hpp, plus the optional split-plane copy of the output)
     const int hw = a.Ho * a.Wo;
-    double csum[NTL], csq[NTL];
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) { csum[j] = 0.0; csq[j] = 0.0; }
-    const size_t yplane = (size_t)a.M * a.Cout;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-            const int n = n0 + wn0 + j * 32 + li;
-            const bool nok = n < a.Cout;
-            const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = tot[i][j][r] + bv;
-                if (a.addend && nok && m < a.M) {
-                    const int img = m / hw;
-                    v += a.addend[((size_t)(img % a.add_nmod) * hw + (m - img * hw)) * a.Cout + n];
-                }
-                if (a.stat_part && m < a.M) { csum[j] += (double)v; csq[j] += (double)v * (double)v; }
-                if (!nok || m >= a.M) continue;
-                if (a.y) a.y[(size_t)m * a.Cout + n] = v;
-                if (a.y3) {
-                    unsigned short sh, sm, sl;
-                    split3_scalar(v, sh, sm, sl);
-                    const size_t o = (size_t)m * a.Cout + n;
-                    a.y3[o] = sh; a.y3[yplane + o] = sm; a.y3[2 * yplane + o] = sl;
-                }
-            }
-        }
-    }
-    if (a.stat_part) {
-        __syncthreads();
-        double* red = reinterpret_cast<double*>(smem_raw);
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-            const double s2 = csum[j] + __shfl_xor(csum[j], 32);
-            const double q2 = csq[j] + __shfl_xor(csq[j], 32);
-            if (lh == 0) {
-                double* o = red + ((size_t)(wave / WARPS_N) * BN + wn0 + j * 32 + li) * 2;
-                o[0] = s2; o[1] = q2;
-            }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < a.Cout) {
-            double s = 0.0, q = 0.0;
-#pragma unroll
-            for (int wmi = 0; wmi < WARPS_M; ++wmi) { s += red[((size_t)wmi * BN + tid) * 2]; q += red[((size_t)wmi * BN + tid) * 2 + 1]; }
-            const int img = m0 / hw;
-            const int tile_in_img = (m0 - img * hw) / BM;
-            const int tiles_per_img = hw / BM;
-            double* o = a.stat_part + (((size_t)img * tiles_per_img + tile_in_img) * a.Cout + n0 + tid) * 2;
-            o[0] = s; o[1] = q;
-        }
-    }
+    const int img0 = m0 / hw;
+    x3_epilogue<BN, WARPS_M, WARPS_N, MT, NTL>(a, tot, smem_raw, tid, wave, n0, (size_t)img0 * (hw / BM) + (m0 - img0 * hw) / BM,
+                                               [&](int l) { const int m = m0 + l; return m < a.M ? m : -1; });
 }
 
 // OIHW fp32 -> three bf16 planes in image order: plane p, k-group kc, column n, physical octet o, element e:

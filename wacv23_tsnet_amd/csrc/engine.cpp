@@ -30,6 +30,7 @@
 #include "conv_dma.hpp"
 #include "conv_igemm.hpp"
 #include "conv_x3.hpp"
+#include "conv_x3p.hpp"
 #include "flow_warp.hpp"
 #include "head_conv.hpp"
 #include "norm_elementwise.hpp"
@@ -240,13 +241,14 @@ int launch_dma_ks(DmaArgs a, int forced_tile, hipStream_t s) {   // returns stat
 }
 
 // ---- bf16x3 kernel (conv_x3.hpp)
-struct XTileCfg { int bm, bn, wm, wn, kc, nstage; double eff; };
+struct XTileCfg { int bm, bn, wm, wn, kc, nstage; double eff; bool patch = false; };
 // eff: per-tile efficiency relative to 128x128 measured by tools/conv_sweep.py (profiles/round1_notes.md); 0 = sweep only
 const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, 1.0}, {128, 128, 2, 2, 1, 4, 0.0}, {128, 128, 2, 2, 2, 3, 0.0},
                             {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, 0.55}, {64, 64, 2, 2, 1, 4, 0.52},
                             {64, 128, 2, 2, 1, 4, 0.62}, {96, 128, 1, 4, 1, 3, 0.81}, {128, 32, 4, 1, 1, 4, 0.3},
-                            {128, 128, 4, 2, 1, 3, 0.0}, {128, 128, 2, 4, 1, 3, 0.0}};
-constexpr int kNumXTiles = 11;
+                            {128, 128, 4, 2, 1, 3, 0.0}, {128, 128, 2, 4, 1, 3, 0.0},
+                            {128, 128, 2, 2, 1, 3, 1.2, true}};   // conv_x3p.hpp: LDS-resident input patch (3x3, stride 1)
+constexpr int kNumXTiles = 12;
 
 template <int KS, int BM, int BN, int WM_, int WN_, int KC, int NST>
 void launch_x3_t(const X3Args& a, hipStream_t s) {
@@ -255,6 +257,21 @@ void launch_x3_t(const X3Args& a, hipStream_t s) {
     auto kern = small ? conv_x3_kernel<KS, BM, BN, WM_, WN_, KC, NST, true> : conv_x3_kernel<KS, BM, BN, WM_, WN_, KC, NST, false>;
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
+}
+
+// conv_x3p.hpp applies to 3x3 / stride 1 / pad 1 layers whose output splits into 4 x 32 rectangles
+template <int KS>
+bool x3p_ok(const X3Args& a) {
+    return KS == 3 && a.stride == 1 && a.pad == 1 && a.Cin >= 16 && (a.Cin & 15) == 0 && (a.Csplit & 15) == 0 &&
+           a.Ho % kPatchRows == 0 && a.Wo % kPatchCols == 0 && a.H == a.Ho && a.W == a.Wo;
+}
+
+template <int BN, int WM_, int WN_>
+void launch_x3p(const X3Args& a, hipStream_t s) {
+    const size_t lds = 2 * 3 * 7 * 1024 + 3 * 3 * (size_t)BN * 32 + 1024;
+    auto kern = conv_x3p_kernel<BN, WM_, WN_>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
 template <int ABL>
@@ -272,8 +289,13 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
     if (best < 0) {
         const char* e_tile = getenv("TSNET_X3_TILE");
         double best_cost = 0;
+        // the patch kernel sums K slab-major, the others tap-major: which of the two a layer runs on must depend on
+        // the layer alone, never on the batch (results are identical for any batch size and any tile of one family)
+        const bool patch_family = !e_tile && x3p_ok<KS>(a) && a.Npad % 128 == 0;
         for (int i = 0; i < kNumXTiles; ++i) {
+            if (!e_tile && kXTiles[i].patch != patch_family) continue;
             if (a.Npad % kXTiles[i].bn) continue;
+            if (kXTiles[i].patch && !x3p_ok<KS>(a)) continue;
             if (e_tile && atoi(e_tile) == i) { best = i; break; }
             if (kXTiles[i].eff <= 0 || (kXTiles[i].bn > 32 && a.Cout <= kXTiles[i].bn / 2)) continue;
             const long tm = (a.M + kXTiles[i].bm - 1) / kXTiles[i].bm, tn = (a.Cout + kXTiles[i].bn - 1) / kXTiles[i].bn;
@@ -282,7 +304,8 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
             if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
         }
     }
-    if (best < 0 || best >= kNumXTiles || a.Npad % kXTiles[best].bn) throw ArgError("conv(x3): no tile configuration");
+    if (best < 0 || best >= kNumXTiles || a.Npad % kXTiles[best].bn || (kXTiles[best].patch && !x3p_ok<KS>(a)))
+        throw ArgError("conv(x3): no tile configuration");
     a.tiles_m = (a.M + kXTiles[best].bm - 1) / kXTiles[best].bm;
     a.tiles_n = (a.Cout + kXTiles[best].bn - 1) / kXTiles[best].bn;
     const int hw = a.Ho * a.Wo;
@@ -297,6 +320,7 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         case 6: launch_x3_t<KS, 64, 128, 2, 2, 1, 4>(a, s); break;
         case 7: launch_x3_t<KS, 96, 128, 1, 4, 1, 3>(a, s); break;
         case 8: launch_x3_t<KS, 128, 32, 4, 1, 1, 4>(a, s); break;
+        case 11: launch_x3p<128, 2, 2>(a, s); break;
         case 9: launch_x3_t<KS, 128, 128, 4, 2, 1, 3>(a, s); break;
         default: launch_x3_t<KS, 128, 128, 2, 4, 1, 3>(a, s); break;
     }
@@ -331,9 +355,12 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
         throw ArgError("conv(x3): tensor too large for 32-bit buffer offsets");
     TimeScope ts(ctx, TSNET_T_CONV);
     const int forced = c.variant >= 0 ? (c.variant & 15) : -1;
-    const int abl = c.variant >= 0 ? (c.variant >> 8) & 15 : 0;
+    const int abl = c.variant >= 0 ? (c.variant >> 16) & 127 : 0;
     if (abl && L.ks == 3) {
         switch (abl) {
+            case 16: launch_x3_abl<16>(g, ctx.stream); break;
+            case 32: launch_x3_abl<32>(g, ctx.stream); break;
+            case 64: launch_x3_abl<64>(g, ctx.stream); break;
             case 1: launch_x3_abl<1>(g, ctx.stream); break;
             case 2: launch_x3_abl<2>(g, ctx.stream); break;
             case 3: launch_x3_abl<3>(g, ctx.stream); break;
