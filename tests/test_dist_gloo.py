@@ -31,14 +31,14 @@ def _worker(rank, world, port, emu_path, out_dir):
     from wacv23_tsnet_amd.dist import build_replica, shard_range
     from wacv23_tsnet_amd.engine import TSNetEngine
     lib = _lib.bind(ctypes.CDLL(emu_path))
-    cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=2, ngf=8, enc_blocks=1, fuse_ngf=128)
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=2, ngf=16, enc_blocks=1, fuse_ngf=256)
     B = 3                                                   # uneven split: rank 0 gets 2 items, rank 1 gets 1
     inp = O.synth_inputs(cfg, B, 32, 32, seed=11, mask_mode="box")
     sd = None
     if rank == 0:                                           # only rank 0 has the checkpoint
         sd = O.synth_state_dict(cfg, seed=5)
         sd = {k: (v * 4 if k.endswith("weight") else v) for k, v in sd.items()}
-    eng = TSNetEngine(label_nc=2, n_blocks=0, n_source=2, ngf=8, enc_blocks=1, height=32, width=32, max_batch=2, lib=lib)
+    eng = TSNetEngine(label_nc=2, n_blocks=0, n_source=2, ngf=16, enc_blocks=1, height=32, width=32, max_batch=2, lib=lib)
     build_replica(eng, sd, "cpu", src=0)
     lo, hi = shard_range(B, rank, world)
     sl = slice(lo, hi)
@@ -53,7 +53,7 @@ def test_two_rank_replicas_match_oracle(emu_lib, tmp_path):
     from oracle import tsnet_oracle as O
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, build_emu_lib(), str(tmp_path)), nprocs=world, join=True)
-    cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=2, ngf=8, enc_blocks=1, fuse_ngf=128)
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=2, ngf=16, enc_blocks=1, fuse_ngf=256)
     sd = O.synth_state_dict(cfg, seed=5)
     sd = {k: (v * 4 if k.endswith("weight") else v) for k, v in sd.items()}
     inp = O.synth_inputs(cfg, 3, 32, 32, seed=11, mask_mode="box")

@@ -738,6 +738,18 @@ void tsnet_engine::alloc_all(hipStream_t s) {
         L->w2_off = off; off += (size_t)L->kpad * L->npad;
         L->b_off = off; off += (size_t)round_up(L->cout, 4);
     }
+    // the derived layouts live in the same allocation -- RGB-head table, bf16x3 planes -- so that the ONE broadcast
+    // of dist.build_replica carries everything a replica computes with
+    const bool want_head = cfg.ngf % kHeadCh == 0;
+    off = (off + 63) / 64 * 64;            // 256-byte aligned sections
+    const size_t head_off = off;
+    if (want_head) off += (size_t)49 * cfg.ngf * 4;
+    size_t o3 = 0;
+    std::vector<size_t> offs;
+    if (x3) for (ConvLayer* L : all_layers) { offs.push_back(o3); o3 += 3 * (size_t)L->kpad * L->npad; }
+    off = (off + 63) / 64 * 64;
+    const size_t x3_off = off;
+    off += (o3 + 1) / 2;                   // two bf16 per float slot
     wpack_floats = off;
     HIP_TRY(hipMalloc((void**)&wpack, wpack_floats * sizeof(float)));
     HIP_TRY(hipMemsetAsync(wpack, 0, wpack_floats * sizeof(float), s));
@@ -759,11 +771,8 @@ void tsnet_engine::alloc_all(hipStream_t s) {
         L->bias = L->bparam.empty() ? nullptr : wpack + L->b_off;
     }
     if (x3) {                              // bf16x3 planes of every layer's weights
-        size_t o3 = 0;
-        std::vector<size_t> offs;
-        for (ConvLayer* L : all_layers) { offs.push_back(o3); o3 += 3 * (size_t)L->kpad * L->npad; }
         wpack3_elems = o3;
-        HIP_TRY(hipMalloc((void**)&wpack3, o3 * sizeof(unsigned short)));
+        wpack3 = reinterpret_cast<unsigned short*>(wpack + x3_off);
         size_t li = 0;
         for (ConvLayer* L : all_layers) {
             const Param& pw = params[pindex[L->wparam]];
@@ -776,10 +785,10 @@ void tsnet_engine::alloc_all(hipStream_t s) {
             ++li;
         }
     }
-    if (cfg.ngf % kHeadCh == 0) {          // RGB head weights for the vector kernel (else the MFMA path is used)
+    if (want_head) {                       // RGB head weights for the vector kernel (else the MFMA path is used)
         const Param& pw = params[pindex[dec_head.wparam]];
         HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMalloc((void**)&head_w, (size_t)49 * cfg.ngf * 4 * sizeof(float)));
+        head_w = wpack + head_off;
         hipLaunchKernelGGL(pack_head_weights_kernel, dim3(64), dim3(256), 0, s, stage, head_w, cfg.ngf);
         check_launch("pack_head_weights");
         HIP_TRY(hipStreamSynchronize(s));
@@ -1227,8 +1236,8 @@ int tsnet_finalize(tsnet_handle h, void* stream) {
 
 void tsnet_destroy(tsnet_handle h) {
     if (!h) return;
-    (void)hipFree(h->wpack3); (void)hipFree(h->arena3);
-    (void)hipFree(h->head_w); (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
+    (void)hipFree(h->arena3);
+    (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
     delete h;
 }
 
