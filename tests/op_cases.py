@@ -149,6 +149,23 @@ def warp_case(lib, dev, B, h, w, C, seed=0):
     return (nchw(out.cpu()) - ref).abs().max().item()
 
 
+def conv_x3_tiles_bitwise(lib, dev, N, H, W, Cin, Cout, tiles, reflect=True, seed=0):
+    """Largest |difference| between the outputs of several tile configurations of one kernel family on the same
+    3x3 / stride-1 layer (0.0 = bit-identical: tile choice must not change the arithmetic)."""
+    x = F.relu(_rand(seed, "x", (N, Cin, H, W), -1.0, 2.0))
+    w = _rand(seed, "w", (Cout, Cin, 3, 3)) * (2.0 / (Cin * 9) ** 0.5)
+    b = _rand(seed, "b", (Cout,))
+    xd, wd, bd = nhwc(x).to(dev), w.to(dev), b.to(dev)
+    outs = []
+    for t in tiles:
+        y = torch.full((N, H, W, Cout), float("nan"), device=dev)
+        rc = lib.tsnet_op_conv2d_x3(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), bd.data_ptr(), Cout, 3, 1, 1, int(reflect), t, y.data_ptr(), None)
+        assert rc == 0, lib.tsnet_op_last_error().decode()
+        _sync(dev)
+        outs.append(y.cpu())
+    return max((o - outs[0]).abs().max().item() for o in outs[1:])
+
+
 def conv_x3_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, tile=-1, bias=True, seed=0):
     """nn.Conv2d (+padding) on the bf16x3 kernel (3-way bf16 operand split on the bf16 MFMA) vs PyTorch fp32."""
     x = F.relu(_rand(seed, "x", (N, Cin, H, W), -1.0, 2.0))

@@ -84,6 +84,12 @@ def test_conv_x3_patch_kernel(emu_lib):
     assert oc.conv_x3_case(emu_lib, "cpu", 2, 8, 32, 16, 128, 3, 1, 1, True, tile=11) < TOL
     assert oc.conv_x3_case(emu_lib, "cpu", 1, 4, 64, 64, 256, 3, 1, 1, False, tile=11) < TOL
     assert oc.conv_x3_case(emu_lib, "cpu", 1, 4, 32, 32, 128, 3, 1, 1, False, tile=11, bias=False) < TOL
+    # 128 x 64 tiles, and the mixed launch (whole 128 x 128 units + units cut into two 128 x 64 halves)
+    assert oc.conv_x3_case(emu_lib, "cpu", 1, 8, 32, 16, 64, 3, 1, 1, True, tile=12) < TOL
+    assert oc.conv_x3_case(emu_lib, "cpu", 1, 4, 32, 32, 192, 3, 1, 1, False, tile=12) < TOL
+    assert oc.conv_x3_case(emu_lib, "cpu", 3, 4, 32, 16, 256, 3, 1, 1, True, tile=13) < TOL
+    # same arithmetic per output element whatever the launch shape
+    assert oc.conv_x3_tiles_bitwise(emu_lib, "cpu", 3, 4, 32, 32, 256, (11, 12, 13)) == 0.0
 
 
 def test_conv_x3_1x1_and_ragged(emu_lib):

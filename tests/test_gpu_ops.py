@@ -98,6 +98,9 @@ def test_conv_x3_patch_kernel(lib):
     assert oc.conv_x3_case(lib, DEV, 4, 32, 32, 1024, 256, 3, 1, 1, False, tile=11) < 1e-4
     assert oc.conv_x3_case(lib, DEV, 2, 128, 128, 256, 128, 3, 1, 1, False, tile=11) < TOL
     assert oc.conv_x3_case(lib, DEV, 1, 4, 256, 16, 128, 3, 1, 1, True, tile=11, bias=False) < TOL
+    assert oc.conv_x3_case(lib, DEV, 2, 64, 64, 128, 64, 3, 1, 1, False, tile=12) < TOL
+    assert oc.conv_x3_case(lib, DEV, 12, 32, 32, 512, 512, 3, 1, 1, True, tile=13) < TOL       # mixed 128/64 launch
+    assert oc.conv_x3_tiles_bitwise(lib, DEV, 12, 32, 32, 256, 512, (11, 12, 13)) == 0.0
 
 
 def test_conv_x3_big_layers(lib):

@@ -6,6 +6,8 @@ rows = cur.execute("select name, start, end, duration, grid_x, workgroup_x, lds_
 def short(n):
     m = re.search(r"conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", n)
     if m: return "conv<k%s,%sx%s>" % (m.group(1), m.group(2), m.group(3))
+    m = re.search(r"(conv_x3p?|conv_dma)_kernel<([^>]*)>", n)
+    if m: return "%s<%s>" % (m.group(1), m.group(2).replace(" ", "").replace("false", "f").replace("true", "t"))
     n = re.sub(r"\(.*", "", n); return n.split("::")[-1][:40]
 agg = {}
 for r in rows:
@@ -21,5 +23,5 @@ if len(idx) >= 2:
     fw = rows[start:]
     print("\nlast forward: %d dispatches, span %.3f ms, busy %.3f ms" % (len(fw), (fw[-1][2] - fw[0][1]) / 1e6, sum(r[3] for r in fw) / 1e6))
     for r in fw:
-        if "conv_igemm" in r[0]:
-            print("  %-18s grid=%6d wg=%d lds=%d vgpr=%d agpr=%d  %9.1f us" % (short(r[0]), r[4] // r[5], r[5], r[6], r[7], r[8], r[3] / 1e3))
+        if "conv_" in r[0] and "pack" not in r[0]:
+            print("  %-34s grid=%6d wg=%d lds=%d vgpr=%d agpr=%d  %9.1f us" % (short(r[0]), r[4] // r[5], r[5], r[6], r[7], r[8], r[3] / 1e3))

@@ -23,9 +23,9 @@ namespace tsnet {
 
 constexpr int kPatchRows = 4, kPatchCols = 32;            // output rectangle of one tile (BM = 128 positions)
 
-template <int BN, int WARPS_M, int WARPS_N>
-__global__ __launch_bounds__(256)
-void conv_x3p_kernel(X3Args a) {
+// one output tile: rows tile_m*128 .. +127 (a 4 x 32 rectangle), columns n0 .. n0+BN-1
+template <int BN, int WARPS_M, int WARPS_N, bool FOLD>
+__device__ __forceinline__ void x3p_tile(const X3Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
     constexpr int BM = kPatchRows * kPatchCols;
     constexpr int NW = WARPS_M * WARPS_N;
     static_assert(NW == 4, "four waves: patch blocks are dealt w, w+4");
@@ -40,22 +40,12 @@ void conv_x3p_kernel(X3Args a) {
     constexpr int PLANE_B = BN * 32, BSTAGE = 3 * PLANE_B;
     constexpr int OFF_B = 2 * PATCH_BYTES, OFF_SCRATCH = OFF_B + 3 * BSTAGE;
 
-    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = TSNET_UNIFORM(tid >> 6);
     const int wrow = wave / WARPS_N;
     const int wn0 = (wave % WARPS_N) * WN;
     const int li = lane & 31, lh = lane >> 5;
-
-    const int ntiles = a.tiles_m * a.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
-    const int n0 = tile_n * BN;
     // tile_m -> (image, row block, column block); stride 1 / pad 1: input and output grids coincide
     const int tcols = a.Wo / kPatchCols, tper = (a.Ho / kPatchRows) * tcols;
     const int img = tile_m / tper, tin = tile_m - img * tper;
@@ -117,7 +107,7 @@ void conv_x3p_kernel(X3Args a) {
         const unsigned so = (unsigned)((kc * a.Npad + n0 + wave * 32) * 32);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            if (wave < TB) {
+            if (TB == NW || wave < TB) {
                 TSNET_BUF_DMA16(rsw[p], vB, so, lds0 + OFF_B + stage * BSTAGE + p * PLANE_B + wave * 1024);
             } else {
                 const unsigned oob = kOOB;
@@ -173,7 +163,7 @@ void conv_x3p_kernel(X3Args a) {
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
                     acc[i][j] = TSNET_MFMA_BF16(af[PA[q]][i], bf[PB[q]][j], acc[i][j]);
-        if (((cc + t + 1) & 3) == 0) {                       // step index 9*cc + t == cc + t (mod 4); wave-uniform
+        if (FOLD && ((cc + t + 1) & 3) == 0) {                       // step index 9*cc + t == cc + t (mod 4); wave-uniform
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -204,6 +194,42 @@ void conv_x3p_kernel(X3Args a) {
     const int m_img = img * a.Ho * a.Wo;
     x3_epilogue<BN, WARPS_M, WARPS_N, MT, NTL>(a, tot, smem_raw, tid, wave, n0, (size_t)img * tper + tin,
                                                [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
+}
+
+// XCD-aware block -> work item: consecutive items stay on one XCD (its L2 then holds their shared operands)
+__device__ __forceinline__ int x3p_item(int bid, int nitems) {
+    const int q = nitems >> 3, r = nitems & 7, xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <int BN, int WARPS_M, int WARPS_N, bool FOLD = true>
+__global__ __launch_bounds__(256)
+void conv_x3p_kernel(X3Args a) {
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
+    const int tile_m = bid / a.tiles_n;
+    x3p_tile<BN, WARPS_M, WARPS_N, FOLD>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+}
+
+// Mixed launch for layers whose 128 x 128 unit count is a half-integer multiple of the CU count (the 384-tile
+// residual convolutions at batch 4: half the CUs would run two tiles, half one -- 75 % of the machine).  The last
+// `a.tiles_n`-major `nsplit` units are cut into two 128 x 64 halves; blocks [0, nbig) run whole units, the rest
+// halves, so with two resident blocks per CU every CU gets one whole and one half unit.  Per output element the
+// K order and fold points are those of the plain kernel: results are bit-identical.
+__global__ __launch_bounds__(256)
+void conv_x3p_mixed_kernel(X3Args a, int nbig) {
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    if ((int)blockIdx.x < nbig) {
+        const int u = x3p_item(blockIdx.x, nbig);
+        const int tile_m = u / a.tiles_n;
+        x3p_tile<128, 2, 2, true>(a, smem_raw, tile_m, (u - tile_m * a.tiles_n) * 128);
+    } else {
+        const int nsmall = (int)gridDim.x - nbig;
+        const int h = x3p_item((int)blockIdx.x - nbig, nsmall);
+        const int u = nbig + (h >> 1);
+        const int tile_m = u / a.tiles_n;
+        x3p_tile<64, 2, 2, true>(a, smem_raw, tile_m, (u - tile_m * a.tiles_n) * 128 + (h & 1) * 64);
+    }
 }
 
 }  // namespace tsnet

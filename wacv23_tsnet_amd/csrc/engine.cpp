@@ -247,8 +247,9 @@ const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, 1.0}, {128, 128, 2, 2, 1, 4, 
                             {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, 0.55}, {64, 64, 2, 2, 1, 4, 0.52},
                             {64, 128, 2, 2, 1, 4, 0.62}, {96, 128, 1, 4, 1, 3, 0.81}, {128, 32, 4, 1, 1, 4, 0.3},
                             {128, 128, 4, 2, 1, 3, 0.0}, {128, 128, 2, 4, 1, 3, 0.0},
-                            {128, 128, 2, 2, 1, 3, 1.2, true}};   // conv_x3p.hpp: LDS-resident input patch (3x3, stride 1)
-constexpr int kNumXTiles = 12;
+                            {128, 128, 2, 2, 1, 3, 1.2, true}, {128, 64, 2, 2, 1, 3, 0.85, true},   // conv_x3p.hpp: LDS-resident input patch
+                            {128, 128, 2, 2, 1, 3, 0.0, true}};                                    // 13: mixed 128/64 launch (chosen by rule)
+constexpr int kNumXTiles = 14;
 
 template <int KS, int BM, int BN, int WM_, int WN_, int KC, int NST>
 void launch_x3_t(const X3Args& a, hipStream_t s) {
@@ -274,6 +275,14 @@ void launch_x3p(const X3Args& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
+// a.tiles_n counts 128-wide units; the last `nsplit` units run as two 128 x 64 halves (conv_x3p_mixed_kernel)
+void launch_x3p_mixed(const X3Args& a, int nsplit, hipStream_t s) {
+    const size_t lds = 2 * 3 * 7 * 1024 + 3 * 3 * (size_t)128 * 32 + 1024;
+    const int units = a.tiles_m * a.tiles_n, nbig = units - nsplit;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3p_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(conv_x3p_mixed_kernel, dim3(nbig + 2 * nsplit), dim3(256), lds, s, a, nbig);
+}
+
 template <int ABL>
 void launch_x3_abl(X3Args a, hipStream_t s) {     // diagnostic: 3x3, tile 0 (128x128, 4 waves, ring of 3)
     a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.Cout + 127) / 128;
@@ -291,7 +300,7 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         double best_cost = 0;
         // the patch kernel sums K slab-major, the others tap-major: which of the two a layer runs on must depend on
         // the layer alone, never on the batch (results are identical for any batch size and any tile of one family)
-        const bool patch_family = !e_tile && x3p_ok<KS>(a) && a.Npad % 128 == 0;
+        const bool patch_family = !e_tile && x3p_ok<KS>(a) && a.Npad % 64 == 0;
         for (int i = 0; i < kNumXTiles; ++i) {
             if (!e_tile && kXTiles[i].patch != patch_family) continue;
             if (a.Npad % kXTiles[i].bn) continue;
@@ -306,6 +315,16 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
     }
     if (best < 0 || best >= kNumXTiles || a.Npad % kXTiles[best].bn || (kXTiles[best].patch && !x3p_ok<KS>(a)))
         throw ArgError("conv(x3): no tile configuration");
+    // balance rule (depends on the launch only, not on the arithmetic): with two resident 128x128 blocks per CU a unit
+    // count of (k + 1/2) x 256 leaves half the CUs one unit short -- run the last 128 units as 256 half tiles
+    int mixed_split = 0;
+    if (best == 11 && forced_tile < 0 && !getenv("TSNET_X3_TILE") && !getenv("TSNET_X3_NOMIX")) {
+        const long units = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+        if (units % 256 == 128 && a.Cout % 128 == 0) { best = 13; mixed_split = 128; }
+    }
+    if (best == 13 && !mixed_split) {      // forced from the sweep tool: split a third of the units
+        mixed_split = (int)(((a.M + 127) / 128) * ((a.Cout + 127) / 128) / 3);
+    }
     a.tiles_m = (a.M + kXTiles[best].bm - 1) / kXTiles[best].bm;
     a.tiles_n = (a.Cout + kXTiles[best].bn - 1) / kXTiles[best].bn;
     const int hw = a.Ho * a.Wo;
@@ -321,6 +340,8 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         case 7: launch_x3_t<KS, 96, 128, 1, 4, 1, 3>(a, s); break;
         case 8: launch_x3_t<KS, 128, 32, 4, 1, 1, 4>(a, s); break;
         case 11: launch_x3p<128, 2, 2>(a, s); break;
+        case 12: launch_x3p<64, 2, 2>(a, s); break;
+        case 13: launch_x3p_mixed(a, mixed_split, s); break;
         case 9: launch_x3_t<KS, 128, 128, 4, 2, 1, 3>(a, s); break;
         default: launch_x3_t<KS, 128, 128, 2, 4, 1, 3>(a, s); break;
     }
