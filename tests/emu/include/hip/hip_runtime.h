@@ -76,6 +76,16 @@ static inline tsnet_rsrc_t tsnet_make_rsrc(const void* p, unsigned bytes) { tsne
 #define TSNET_LDS_BASE(p) ((unsigned char*)(p))
 #define TSNET_BUF_DMA16(rsrc, voff, soff, lds) emu::buf_dma16((rsrc).base, (rsrc).bytes, (voff), (soff), (lds))
 #define TSNET_UNIFORM(x) (x)
+// hook of conv_x3p.hpp (x3q): buffer_load_dwordx4 into registers, same descriptor and out-of-range rule as the DMA
+typedef tsnet_rsrc_t tsnet_brsrc_t;
+#define tsnet_make_brsrc tsnet_make_rsrc
+template <class T> static inline T emu_buf_load16(const tsnet_rsrc_t& r, unsigned voff, unsigned soff) {
+    T v; static_assert(sizeof(T) == 16, "16-byte load");
+    const bool oob = soff > r.bytes || (unsigned long long)voff + 16 > (unsigned long long)(r.bytes - soff);
+    if (oob) memset(&v, 0, 16); else memcpy(&v, r.base + (size_t)voff + soff, 16);
+    return v;
+}
+#define TSNET_BUF_LOAD16(rsrc, voff, soff) emu_buf_load16<F4>((rsrc), (voff), (soff))
 // hook of conv_x3.hpp: v_mfma_f32_32x32x16_bf16 on raw 16-byte operands (8 bf16 per lane)
 #define TSNET_MFMA_BF16(a, b, c) emu::mfma_bf16_32x32x16(&(a), &(b), (c))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)

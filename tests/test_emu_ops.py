@@ -88,6 +88,11 @@ def test_conv_x3_patch_kernel(emu_lib):
     assert oc.conv_x3_case(emu_lib, "cpu", 1, 8, 32, 16, 64, 3, 1, 1, True, tile=12) < TOL
     assert oc.conv_x3_case(emu_lib, "cpu", 1, 4, 32, 32, 192, 3, 1, 1, False, tile=12) < TOL
     assert oc.conv_x3_case(emu_lib, "cpu", 3, 4, 32, 16, 256, 3, 1, 1, True, tile=13) < TOL
+    # x3q (weights fetched into registers, patch staged through registers): tiles 14 (128 x 128), 15 (128 x 64)
+    assert oc.conv_x3_case(emu_lib, "cpu", 2, 8, 32, 16, 128, 3, 1, 1, True, tile=14) < TOL
+    assert oc.conv_x3_case(emu_lib, "cpu", 1, 4, 64, 64, 256, 3, 1, 1, False, tile=14) < TOL
+    assert oc.conv_x3_case(emu_lib, "cpu", 1, 8, 32, 32, 64, 3, 1, 1, True, tile=15, bias=False) < TOL
+    assert oc.conv_x3_tiles_bitwise(emu_lib, "cpu", 3, 4, 32, 32, 256, (14, 15)) == 0.0
     # same arithmetic per output element whatever the launch shape
     assert oc.conv_x3_tiles_bitwise(emu_lib, "cpu", 3, 4, 32, 32, 256, (11, 12, 13)) == 0.0
 

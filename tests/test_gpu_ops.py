@@ -101,6 +101,13 @@ def test_conv_x3_patch_kernel(lib):
     assert oc.conv_x3_case(lib, DEV, 2, 64, 64, 128, 64, 3, 1, 1, False, tile=12) < TOL
     assert oc.conv_x3_case(lib, DEV, 12, 32, 32, 512, 512, 3, 1, 1, True, tile=13) < TOL       # mixed 128/64 launch
     assert oc.conv_x3_tiles_bitwise(lib, DEV, 12, 32, 32, 256, 512, (11, 12, 13)) == 0.0
+    # x3q: weights in registers (the default family for 3x3 / stride-1 layers)
+    assert oc.conv_x3_case(lib, DEV, 12, 32, 32, 512, 512, 3, 1, 1, True, tile=14) < TOL
+    assert oc.conv_x3_case(lib, DEV, 12, 32, 32, 512, 512, 3, 1, 1, True, tile=15) < TOL
+    assert oc.conv_x3_case(lib, DEV, 4, 32, 32, 1024, 256, 3, 1, 1, False, tile=14) < 1e-4
+    assert oc.conv_x3_case(lib, DEV, 2, 128, 128, 256, 128, 3, 1, 1, False, tile=14) < TOL
+    assert oc.conv_x3_case(lib, DEV, 2, 64, 64, 128, 64, 3, 1, 1, False, tile=15) < TOL
+    assert oc.conv_x3_tiles_bitwise(lib, DEV, 12, 32, 32, 256, 512, (14, 15)) == 0.0
 
 
 def test_conv_x3_big_layers(lib):

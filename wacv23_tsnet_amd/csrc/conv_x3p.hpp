@@ -24,7 +24,9 @@ namespace tsnet {
 constexpr int kPatchRows = 4, kPatchCols = 32;            // output rectangle of one tile (BM = 128 positions)
 
 // one output tile: rows tile_m*128 .. +127 (a 4 x 32 rectangle), columns n0 .. n0+BN-1
-template <int BN, int WARPS_M, int WARPS_N, bool FOLD>
+// ABL (tools/x3_ablate.py only; non-zero computes garbage): bit0 no DMA in the loop, bit1 no vmcnt/barrier, bit2 no
+// fold, bit3 fragments read from LDS once instead of every step
+template <int BN, int WARPS_M, int WARPS_N, bool FOLD, int ABL = 0>
 __device__ __forceinline__ void x3p_tile(const X3Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
     constexpr int BM = kPatchRows * kPatchCols;
     constexpr int NW = WARPS_M * WARPS_N;
@@ -131,17 +133,19 @@ __device__ __forceinline__ void x3p_tile(const X3Args& a, unsigned char* smem_ra
     // outstanding allowance = patch op of step s-2 + everything of step s-1.
     auto step = [&](int cc, int t) __attribute__((always_inline)) {
         const int n_after = 3 + (((t + 7) % 9) < 6 ? 1 : 0) + (((t + 8) % 9) < 6 ? 1 : 0);
-        if (n_after == 3) TSNET_VMCNT(3); else if (n_after == 4) TSNET_VMCNT(4); else TSNET_VMCNT(5);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if (!(ABL & 2)) {
+            if (n_after == 3) TSNET_VMCNT(3); else if (n_after == 4) TSNET_VMCNT(4); else TSNET_VMCNT(5);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         const int ky = t / 3, kx = t - ky * 3;
-        const unsigned char* pbase = smem_raw + (cc & 1) * PATCH_BYTES;
-        const unsigned char* bbase = smem_raw + OFF_B + (t % 3) * BSTAGE;
+        const unsigned char* pbase = smem_raw + ((ABL & 8) ? 0 : (cc & 1)) * PATCH_BYTES;
+        const unsigned char* bbase = smem_raw + OFF_B + ((ABL & 8) ? 0 : (t % 3)) * BSTAGE;
         F4 af[3][MT], bf[3][NTL];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int slot = p0 + (i + ky) * PC + kx;
+            const int slot = (ABL & 8) ? p0 + i * PC : p0 + (i + ky) * PC + kx;
             const int off = ((slot << 1) | (lh ^ ((slot >> 3) & 1))) << 4;
 #pragma unroll
             for (int p = 0; p < 3; ++p) af[p][i] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + off);
@@ -150,7 +154,7 @@ __device__ __forceinline__ void x3p_tile(const X3Args& a, unsigned char* smem_ra
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) bf[p][j] = *reinterpret_cast<const F4*>(bbase + p * PLANE_B + j * 1024 + b_off);
-        {
+        if (!(ABL & 1)) {
             const int t2 = (t + 2) % 9;
             issue_b(cc + (t + 2 >= 9 ? 1 : 0), t2, t2 % 3);
             if (t < 6) issue_patch(cc + 1, t);
@@ -163,7 +167,7 @@ __device__ __forceinline__ void x3p_tile(const X3Args& a, unsigned char* smem_ra
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
                     acc[i][j] = TSNET_MFMA_BF16(af[PA[q]][i], bf[PB[q]][j], acc[i][j]);
-        if (FOLD && ((cc + t + 1) & 3) == 0) {                       // step index 9*cc + t == cc + t (mod 4); wave-uniform
+        if (FOLD && !(ABL & 4) && ((cc + t + 1) & 3) == 0) {                       // step index 9*cc + t == cc + t (mod 4); wave-uniform
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -196,19 +200,213 @@ __device__ __forceinline__ void x3p_tile(const X3Args& a, unsigned char* smem_ra
                                                [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// x3q: the same patch convolution with the WEIGHT fragments fetched straight into registers.
+//
+// Why (tools/x3_ablate.py patch, profiles/round1_notes.md): x3p_tile moves 14.6 KB of LDS-DMA per 0.52 MFLOP; at its
+// 232 TF that is 6.5 TB/s, the chip's measured LDS-DMA fill ceiling (6.4-6.8 TB/s), and 82 % of it is the weight
+// tile.  A weight fragment is already in the layout the MFMA wants (pack_weights_x3_kernel), it is read by exactly
+// the waves that multiply with it, and a wave's six 1 KiB fragments per step are contiguous in memory: a plain
+// buffer_load_dwordx4 through the vector L1 (64 B/clk/CU, 4x the DMA rate) delivers them with no LDS round trip.
+// That removes the B ring (36 KiB), its 12 ds_reads per step (half of the LDS read traffic), the per-step barrier
+// (the patch is the only shared data: one barrier per 16-channel slab) and every inline-asm load: the patch is
+// staged through registers (buffer load -> ds_write) so that hipcc counts every vmcnt itself.
+//
+// Register reuse instead of double buffering: the six products of a step are ordered so that each operand plane
+// retires early -- (lo,hi) (mid,hi) (hi,hi) (mid,mid) (hi,mid) (hi,lo): weights-hi is free after 3 products,
+// weights-mid after 5 -- and the fragment of the NEXT step is loaded into the same registers right after the
+// last use; every load has >= 12 MFMAs (>= 384 matrix-pipe cycles, twice that with two waves per SIMD) to land.
+// Fold points are static (after taps 3 and 8 of every slab: chains of 64 and 80 products); the first product of
+// a chain takes C = 0, so a fold costs 32 v_pk_add and no zeroing.
+#ifndef TSNET_BUF_LOAD16
+typedef __amdgpu_buffer_rsrc_t tsnet_brsrc_t;
+__device__ __forceinline__ tsnet_brsrc_t tsnet_make_brsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+#define TSNET_BUF_LOAD16(rsrc, voff, soff) __builtin_bit_cast(F4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (int)(voff), (int)(soff), 0))
+#endif
+
+template <int BN, int WARPS_M, int WARPS_N>
+__device__ __forceinline__ void x3q_tile(const X3Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
+    constexpr int BM = kPatchRows * kPatchCols;
+    constexpr int NW = WARPS_M * WARPS_N;
+    static_assert(NW == 4, "four waves: patch blocks are dealt w, w+4");
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 32, NTL = WN / 32;
+    constexpr int PC = kPatchCols + 2, PP = (kPatchRows + 2) * PC;
+    constexpr int PBLK = (PP + 31) / 32;
+    constexpr int PLANE_P = PBLK * 1024, PATCH_BYTES = 3 * PLANE_P;
+    constexpr int OFF_SCRATCH = 2 * PATCH_BYTES;                     // 1 KiB sink for the wave whose second block does not exist
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = TSNET_UNIFORM(tid >> 6);
+    const int wrow = wave / WARPS_N;
+    const int wn0 = (wave % WARPS_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tcols = a.Wo / kPatchCols, tper = (a.Ho / kPatchRows) * tcols;
+    const int img = tile_m / tper, tin = tile_m - img * tper;
+    const int oy0 = (tin / tcols) * kPatchRows, ox0 = (tin % tcols) * kPatchCols;
+    const int ncc = a.Cin >> 4;
+
+    const int C2 = a.Cin - a.Csplit;
+    const size_t plane1 = (size_t)a.N * a.H * a.W * a.Csplit, plane2 = (size_t)a.x2_nmod * a.H * a.W * C2;
+    const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
+    tsnet_brsrc_t rs1[3], rs2[3], rsw[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        rs1[p] = tsnet_make_brsrc(a.x + p * plane1, (unsigned)(plane1 * 2));
+        rs2[p] = tsnet_make_brsrc(a.x2 ? a.x2 + p * plane2 : a.x, a.x2 ? (unsigned)(plane2 * 2) : 0u);
+        rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
+    }
+
+    // patch staging geometry (same LDS image as x3p_tile): this wave owns pixel blocks wave and wave + 4
+    unsigned vP1[2], vP2[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int pp = (wave + 4 * r) * 32 + (lane >> 1);
+        const int oct_log = (lane & 1) ^ ((pp >> 3) & 1);
+        const int pr = pp / PC, pc = pp - pr * PC;
+        int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
+        bool ok = pp < PP;
+        if (a.reflect) {
+            iy = iy < 0 ? -iy : iy;
+            iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+            ix = ix < 0 ? -ix : ix;
+            ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+        } else {
+            ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        }
+        const int pix = iy * a.W + ix;
+        vP1[r] = ok ? (unsigned)(((img * a.H * a.W + pix) * a.Csplit + oct_log * 8) * 2) : kOOB;
+        vP2[r] = ok ? (unsigned)((((img % a.x2_nmod) * a.H * a.W + pix) * C2 + oct_log * 8) * 2) : kOOB;
+    }
+    // entry q = 0..5 of slab cn: plane q%3 of block wave + 4*(q/3); branch-free source select
+    auto patch_load = [&](int cn, int q) __attribute__((always_inline)) {
+        const int p = q % 3, r = q / 3;
+        const int c0 = cn << 4;
+        const bool second = c0 >= a.Csplit;                          // wave-uniform
+        const unsigned so = (unsigned)((second ? c0 - a.Csplit : c0) * 2);
+        const tsnet_brsrc_t rs = second ? rs2[p] : rs1[p];
+        return TSNET_BUF_LOAD16(rs, second ? vP2[r] : vP1[r], so);
+    };
+    auto patch_store = [&](int cn, int q, const F4& v) __attribute__((always_inline)) {
+        const int p = q % 3, r = q / 3;
+        const int b = wave + 4 * r;
+        unsigned char* dst = smem_raw + (b < PBLK ? (cn & 1) * PATCH_BYTES + p * PLANE_P + b * 1024 : OFF_SCRATCH) + lane * 16;
+        *reinterpret_cast<F4*>(dst) = v;
+    };
+
+    // weight fragments: lane (li, lh) takes the 16 bytes of column wn0 + j*32 + li, logical octet lh
+    const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
+    F4 af[3][MT], bf[3][NTL];
+    auto load_b = [&](int p, int cc, int t) __attribute__((always_inline)) {
+        const int kc = t * ncc + cc;
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) bf[p][j] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0 + j * 32) * 32));
+    };
+    const int p0 = wrow * MT * PC + li;
+    auto load_a = [&](int p, int cc, int t) __attribute__((always_inline)) {
+        const int ky = t / 3, kx = t - ky * 3;
+        const unsigned char* pbase = smem_raw + (cc & 1) * PATCH_BYTES + p * PLANE_P;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int slot = p0 + (i + ky) * PC + kx;
+            af[p][i] = *reinterpret_cast<const F4*>(pbase + (((slot << 1) | (lh ^ ((slot >> 3) & 1))) << 4));
+        }
+    };
+
+    f32x16 acc[MT][NTL], tot[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+    // one product of planes (pa, pb) over the wave tile; `fresh` starts a new chain from C = 0
+    auto product = [&](int pa, int pb, bool fresh) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                f32x16 c = acc[i][j];
+                if (fresh) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                }
+                acc[i][j] = TSNET_MFMA_BF16(af[pa][i], bf[pb][j], c);
+            }
+    };
+    auto step = [&](int cc, int t) __attribute__((always_inline)) {
+        const bool fresh = t == 0 || t == 4;                 // chains: taps 0..3 and 4..8 of the slab
+        const bool last = t == 8;
+        const int nc = last ? cc + 1 : cc, nt = last ? 0 : t + 1;
+        F4 stage;
+        if (t < 6) stage = patch_load(cc + 1, t);
+        product(2, 0, fresh);                                // lo  * hi
+        if (!last) load_a(2, nc, nt);
+        product(1, 0, false);                                // mid * hi
+        product(0, 0, false);                                // hi  * hi
+        load_b(0, nc, nt);
+        product(1, 1, false);                                // mid * mid
+        if (!last) load_a(1, nc, nt);
+        product(0, 1, false);                                // hi  * mid
+        load_b(1, nc, nt);
+        product(0, 2, false);                                // hi  * lo
+        if (!last) load_a(0, nc, nt);
+        load_b(2, nc, nt);
+        if (t < 6) patch_store(cc + 1, t, stage);
+        if (t == 3 || t == 8) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];
+        }
+    };
+
+    // prologue: patch of slab 0, then the fragments of step (0, 0)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) patch_store(0, q, patch_load(0, q));
+#pragma unroll
+    for (int p = 0; p < 3; ++p) load_b(p, 0, 0);
+    for (int cc = 0; cc < ncc; ++cc) {
+        __syncthreads();                                     // patch(cc) complete and visible; slab cc-1 fully read
+#pragma unroll
+        for (int p = 0; p < 3; ++p) load_a(p, cc, 0);
+        step(cc, 0); step(cc, 1); step(cc, 2);
+        step(cc, 3); step(cc, 4); step(cc, 5);
+        step(cc, 6); step(cc, 7); step(cc, 8);
+    }
+
+    const int m_img = img * a.Ho * a.Wo;
+    x3_epilogue<BN, WARPS_M, WARPS_N, MT, NTL>(a, tot, smem_raw, tid, wave, n0, (size_t)img * tper + tin,
+                                               [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
+}
+
 // XCD-aware block -> work item: consecutive items stay on one XCD (its L2 then holds their shared operands)
 __device__ __forceinline__ int x3p_item(int bid, int nitems) {
     const int q = nitems >> 3, r = nitems & 7, xcd = bid & 7, loc = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <int BN, int WARPS_M, int WARPS_N, bool FOLD = true>
+template <int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(256)
+void conv_x3q_kernel(X3Args a) {
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
+    const int tile_m = bid / a.tiles_n;
+    x3q_tile<BN, WARPS_M, WARPS_N>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+}
+
+template <int BN, int WARPS_M, int WARPS_N, bool FOLD = true, int ABL = 0>
 __global__ __launch_bounds__(256)
 void conv_x3p_kernel(X3Args a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
     const int tile_m = bid / a.tiles_n;
-    x3p_tile<BN, WARPS_M, WARPS_N, FOLD>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+    x3p_tile<BN, WARPS_M, WARPS_N, FOLD, ABL>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
 }
 
 // Mixed launch for layers whose 128 x 128 unit count is a half-integer multiple of the CU count (the 384-tile

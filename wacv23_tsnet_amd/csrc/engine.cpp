@@ -247,9 +247,11 @@ const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, 1.0}, {128, 128, 2, 2, 1, 4, 
                             {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, 0.55}, {64, 64, 2, 2, 1, 4, 0.52},
                             {64, 128, 2, 2, 1, 4, 0.62}, {96, 128, 1, 4, 1, 3, 0.81}, {128, 32, 4, 1, 1, 4, 0.3},
                             {128, 128, 4, 2, 1, 3, 0.0}, {128, 128, 2, 4, 1, 3, 0.0},
-                            {128, 128, 2, 2, 1, 3, 1.2, true}, {128, 64, 2, 2, 1, 3, 0.85, true},   // conv_x3p.hpp: LDS-resident input patch
-                            {128, 128, 2, 2, 1, 3, 0.0, true}};                                    // 13: mixed 128/64 launch (chosen by rule)
-constexpr int kNumXTiles = 14;
+                            // conv_x3p.hpp, LDS-resident input patch.  11-13: x3p (weights through an LDS-DMA ring; 13 = mixed
+                            // 128/64 launch), kept for the sweep / ablation tools.  14, 15: x3q (weights in registers), the default
+                            {128, 128, 2, 2, 1, 3, 0.0, true}, {128, 64, 2, 2, 1, 3, 0.0, true}, {128, 128, 2, 2, 1, 3, 0.0, true},
+                            {128, 128, 2, 2, 1, 3, 1.4, true}, {128, 64, 2, 2, 1, 3, 1.25, true}};
+constexpr int kNumXTiles = 16;
 
 template <int KS, int BM, int BN, int WM_, int WN_, int KC, int NST>
 void launch_x3_t(const X3Args& a, hipStream_t s) {
@@ -275,12 +277,27 @@ void launch_x3p(const X3Args& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
+template <int BN, int WM_, int WN_>
+void launch_x3q(const X3Args& a, hipStream_t s) {
+    const size_t lds = 2 * 3 * 7 * 1024 + 1024;
+    hipLaunchKernelGGL((conv_x3q_kernel<BN, WM_, WN_>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+}
+
 // a.tiles_n counts 128-wide units; the last `nsplit` units run as two 128 x 64 halves (conv_x3p_mixed_kernel)
 void launch_x3p_mixed(const X3Args& a, int nsplit, hipStream_t s) {
     const size_t lds = 2 * 3 * 7 * 1024 + 3 * 3 * (size_t)128 * 32 + 1024;
     const int units = a.tiles_m * a.tiles_n, nbig = units - nsplit;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3p_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(conv_x3p_mixed_kernel, dim3(nbig + 2 * nsplit), dim3(256), lds, s, a, nbig);
+}
+
+template <int ABL>
+void launch_x3p_abl(X3Args a, hipStream_t s) {    // diagnostic: patch kernel, 128x128 tiles
+    a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.Cout + 127) / 128;
+    const size_t lds = 2 * 3 * 7 * 1024 + 3 * 3 * (size_t)128 * 32 + 1024;
+    auto kern = conv_x3p_kernel<128, 2, 2, true, ABL>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
 template <int ABL>
@@ -315,16 +332,8 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
     }
     if (best < 0 || best >= kNumXTiles || a.Npad % kXTiles[best].bn || (kXTiles[best].patch && !x3p_ok<KS>(a)))
         throw ArgError("conv(x3): no tile configuration");
-    // balance rule (depends on the launch only, not on the arithmetic): with two resident 128x128 blocks per CU a unit
-    // count of (k + 1/2) x 256 leaves half the CUs one unit short -- run the last 128 units as 256 half tiles
-    int mixed_split = 0;
-    if (best == 11 && forced_tile < 0 && !getenv("TSNET_X3_TILE") && !getenv("TSNET_X3_NOMIX")) {
-        const long units = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-        if (units % 256 == 128 && a.Cout % 128 == 0) { best = 13; mixed_split = 128; }
-    }
-    if (best == 13 && !mixed_split) {      // forced from the sweep tool: split a third of the units
-        mixed_split = (int)(((a.M + 127) / 128) * ((a.Cout + 127) / 128) / 3);
-    }
+    // tile 13 (sweep tool only): x3p launch with the last third of the 128-wide units cut into two 128 x 64 halves
+    const int mixed_split = best == 13 ? (int)(((a.M + 127) / 128) * ((a.Cout + 127) / 128) / 3) : 0;
     a.tiles_m = (a.M + kXTiles[best].bm - 1) / kXTiles[best].bm;
     a.tiles_n = (a.Cout + kXTiles[best].bn - 1) / kXTiles[best].bn;
     const int hw = a.Ho * a.Wo;
@@ -342,6 +351,8 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         case 11: launch_x3p<128, 2, 2>(a, s); break;
         case 12: launch_x3p<64, 2, 2>(a, s); break;
         case 13: launch_x3p_mixed(a, mixed_split, s); break;
+        case 14: launch_x3q<128, 2, 2>(a, s); break;
+        case 15: launch_x3q<64, 2, 2>(a, s); break;
         case 9: launch_x3_t<KS, 128, 128, 4, 2, 1, 3>(a, s); break;
         default: launch_x3_t<KS, 128, 128, 2, 4, 1, 3>(a, s); break;
     }
@@ -375,8 +386,22 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
     if ((double)c.N * c.H * c.W * L.cin_pad * 2 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
         throw ArgError("conv(x3): tensor too large for 32-bit buffer offsets");
     TimeScope ts(ctx, TSNET_T_CONV);
-    const int forced = c.variant >= 0 ? (c.variant & 15) : -1;
+    const int forced = c.variant >= 0 ? (c.variant & 63) : -1;
     const int abl = c.variant >= 0 ? (c.variant >> 16) & 127 : 0;
+    if (abl && L.ks == 3 && forced == 11) {
+        if (!x3p_ok<3>(g)) throw ArgError("ablation: layer not eligible for the patch kernel");
+        switch (abl) {
+            case 1: launch_x3p_abl<1>(g, ctx.stream); break;
+            case 2: launch_x3p_abl<2>(g, ctx.stream); break;
+            case 3: launch_x3p_abl<3>(g, ctx.stream); break;
+            case 4: launch_x3p_abl<4>(g, ctx.stream); break;
+            case 8: launch_x3p_abl<8>(g, ctx.stream); break;
+            case 12: launch_x3p_abl<12>(g, ctx.stream); break;
+            case 15: launch_x3p_abl<15>(g, ctx.stream); break;
+            default: throw ArgError("unsupported ablation mask");
+        }
+        return;
+    }
     if (abl && L.ks == 3) {
         switch (abl) {
             case 16: launch_x3_abl<16>(g, ctx.stream); break;
