@@ -104,7 +104,9 @@ int tsnet_forward_target(tsnet_handle h, const float* tar_lbl, const float* tar_
 
 /* Device copies of the stage tensors of the last forward, for stage-wise parity tests
  * (NHWC fp32).  name: "src_fea" (K*B,h,w,c; n = i*B+b), "tar_fea" (B,h,w,c), "pg", "sg" (B,h,w,c),
- * "dec_map" (B,h,w,c).  Returns the element count through *count. */
+ * "dec_map" (B,h,w,c), "dec_up<i>" (B, h<<(i+1), w<<(i+1), c>>(i+1)): RAW output of the i-th decoder
+ * up-convolution, before its InstanceNorm + ReLU (the last one is normalised in place when ngf % 16 != 0, i.e. when the
+ * RGB head runs on the MFMA kernel).  Returns the element count through *count. */
 int tsnet_stage_ptr(tsnet_handle h, const char* name, const float** dev_ptr, size_t* count);
 
 /* Algorithmic work of one forward at batch B (multiply-accumulates, SURVEY.md section 8-d closed form). */

@@ -51,6 +51,12 @@ def stage_report(eng, ref_stages, K, B, device):
         out[f"src_fea{i}"] = (src[i * B:(i + 1) * B] - ref_stages["src_fea"][i]).abs().max().item()
     for k in ("tar_fea", "pg", "sg", "dec_map"):
         out[k] = (nhwc_to_nchw(eng.stage(k, device).cpu()) - ref_stages[k]).abs().max().item()
+    i = 0
+    while f"dec_up{i}" in ref_stages:      # the engine exposes the raw up-convolution output; the oracle stage is IN + ReLU of it
+        r = ref_stages[f"dec_up{i}"]
+        raw = nhwc_to_nchw(eng.stage(f"dec_up{i}", device, shape=(r.shape[2], r.shape[3], r.shape[1])).cpu())
+        out[f"dec_up{i}"] = (torch.relu(torch.nn.functional.instance_norm(raw, eps=1e-5)) - r).abs().max().item()
+        i += 1
     return out
 
 

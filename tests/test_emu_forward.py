@@ -31,6 +31,8 @@ def test_forward_matches_oracle(emu_lib, kw):
         assert (a - b).abs().max().item() < 1e-4
     rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, B, "cpu")
     assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4 and rep["pg"] < 2e-3
+    # downstream of pg (flow error x feature gradient).  Not the last one: at ngf = 8 the MFMA head path normalises it in place
+    assert max(rep[f"dec_up{i}"] for i in range(cfg.n_downsampling - 1)) < 2e-3
     cnt = (C.c_int64 * 4)()
     emu_lib.tsnet_debug_counters(cnt, 1)
     assert cnt[2] > 0 and cnt[1] == 0        # every conv went through conv_dma_kernel
@@ -122,6 +124,7 @@ def test_bf16x3_schedule(emu_lib, monkeypatch):
     assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
     rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, 2, "cpu")
     assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4
+    assert max(rep[k] for k in rep if k.startswith("dec_up")) < 2e-3
     # clip mode on the x3 schedule
     eng.set_sources(inp[0], inp[1], inp[2])
     r2, _ = eng.forward_target(inp[3], inp[4])

@@ -1341,6 +1341,10 @@ int tsnet_stage_ptr(tsnet_handle h, const char* name, const float** dev_ptr, siz
     else if (n == "pg") { p = h->pg; c = B * fe; }
     else if (n == "sg") { p = h->sg; c = B * fe; }
     else if (n == "dec_map") { p = h->D; c = B * fe; }
+    else if (n.rfind("dec_up", 0) == 0 && n.size() == 7 && n[6] >= '0' && n[6] < '0' + h->cfg.n_downsampling) {
+        const int i = n[6] - '0';        // raw output of the i-th decoder up-convolution (before its InstanceNorm)
+        p = h->R[i]; c = B * ((size_t)(h->h << (i + 1)) * (h->w << (i + 1)) * (h->C >> (i + 1)));
+    }
     else throw ArgError("unknown stage '" + n + "'");
     if (dev_ptr) *dev_ptr = p;
     if (count) *count = c;

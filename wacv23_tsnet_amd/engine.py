@@ -169,13 +169,14 @@ class TSNetEngine:
         self._keep = (tl, tb)
         return out, ([flow[i] for i in range(K)] if return_flow else None)
 
-    def stage(self, name: str, device) -> torch.Tensor:
-        """Copy of a stage tensor of the last forward, NHWC (see tsnet_stage_ptr)."""
+    def stage(self, name: str, device, shape=None) -> torch.Tensor:
+        """Copy of a stage tensor of the last forward, NHWC (see tsnet_stage_ptr); `shape` = trailing (H, W, C)
+        for stages that are not at the feature resolution ("dec_up<i>")."""
         p = C.c_void_p()
         n = C.c_size_t()
         self._check(self.lib.tsnet_stage_ptr(self._h, name.encode(), C.byref(p), C.byref(n)), "tsnet_stage_ptr")
         flat = _alias_device_bytes(p.value, n.value * 4, device).view(torch.float32).clone()
-        return flat.view(-1, self.h, self.w, self.C)
+        return flat.view(-1, *(shape if shape is not None else (self.h, self.w, self.C)))
 
     def forward_macs(self, B: int) -> float:
         return float(self.lib.tsnet_forward_macs(self._h, B))
