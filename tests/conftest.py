@@ -6,6 +6,7 @@ MFMA fragment layouts are checked against the oracle in the CPU-only test tier. 
 infrastructure: nothing under wacv23_tsnet_amd/ ever loads it.
 """
 import ctypes
+import glob
 import os
 import subprocess
 import sys
@@ -23,7 +24,7 @@ def pytest_configure(config):
 
 def build_emu_lib() -> str:
     src = [os.path.join(ROOT, "wacv23_tsnet_amd", "csrc", "engine.cpp"), os.path.join(ROOT, "tests", "emu", "emu_runtime.cpp")]
-    deps = src + [os.path.join(ROOT, "wacv23_tsnet_amd", "csrc", f) for f in ("conv_igemm.hpp", "conv_dma.hpp", "conv_x3.hpp", "split3.hpp", "head_conv.hpp", "flow_warp.hpp", "norm_elementwise.hpp")]
+    deps = src + sorted(glob.glob(os.path.join(ROOT, "wacv23_tsnet_amd", "csrc", "*.hpp")))
     deps += [os.path.join(ROOT, "include", "tsnet_abi.h"), os.path.join(ROOT, "tests", "emu", "include", "hip", "hip_runtime.h")]
     out_dir = os.path.join(ROOT, "tests", "emu", "_build")
     os.makedirs(out_dir, exist_ok=True)
