@@ -542,7 +542,10 @@ void run_norm_act(Ctx& ctx, const float* x, const float* alpha, const float* bet
     if (C & 3) throw ArgError("norm_act: C must be a multiple of 4");
     TimeScope ts(ctx, TSNET_T_ELEMWISE);
     NormActArgs a{x, alpha, beta, resid, y, HW, C, relu, (size_t)N * HW * C / 4, y3};
-    hipLaunchKernelGGL(norm_act_kernel, dim3(ew_grid(a.total4)), dim3(256), 0, ctx.stream, a);
+    if ((double)HW * C / 4 >= 4294967295.0 || N > 65535) throw ArgError("norm_act: tensor too large");
+    size_t per_img4 = (size_t)HW * C / 4, gx = (per_img4 + 255) / 256, cap = std::max<size_t>(1, 4096 / (size_t)N);
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)gx, N), dim3(256), 0, ctx.stream, a);
     check_launch("norm_act");
 }
 
@@ -551,7 +554,9 @@ void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* bet
     if (C & 3) throw ArgError("upsample: C must be a multiple of 4");
     TimeScope ts(ctx, TSNET_T_UPSAMPLE);
     UpsampleArgs a{x, alpha, beta, y, N, H, W, C, relu, y3};
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, ctx.stream, a);
+    if (2 * H > 65535 || N > 65535) throw ArgError("upsample: tensor too large");
+    const size_t row4 = (size_t)2 * W * C / 4;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)std::min<size_t>((row4 + 255) / 256, 64), 2 * H, N), dim3(256), 0, ctx.stream, a);
     check_launch("upsample2x");
 }
 

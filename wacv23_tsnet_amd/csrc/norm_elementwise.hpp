@@ -132,16 +132,33 @@ struct NormActArgs {
     unsigned short* y3;    // null, or bf16x3 planes of the output (conv_x3 operand format)
 };
 
+// grid = (chunks, N): the image comes from blockIdx.y and the channel quad is advanced incrementally -- no per-element
+// division (a 64-bit i / per_img, i % c4n per float4 made this kernel VALU-bound at 3.2 TB/s).  When the grid stride
+// is a multiple of C/4 (always, for the power-of-two widths of the model) a thread stays on one channel quad and the
+// scale/shift pair is loaded once.
 __global__ __launch_bounds__(256) void norm_act_kernel(NormActArgs a) {
-    const int c4n = a.C >> 2;
-    const size_t per_img = (size_t)a.HW * c4n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int n = (int)(i / per_img);
-        const int c = (int)(i % c4n) * 4;
+    const unsigned c4n = (unsigned)a.C >> 2;
+    const unsigned per_img = (unsigned)a.HW * c4n;
+    const unsigned n = blockIdx.y;
+    const unsigned stride = gridDim.x * 256u;
+    const unsigned sc = stride % c4n;
+    unsigned j = blockIdx.x * 256u + threadIdx.x;
+    unsigned cq = j % c4n;
+    const bool fixed_c = sc == 0 && a.alpha != nullptr;
+    float4 al = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fixed_c) {
+        al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * a.C + cq * 4);
+        be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * a.C + cq * 4);
+    }
+    for (; j < per_img; j += stride) {
+        const size_t i = (size_t)n * per_img + j;
         float4 v = reinterpret_cast<const float4*>(a.x)[i];
         if (a.alpha) {
-            const float4 al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * a.C + c);
-            const float4 be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * a.C + c);
+            if (!fixed_c) {
+                al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * a.C + cq * 4);
+                be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * a.C + cq * 4);
+                cq += sc; if (cq >= c4n) cq -= c4n;
+            }
             v.x = __builtin_fmaf(v.x, al.x, be.x);
             v.y = __builtin_fmaf(v.y, al.y, be.y);
             v.z = __builtin_fmaf(v.z, al.z, be.z);
@@ -230,16 +247,17 @@ __device__ __forceinline__ float4 na4(float4 v, const float4& al, const float4& 
     return v;
 }
 
+// grid = (chunks of one output row, 2H, N): row and image come from the block index, one 32-bit division per element
 __global__ __launch_bounds__(256) void upsample2x_kernel(UpsampleArgs a) {
-    const int c4n = a.C >> 2;
+    const unsigned c4n = (unsigned)a.C >> 2;
     const int Ho = 2 * a.H, Wo = 2 * a.W;
     const size_t total = (size_t)a.N * Ho * Wo * c4n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
-        size_t t = i / c4n;
-        const int ox = (int)(t % Wo); t /= Wo;
-        const int oy = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+    const int oy = blockIdx.y, n = blockIdx.z;
+    const unsigned row4 = (unsigned)Wo * c4n;
+    for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < row4; j += gridDim.x * 256u) {
+        const int ox = (int)(j / c4n);
+        const int c = (int)(j - (unsigned)ox * c4n) * 4;
+        const size_t i = ((size_t)n * Ho + oy) * row4 + j;
         float sy = (oy + 0.5f) * 0.5f - 0.5f; if (sy < 0.f) sy = 0.f;
         float sx = (ox + 0.5f) * 0.5f - 0.5f; if (sx < 0.f) sx = 0.f;
         const int y0 = (int)sy, x0 = (int)sx;
