@@ -30,6 +30,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA
 # The conv kernel evaluates every fp32 product as 6 bf16 MFMA products (3-way operand split, conv_x3.hpp), so the
 # ceiling of the method in algorithmic (fp32) FLOPs is the bf16 peak / 6.
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PMC_TRAFFIC_BYTES_RES_CONV = int((317.92 + 26.92) * 2**20)   # profiles/round1_pmc_summary.txt, conv_x3q<64,2,2>, per launch
 
 
 def _usable_cores() -> int:
@@ -114,20 +115,45 @@ def main():
         total_macs = eng.forward_macs(B_PER_GPU)
         corr_macs = B_PER_GPU * K * P * P * (C + 2)
         conv_flops = 2.0 * (total_macs - corr_macs)
-        conv_ms, conv_launches = tm["conv"]
-        achieved = conv_flops * nprobe / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        res_ms, res_launches = tm.get("conv_res", (0.0, 0))
+        conv_ms, conv_launches = tm["conv"][0] + res_ms, tm["conv"][1] + res_launches
+        conv_tf = conv_flops * nprobe / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         x3 = os.environ.get("TSNET_X3", "1") != "0"
         peak = PEAK_X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
-        roofline = {"bound": "mfma",
-                    "kernel": ("conv_x3_kernel" if x3 else "conv_dma_kernel") + " (all conv launches of one forward)",
-                    "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
-                    "peak_basis": ("2500 TF dense bf16 MFMA / 6 bf16 products per fp32 product (3-way split)" if x3
-                                   else "157.3 TF exact-fp32 MFMA"),
-                    "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "algorithmic_gflop_per_launch_set": round(conv_flops / 1e9, 2),
-                    "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4), "launches_per_forward": conv_launches // nprobe,
-                    "class_ms_per_forward": {k: round(v[0] / nprobe, 3) for k, v in tm.items() if v[1]}}
+        class_ms = {k: round(v[0] / nprobe, 3) for k, v in tm.items() if v[1]}
+        if x3 and res_launches:
+            # dominant kernel: the 3x3 convolution of the encoder's residual blocks (2 per block; conv_x3p.hpp x3q tiles):
+            # M = K*B*h*w output positions, Cin = Cout = C, 9 taps -- SURVEY.md section 8-d: 2*M*C*9C flop per launch
+            flop_per_launch = 2.0 * (K * B_PER_GPU * P) * C * (9 * C)
+            avg_ms = res_ms / res_launches
+            achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma",
+                        "kernel": "conv_x3q_kernel<64,2,2> (3x3 ResnetBlock convolution, %d launches per forward = %.0f %% of the forward)"
+                                  % (res_launches // nprobe, 100.0 * res_ms / nprobe / (dt * 1e3 / args.steps)),
+                        "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4),
+                        # HBM-side bytes per launch of this kernel from the committed PMC passes (profiles/round1_pmc_summary.txt:
+                        # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); bench.py cannot run rocprofv3 on itself
+                        "traffic": PMC_TRAFFIC_BYTES_RES_CONV,
+                        "peak_basis": "2500 TF dense bf16 MFMA / 6 bf16 products per fp32 product (3-way operand split)",
+                        "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "algorithmic_gflop_per_launch": round(flop_per_launch / 1e9, 2),
+                        "avg_launch_ms": round(avg_ms, 4), "launches_per_forward": res_launches // nprobe,
+                        "all_conv_launches": {"achieved": round(conv_tf, 2), "frac": round(conv_tf / peak, 4),
+                                              "launches_per_forward": conv_launches // nprobe,
+                                              "algorithmic_gflop": round(conv_flops / 1e9, 2)},
+                        "class_ms_per_forward": class_ms}
+        else:
+            roofline = {"bound": "mfma",
+                        "kernel": ("conv_x3_kernel" if x3 else "conv_dma_kernel") + " (all conv launches of one forward)",
+                        "achieved": round(conv_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(conv_tf / peak, 4), "traffic": None,
+                        "peak_basis": ("2500 TF dense bf16 MFMA / 6 bf16 products per fp32 product (3-way split)" if x3
+                                       else "157.3 TF exact-fp32 MFMA"),
+                        "frac_of_fp32_mfma_peak": round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "algorithmic_gflop_per_launch_set": round(conv_flops / 1e9, 2),
+                        "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4), "launches_per_forward": conv_launches // nprobe,
+                        "class_ms_per_forward": class_ms}
 
     # ---- CPU baseline beside it (rank 0, N=1 only): the oracle on the host cores, same workload
     cpu_baseline, max_abs_delta = None, None

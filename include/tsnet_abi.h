@@ -115,9 +115,10 @@ double tsnet_forward_macs(tsnet_handle h, int B);
 /* Per-kernel-class timing of the next forward(s): when enabled the engine brackets every launch
  * class with hipEvents on the caller's stream (used by bench.py for the roofline object).
  * tsnet_timing_read returns accumulated milliseconds and launch counts per class. */
-#define TSNET_TIMING_CLASSES 8
+#define TSNET_TIMING_CLASSES 9
 enum { TSNET_T_CONV = 0, TSNET_T_STATS = 1, TSNET_T_ELEMWISE = 2, TSNET_T_FLOW = 3, TSNET_T_WARP = 4,
-       TSNET_T_PACK = 5, TSNET_T_UPSAMPLE = 6, TSNET_T_OTHER = 7 };
+       TSNET_T_PACK = 5, TSNET_T_UPSAMPLE = 6, TSNET_T_OTHER = 7,
+       TSNET_T_CONV_RES = 8 /* the 3x3 convolutions of the ResnetBlocks: the dominant kernel, timed apart from TSNET_T_CONV */ };
 int tsnet_timing_enable(tsnet_handle h, int on);
 int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64_t launches_out[TSNET_TIMING_CLASSES], int reset);
 

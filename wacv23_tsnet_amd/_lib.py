@@ -18,8 +18,8 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtsnet_hip.so")
 MAX_SOURCES = 8
-TIMING_CLASSES = 8
-TIMING_NAMES = ("conv", "stats", "elementwise", "flow", "warp", "pack", "upsample", "other")
+TIMING_CLASSES = 9
+TIMING_NAMES = ("conv", "stats", "elementwise", "flow", "warp", "pack", "upsample", "other", "conv_res")
 
 # every symbol include/tsnet_abi.h declares (tests/test_abi.py checks header <-> library <-> this list)
 ABI_SYMBOLS = (

@@ -366,6 +366,7 @@ struct X3Call {
     const float* addend = nullptr; int add_nmod = 1;
     double* stat_part = nullptr; mutable int stat_S = 0;
     int variant = -1;
+    int tclass = TSNET_T_CONV;
 };
 
 void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
@@ -385,7 +386,7 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
     if ((g.Csplit & 15) && c.x23) throw ArgError("conv(x3): channel split must be a multiple of 16");
     if ((double)c.N * c.H * c.W * L.cin_pad * 2 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
         throw ArgError("conv(x3): tensor too large for 32-bit buffer offsets");
-    TimeScope ts(ctx, TSNET_T_CONV);
+    TimeScope ts(ctx, c.tclass);
     const int forced = c.variant >= 0 ? (c.variant & 63) : -1;
     const int abl = c.variant >= 0 ? (c.variant >> 16) & 127 : 0;
     if (abl && L.ks == 3 && forced == 11) {
@@ -928,11 +929,11 @@ void tsnet_engine::alloc_all(hipStream_t s) {
 // ---- bf16x3 schedule: same graph as the fp32 one; every conv reads planes, producers write planes
 void tsnet_engine::resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float* y1, float* y2, int N, int hh, int ww) {
     const int Cc = c1.cout, HW = hh * ww;
-    X3Call a; a.x3 = Xs3; a.N = N; a.H = hh; a.W = ww; a.y = y1;
+    X3Call a; a.x3 = Xs3; a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
     auto s1 = next_ab();
     conv_stats_x3(ctx, c1, a, N, HW, s1.first, s1.second);
     run_norm_act(ctx, y1, s1.first, s1.second, 1, nullptr, N, HW, Cc, nullptr, T3);            // relu(IN(y1)) -> planes only
-    X3Call b; b.x3 = T3; b.N = N; b.H = hh; b.W = ww; b.y = y2;
+    X3Call b; b.x3 = T3; b.N = N; b.H = hh; b.W = ww; b.y = y2; b.tclass = TSNET_T_CONV_RES;
     auto s2 = next_ab();
     conv_stats_x3(ctx, c2, b, N, HW, s2.first, s2.second);
     run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs, Xs3);                       // X += IN(y2): fp32 + planes

@@ -66,11 +66,16 @@ __global__ __launch_bounds__(256) void head_conv_kernel(HeadArgs a) {
 #pragma unroll
                 for (int q = 0; q < kHeadCh / 4; ++q) {
                     const float4 v = tile[q * (kHeadP * kHeadP) + p];
-                    const float* w4 = wt + q * 16;
-                    a0 = __builtin_fmaf(v.x, w4[0], a0);  a1 = __builtin_fmaf(v.x, w4[1], a1);  a2 = __builtin_fmaf(v.x, w4[2], a2);
-                    a0 = __builtin_fmaf(v.y, w4[4], a0);  a1 = __builtin_fmaf(v.y, w4[5], a1);  a2 = __builtin_fmaf(v.y, w4[6], a2);
-                    a0 = __builtin_fmaf(v.z, w4[8], a0);  a1 = __builtin_fmaf(v.z, w4[9], a1);  a2 = __builtin_fmaf(v.z, w4[10], a2);
-                    a0 = __builtin_fmaf(v.w, w4[12], a0); a1 = __builtin_fmaf(v.w, w4[13], a1); a2 = __builtin_fmaf(v.w, w4[14], a2);
+                    // whole 16-float rows (padding lane included): one wide scalar load per channel quad instead of
+                    // twelve dword / dwordx2 loads, each of which forced an lgkmcnt(0) shared with the LDS reads
+                    // (315 -> 275 us).  Four pixels per thread (4x fewer weight loads) was slower: 256 workgroups
+                    // leave one wave per SIMD and the scalar-cache latency shows (298 us).
+                    const float4* w4 = reinterpret_cast<const float4*>(wt + q * 16);
+                    const float4 wx = w4[0], wy = w4[1], wz = w4[2], ww = w4[3];
+                    a0 = __builtin_fmaf(v.x, wx.x, a0); a1 = __builtin_fmaf(v.x, wx.y, a1); a2 = __builtin_fmaf(v.x, wx.z, a2);
+                    a0 = __builtin_fmaf(v.y, wy.x, a0); a1 = __builtin_fmaf(v.y, wy.y, a1); a2 = __builtin_fmaf(v.y, wy.z, a2);
+                    a0 = __builtin_fmaf(v.z, wz.x, a0); a1 = __builtin_fmaf(v.z, wz.y, a1); a2 = __builtin_fmaf(v.z, wz.z, a2);
+                    a0 = __builtin_fmaf(v.w, ww.x, a0); a1 = __builtin_fmaf(v.w, ww.y, a1); a2 = __builtin_fmaf(v.w, ww.z, a2);
                 }
             }
         }
