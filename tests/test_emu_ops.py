@@ -97,6 +97,17 @@ def test_conv_x3_patch_kernel(emu_lib):
     assert oc.conv_x3_tiles_bitwise(emu_lib, "cpu", 3, 4, 32, 32, 256, (11, 12, 13)) == 0.0
 
 
+def test_conv_x3r_register_staged(emu_lib):
+    """conv_x3r.hpp (tiles 16, 17): A tile staged through registers, weights fetched into registers; every kind of
+    layer the patch kernels do not take, and bit-identical to the LDS-DMA kernel of the same family"""
+    for tile in (16, 17):
+        assert oc.conv_x3_case(emu_lib, "cpu", 2, 11, 13, 16, 256, 3, 1, 1, True, tile=tile) < TOL
+        assert oc.conv_x3_case(emu_lib, "cpu", 1, 20, 13, 32, 128, 3, 2, 1, False, tile=tile) < TOL
+        assert oc.conv_x3_case(emu_lib, "cpu", 1, 9, 9, 8, 128, 7, 1, 3, True, tile=tile) < TOL
+        assert oc.conv_x3_case(emu_lib, "cpu", 3, 6, 5, 128, 192, 1, 1, 0, False, tile=tile, bias=False) < TOL
+    assert oc.conv_x3_tiles_bitwise(emu_lib, "cpu", 2, 9, 11, 32, 128, (0, 4, 16, 17)) == 0.0
+
+
 def test_conv_x3_1x1_and_ragged(emu_lib):
     assert oc.conv_x3_case(emu_lib, "cpu", 3, 6, 5, 128, 160, 1, 1, 0, False) < TOL
     assert oc.conv_x3_case(emu_lib, "cpu", 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL

@@ -110,6 +110,15 @@ def test_conv_x3_patch_kernel(lib):
     assert oc.conv_x3_tiles_bitwise(lib, DEV, 12, 32, 32, 256, 512, (14, 15)) == 0.0
 
 
+def test_conv_x3r_register_staged(lib):
+    """conv_x3r.hpp (tiles 16, 17): stems, stride-2 and 1x1 layers; bit-identical to the LDS-DMA kernel of its family"""
+    assert oc.conv_x3_case(lib, DEV, 2, 128, 128, 8, 64, 7, 1, 3, True, tile=17) < TOL
+    assert oc.conv_x3_case(lib, DEV, 4, 64, 64, 128, 256, 3, 2, 1, False, tile=16) < TOL
+    assert oc.conv_x3_case(lib, DEV, 4, 32, 32, 512, 512, 1, 1, 0, False, tile=17) < TOL
+    assert oc.conv_x3_case(lib, DEV, 3, 21, 19, 32, 130, 3, 1, 1, True, tile=16, bias=False) < TOL
+    assert oc.conv_x3_tiles_bitwise(lib, DEV, 4, 32, 32, 256, 256, (0, 4, 7, 16, 17)) == 0.0
+
+
 def test_conv_x3_big_layers(lib):
     assert oc.conv_x3_case(lib, DEV, 12, 32, 32, 512, 512, 3, 1, 1, True) < TOL
     assert oc.conv_x3_case(lib, DEV, 2, 16, 16, 1024, 1024, 3, 1, 1, True) < 1e-4

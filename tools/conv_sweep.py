@@ -25,14 +25,14 @@ LAYERS = [
 ]
 TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32)}
 DT = TILES
-XT = {0: (128, 128), 1: (128, 128), 2: (128, 128), 3: (128, 128), 4: (128, 64), 5: (64, 64), 6: (64, 128), 7: (96, 128), 8: (128, 32), 9: (128, 128), 10: (128, 128), 11: (128, 128), 12: (128, 64), 13: (128, 128), 14: (128, 128), 15: (128, 64)}
+XT = {0: (128, 128), 1: (128, 128), 2: (128, 128), 3: (128, 128), 4: (128, 64), 5: (64, 64), 6: (64, 128), 7: (96, 128), 8: (128, 32), 9: (128, 128), 10: (128, 128), 11: (128, 128), 12: (128, 64), 13: (128, 128), 14: (128, 128), 15: (128, 64), 16: (128, 128), 17: (128, 64)}
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
     npad = (Cout + 127) // 128 * 128 if Cout >= 128 else (Cout + 31) // 32 * 32
     res = []
-    for v in ([4096 + t for t in (0, 1)] + [8192 + t for t in (0, 7, 11, 13, 14, 15)]):
+    for v in ([4096 + t for t in (0, 1)] + [8192 + t for t in (0, 4, 7, 14, 15, 16, 17)]):
         tl = XT if v & 8192 else (DT if v & 4096 else TILES)
         if npad % tl[v & 63][1] or (tl[v & 63][1] > 32 and Cout <= tl[v & 63][1] // 2):
             continue

@@ -284,8 +284,9 @@ void conv_x3_kernel(X3Args a) {
                 for (int j = 0; j < NTL; ++j) bf[p][j] = *reinterpret_cast<const F4*>(gb + 3 * PLANE_A + p * PLANE_B + j * 1024 + b_off);
             }
             if (g == 0 && !(ABL & 1)) issue_step(st + NSTAGE - 1, refill_stage);
-            // six products per tile, small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            // six products per tile: lo*hi, mid*hi, hi*hi, mid*mid, hi*mid, hi*lo -- the order of conv_x3r.hpp (each
+            // weight plane retires early there); the two kernels must agree bit for bit
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 0, 0, 1, 1, 2};
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll

@@ -31,6 +31,7 @@
 #include "conv_igemm.hpp"
 #include "conv_x3.hpp"
 #include "conv_x3p.hpp"
+#include "conv_x3r.hpp"
 #include "flow_warp.hpp"
 #include "head_conv.hpp"
 #include "norm_elementwise.hpp"
@@ -250,8 +251,10 @@ const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, 1.0}, {128, 128, 2, 2, 1, 4, 
                             // conv_x3p.hpp, LDS-resident input patch.  11-13: x3p (weights through an LDS-DMA ring; 13 = mixed
                             // 128/64 launch), kept for the sweep / ablation tools.  14, 15: x3q (weights in registers), the default
                             {128, 128, 2, 2, 1, 3, 0.0, true}, {128, 64, 2, 2, 1, 3, 0.0, true}, {128, 128, 2, 2, 1, 3, 0.0, true},
-                            {128, 128, 2, 2, 1, 3, 1.4, true}, {128, 64, 2, 2, 1, 3, 1.25, true}};
-constexpr int kNumXTiles = 16;
+                            {128, 128, 2, 2, 1, 3, 1.4, true}, {128, 64, 2, 2, 1, 3, 1.25, true},
+                            // 16, 17: conv_x3r.hpp (register-staged A tile, weights in registers), same arithmetic as 0..10
+                            {128, 128, 2, 2, 1, 2, 1.02}, {128, 64, 2, 2, 1, 2, 0.75}};
+constexpr int kNumXTiles = 18;
 
 template <int KS, int BM, int BN, int WM_, int WN_, int KC, int NST>
 void launch_x3_t(const X3Args& a, hipStream_t s) {
@@ -289,6 +292,13 @@ void launch_x3p_mixed(const X3Args& a, int nsplit, hipStream_t s) {
     const int units = a.tiles_m * a.tiles_n, nbig = units - nsplit;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3p_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(conv_x3p_mixed_kernel, dim3(nbig + 2 * nsplit), dim3(256), lds, s, a, nbig);
+}
+
+template <int KS, int BN, int WM_, int WN_>
+void launch_x3r(const X3Args& a, hipStream_t s) {
+    const size_t lds = 2 * 3 * 128 * 32;
+    if (a.Cin < 16) hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
 template <int ABL>
@@ -351,6 +361,8 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         case 11: launch_x3p<128, 2, 2>(a, s); break;
         case 12: launch_x3p<64, 2, 2>(a, s); break;
         case 13: launch_x3p_mixed(a, mixed_split, s); break;
+        case 16: launch_x3r<KS, 128, 2, 2>(a, s); break;
+        case 17: launch_x3r<KS, 64, 2, 2>(a, s); break;
         case 14: launch_x3q<128, 2, 2>(a, s); break;
         case 15: launch_x3q<64, 2, 2>(a, s); break;
         case 9: launch_x3_t<KS, 128, 128, 4, 2, 1, 3>(a, s); break;
