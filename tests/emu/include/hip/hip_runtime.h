@@ -89,6 +89,12 @@ template <class T> static inline T emu_buf_load16(const tsnet_rsrc_t& r, unsigne
 // hook of conv_x3.hpp: v_mfma_f32_32x32x16_bf16 on raw 16-byte operands (8 bf16 per lane)
 #define TSNET_MFMA_BF16(a, b, c) emu::mfma_bf16_32x32x16(&(a), &(b), (c))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+// device-scope atomics of the statistics hand-off (conv_x3.hpp x3_epilogue): workgroups run one after another here
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
+template <class T> static inline T emu_fetch_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+#define __hip_atomic_fetch_add(p, v, order, scope) emu_fetch_add((p), (v))
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 

@@ -34,6 +34,9 @@ struct X3Args {
     int Ho, Wo, Cout, Npad;
     int stride, pad, reflect, taps, nchunks, M;   // nchunks in units of 16 k
     int tiles_m, tiles_n;
+    // optional: the last workgroup to deliver the statistics of an (image, channel tile) finalises them itself
+    // (alpha = rstd, beta = -mean*rstd), replacing the in_finalize2 launch; null = off
+    float* fin_alpha; float* fin_beta; int* fin_counter; int fin_S; float fin_eps;
 };
 
 #ifndef TSNET_MFMA_BF16
@@ -100,7 +103,45 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& a, f32x16 (&tot)[MT][N
 #pragma unroll
             for (int wmi = 0; wmi < WARPS_M; ++wmi) { s += red[((size_t)wmi * BN + tid) * 2]; q += red[((size_t)wmi * BN + tid) * 2 + 1]; }
             double* o = a.stat_part + (stat_tile * a.Cout + n0 + tid) * 2;
-            o[0] = s; o[1] = q;
+            if (a.fin_counter) {            // device-scope write-through: another XCD's workgroup may read them
+                __hip_atomic_store(o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                o[0] = s; o[1] = q;
+            }
+        }
+        if (a.fin_counter) {
+            // Arrival counter per (image, channel tile).  The partials above are
+            // acknowledged at device scope (vmcnt(0)) before this workgroup counts itself, so the workgroup that
+            // reads fin_S - 1 sees all of them.  It sums them in in_finalize2_kernel's order (four interleaved
+            // groups, then g0+g1+g2+g3): bit-identical to the separate kernel, run-to-run deterministic.
+            const int S = a.fin_S;
+            const int img = (int)(stat_tile / (size_t)S);
+            int* counter = a.fin_counter + (size_t)img * ((a.Npad + 31) / 32) + n0 / 32;   // 32 = narrowest tile
+            int* flag = reinterpret_cast<int*>(smem_raw + 8192);
+            TSNET_VMCNT(0);
+            __syncthreads();
+            if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*flag == S - 1) {
+                if (tid < BN && n0 + tid < a.Cout) {
+                    double gs[4] = {0, 0, 0, 0}, gq[4] = {0, 0, 0, 0};
+                    for (int t = 0; t < S; ++t) {
+                        const double* p = a.stat_part + (((size_t)img * S + t) * a.Cout + n0 + tid) * 2;
+                        gs[t & 3] += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gq[t & 3] += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    double sm = gs[0], sq = gq[0];
+                    for (int k = 1; k < 4; ++k) { sm += gs[k]; sq += gq[k]; }
+                    const double mean = sm / hw;
+                    double var = sq / hw - mean * mean;
+                    if (var < 0) var = 0;
+                    const float al = 1.0f / sqrtf((float)var + a.fin_eps);
+                    a.fin_alpha[(size_t)img * a.Cout + n0 + tid] = al;
+                    a.fin_beta[(size_t)img * a.Cout + n0 + tid] = -((float)mean) * al;
+                }
+                if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
         }
     }
 }

@@ -348,6 +348,11 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
     a.tiles_n = (a.Cout + kXTiles[best].bn - 1) / kXTiles[best].bn;
     const int hw = a.Ho * a.Wo;
     if (hw % kXTiles[best].bm) a.stat_part = nullptr;
+    // few tiles per image: the last workgroup of each (image, channel tile) finalises the statistics (x3_epilogue);
+    // many tiles per image (the 128^2 / 256^2 layers): a serial tail of hundreds of partials would cost more than the
+    // in_finalize2 launch it saves.  The mixed x3p launch (tile 13) has two tile widths per launch: not counted.
+    if (!a.stat_part || hw / kXTiles[best].bm > 32 || best == 13 || (size_t)a.N * ((a.Npad + 31) / 32) > 65536) a.fin_counter = nullptr;
+    a.fin_S = hw / kXTiles[best].bm;
     switch (best) {
         case 0: launch_x3_t<KS, 128, 128, 2, 2, 1, 3>(a, s); break;
         case 1: launch_x3_t<KS, 128, 128, 2, 2, 1, 4>(a, s); break;
@@ -368,6 +373,7 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         case 9: launch_x3_t<KS, 128, 128, 4, 2, 1, 3>(a, s); break;
         default: launch_x3_t<KS, 128, 128, 2, 4, 1, 3>(a, s); break;
     }
+    if (a.stat_part && a.fin_counter) return -1;     // statistics complete: alpha / beta written by the kernel
     return a.stat_part ? hw / kXTiles[best].bm : 0;
 }
 
@@ -376,7 +382,8 @@ struct X3Call {
     int N = 0, H = 0, W = 0, csplit = 0, x2_nmod = 1;
     float* y = nullptr; unsigned short* y3 = nullptr;
     const float* addend = nullptr; int add_nmod = 1;
-    double* stat_part = nullptr; mutable int stat_S = 0;
+    double* stat_part = nullptr; mutable int stat_S = 0;   // stat_S out: partials per image; 0 = none; -1 = finalised in the kernel
+    float* fin_alpha = nullptr; float* fin_beta = nullptr; int* fin_counter = nullptr;   // optional in-kernel finalize
     int variant = -1;
     int tclass = TSNET_T_CONV;
 };
@@ -385,6 +392,7 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
     X3Args g{};
     g.x = c.x3; g.x2 = c.x23; g.w = L.w3; g.bias = L.bias; g.y = c.y; g.y3 = c.y3;
     g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
+    g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_counter = c.stat_part ? c.fin_counter : nullptr; g.fin_eps = 1e-5f;
     g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
     g.Csplit = c.x23 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
     g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
@@ -684,6 +692,7 @@ struct tsnet_engine {
     std::vector<float*> U, R;
     float* ab[4][2] = {{nullptr}};
     double* part = nullptr;
+    int* fin_counter = nullptr;        // arrival counters of the in-kernel statistics finalize (x3_epilogue), all zero between launches
     int ab_rr = 0;
 
     // clip-mode cache
@@ -717,7 +726,9 @@ struct tsnet_engine {
     void forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
     void conv_stats_x3(Ctx& ctx, const ConvLayer& L, X3Call& c, int N, int HW, float* alpha, float* beta) {
         c.stat_part = part;
+        c.fin_alpha = alpha; c.fin_beta = beta; c.fin_counter = fin_counter;
         run_conv_x3(ctx, L, c);
+        if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
         if (c.stat_S > 0) {
             TimeScope ts(ctx, TSNET_T_STATS);
             hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + 63) / 64, N), dim3(256), 0, ctx.stream, part, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
@@ -913,6 +924,8 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     size_t o = 0;
     for (auto& r : req) { *r.first = arena + o; o += r.second; }
     part = reinterpret_cast<double*>(part_f);
+    HIP_TRY(hipMalloc((void**)&fin_counter, 65536 * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(fin_counter, 0, 65536 * sizeof(int), s));
 
     if (x3) {    // ---- bf16x3 planes of every conv input (3 planes x 2 bytes per element)
         std::vector<std::pair<unsigned short**, size_t>> rq;
@@ -1300,7 +1313,7 @@ int tsnet_finalize(tsnet_handle h, void* stream) {
 
 void tsnet_destroy(tsnet_handle h) {
     if (!h) return;
-    (void)hipFree(h->arena3);
+    (void)hipFree(h->arena3); (void)hipFree(h->fin_counter);
     (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
     delete h;
 }
