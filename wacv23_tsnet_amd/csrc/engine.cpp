@@ -590,11 +590,11 @@ void run_l2norm(Ctx& ctx, const float* x, float* y, int rows, int C) {
 void run_flow(Ctx& ctx, FlowArgs a, int NB) {
     if (a.C & 7) throw ArgError("flow: C must be a multiple of 8");
     TimeScope ts(ctx, TSNET_T_FLOW);
-    const size_t lds = ((size_t)32 * (a.C + 4) + ((a.P + 3) & ~3) + 8 * 32 * 4) * sizeof(float);
+    const size_t lds = ((size_t)32 * (a.C + 4) + ((a.P + 3) & ~3) + 2 * kFlowWaves * 32 * 4) * sizeof(float);
     if (lds > 160 * 1024) throw ArgError("flow: feature width / position count exceed the LDS budget");
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(flow_kernel, dim3((a.P + 31) / 32, NB), dim3(256), lds, ctx.stream, a);
+    hipLaunchKernelGGL(flow_kernel, dim3((a.P + 31) / 32, NB), dim3(64 * kFlowWaves), lds, ctx.stream, a);
     check_launch("flow");
 }
 

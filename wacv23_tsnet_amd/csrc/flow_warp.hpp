@@ -30,13 +30,17 @@ struct FlowArgs {
     int B, P, C, h, w, H, W, sy, sx;
 };
 
-// grid = (ceil(P/32), NB), block = 256.  dyn LDS: T tile [32][C+4] floats + ms[P] + merge[8][32][4]
-__global__ __launch_bounds__(256) void flow_kernel(FlowArgs a) {
+// grid = (ceil(P/32), NB), block = 64 * kFlowWaves.  dyn LDS: T tile [32][C+4] floats + ms[P] + merge[2*waves][32][4].
+// Eight waves per workgroup: the grid is only 384 workgroups at cfg0 (12 images x 32 target tiles), and every wave
+// streams its own source rows from global memory -- with four waves that was 1.5 waves per SIMD to hide the loads.
+constexpr int kFlowWaves = 8;
+__global__ __launch_bounds__(64 * kFlowWaves) void flow_kernel(FlowArgs a) {
+    constexpr int NT = 64 * kFlowWaves;
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     const int LDT = a.C + 4;
     float* sT = reinterpret_cast<float*>(smem_raw);     // [32][LDT]
     float* sMs = sT + 32 * LDT;                          // [P]
-    float* sRed = sMs + ((a.P + 3) & ~3);                // [8][32][4]
+    float* sRed = sMs + ((a.P + 3) & ~3);                // [2 * kFlowWaves][32][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -46,14 +50,14 @@ __global__ __launch_bounds__(256) void flow_kernel(FlowArgs a) {
 
     // stage the target tile (rows beyond P are zero) and the source mask row
     const int c4n = a.C >> 2;
-    for (int i = tid; i < 32 * c4n; i += 256) {
+    for (int i = tid; i < 32 * c4n; i += NT) {
         const int r = i / c4n, c = (i - r * c4n) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t0 + r < a.P) v = *reinterpret_cast<const float4*>(a.that + ((size_t)b * a.P + t0 + r) * a.C + c);
         *reinterpret_cast<float4*>(sT + r * LDT + c) = v;
     }
     const float* sb = a.src_bbox[s_idx] + (size_t)b * a.H * a.W;
-    for (int p = tid; p < a.P; p += 256) {
+    for (int p = tid; p < a.P; p += NT) {
         const int py = p / a.w, px = p - py * a.w;
         sMs[p] = sb[(size_t)(py * a.sy) * a.W + px * a.sx];   // F.interpolate(nearest): src = dst*scale
     }
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void flow_kernel(FlowArgs a) {
     float m_run = -3.0e38f, l_run = 0.f, ax = 0.f, ay = 0.f;
     const int ntile = (a.P + 31) >> 5;
     const float* srow_base = a.shat + (size_t)n * a.P * a.C;
-    for (int st = wave; st < ntile; st += 4) {
+    for (int st = wave; st < ntile; st += kFlowWaves) {
         const int s0 = st * 32;
         const int srow = s0 + li < a.P ? s0 + li : a.P - 1;     // clamp (masked below)
         const float* ap = srow_base + (size_t)srow * a.C + lh * 4;
@@ -115,15 +119,15 @@ __global__ __launch_bounds__(256) void flow_kernel(FlowArgs a) {
         }
         m_run = m_new;
     }
-    // merge the 8 partial states (4 waves x 2 half-waves) of each target column
+    // merge the partial states (waves x 2 half-waves) of each target column
     float* o = sRed + ((wave * 2 + lh) * 32 + li) * 4;
     o[0] = m_run; o[1] = l_run; o[2] = ax; o[3] = ay;
     __syncthreads();
     if (tid < 32 && t0 + tid < a.P) {
         float M = -3.0e38f;
-        for (int q = 0; q < 8; ++q) { const float v = sRed[(q * 32 + tid) * 4]; M = v > M ? v : M; }
+        for (int q = 0; q < 2 * kFlowWaves; ++q) { const float v = sRed[(q * 32 + tid) * 4]; M = v > M ? v : M; }
         float L = 0.f, X = 0.f, Y = 0.f;
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 2 * kFlowWaves; ++q) {
             const float* p = sRed + (q * 32 + tid) * 4;
             if (p[1] > 0.f) {
                 const float sc = expf(p[0] - M);
