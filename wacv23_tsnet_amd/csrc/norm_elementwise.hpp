@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void in_finalize2_kernel(const double* __restr
     const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double sm = 0, sq = 0;
     if (c < C) {
-        for (int s = g; s < S; s += 4) {
+#pragma unroll 8
+        for (int s = g; s < S; s += 4) {      // unrolled: the loads of 8 partials are in flight together, the additions stay in order
             const double* p = part + (((size_t)n * S + s) * C + c) * 2;
             sm += p[0];
             sq += p[1];
