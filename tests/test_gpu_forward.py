@@ -180,3 +180,26 @@ def test_cfg4_shape_512_k5():
     print(f"[cfg4-shape] d_rec={d:.2e} d_flow={df:.2e}")
     assert d <= TOL_REC and df <= TOL_FLOW
     eng.close()
+
+
+def test_packed_weight_buffer_goes_through_rccl(cfg0):
+    """The multi-GPU path broadcasts the engine's packed weight buffer in place (dist.build_replica).  With one GPU
+    the collective is a self-broadcast, but it takes the same route: RCCL must accept the zero-copy alias of the
+    engine's allocation, and the engine must compute the same image afterwards."""
+    import socket
+    import torch.distributed as dist
+    eng, inputs = cfg0["eng"], cfg0["inputs"]
+    rec0, _ = Hh.run_engine(eng, inputs, DEV, return_flow=False)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        buf = eng.packed_weights(DEV)
+        assert buf.dtype == torch.uint8 and buf.numel() > 3 * 67_000_000      # fp32 packings + bf16x3 planes of 67 M weights
+        dist.broadcast(buf, src=0)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    rec1, _ = Hh.run_engine(eng, inputs, DEV, return_flow=False)
+    assert torch.equal(rec0, rec1)
