@@ -30,7 +30,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA
 # The conv kernel evaluates every fp32 product as 6 bf16 MFMA products (3-way operand split, conv_x3.hpp), so the
 # ceiling of the method in algorithmic (fp32) FLOPs is the bf16 peak / 6.
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-PMC_TRAFFIC_BYTES_RES_CONV = int((317.92 + 26.92) * 2**20)   # profiles/round1_pmc_summary.txt, conv_x3q<64,2,2>, per launch
+PMC_TRAFFIC_BYTES_RES_CONV = int((320.96 + 27.70) * 2**20)   # profiles/round1_pmc_summary.txt, conv_x3q<64,2,2>, per launch
 
 
 def _usable_cores() -> int:
