@@ -226,7 +226,9 @@ __device__ __forceinline__ tsnet_brsrc_t tsnet_make_brsrc(const void* p, unsigne
 #define TSNET_BUF_LOAD16(rsrc, voff, soff) __builtin_bit_cast(F4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (int)(voff), (int)(soff), 0))
 #endif
 
-template <int BN, int WARPS_M, int WARPS_N>
+// QABL (tools/x3_ablate.py q only; non-zero computes garbage): bit0 no patch staging, bit1 no slab barrier, bit2 no fold,
+// bit3 weight fragments loaded once, bit4 A fragments read once
+template <int BN, int WARPS_M, int WARPS_N, int QABL = 0>
 __device__ __forceinline__ void x3q_tile(const X3Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
     constexpr int BM = kPatchRows * kPatchCols;
     constexpr int NW = WARPS_M * WARPS_N;
@@ -344,21 +346,21 @@ __device__ __forceinline__ void x3q_tile(const X3Args& a, unsigned char* smem_ra
         const bool last = t == 8;
         const int nc = last ? cc + 1 : cc, nt = last ? 0 : t + 1;
         F4 stage;
-        if (t < 6) stage = patch_load(cc + 1, t);
-        product(2, 0, fresh);                                // lo  * hi
-        if (!last) load_a(2, nc, nt);
+        if (t < 6 && !(QABL & 1)) stage = patch_load(cc + 1, t);
+        product(2, 0, fresh && !(QABL & 4));                 // lo  * hi
+        if (!last && !(QABL & 16)) load_a(2, nc, nt);
         product(1, 0, false);                                // mid * hi
         product(0, 0, false);                                // hi  * hi
-        load_b(0, nc, nt);
+        if (!(QABL & 8)) load_b(0, nc, nt);
         product(1, 1, false);                                // mid * mid
-        if (!last) load_a(1, nc, nt);
+        if (!last && !(QABL & 16)) load_a(1, nc, nt);
         product(0, 1, false);                                // hi  * mid
-        load_b(1, nc, nt);
+        if (!(QABL & 8)) load_b(1, nc, nt);
         product(0, 2, false);                                // hi  * lo
-        if (!last) load_a(0, nc, nt);
-        load_b(2, nc, nt);
-        if (t < 6) patch_store(cc + 1, t, stage);
-        if (t == 3 || t == 8) {
+        if (!last && !(QABL & 16)) load_a(0, nc, nt);
+        if (!(QABL & 8)) load_b(2, nc, nt);
+        if (t < 6 && !(QABL & 1)) patch_store(cc + 1, t, stage);
+        if ((t == 3 || t == 8) && !(QABL & 4)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -372,9 +374,11 @@ __device__ __forceinline__ void x3q_tile(const X3Args& a, unsigned char* smem_ra
 #pragma unroll
     for (int p = 0; p < 3; ++p) load_b(p, 0, 0);
     for (int cc = 0; cc < ncc; ++cc) {
-        __syncthreads();                                     // patch(cc) complete and visible; slab cc-1 fully read
+        if (!(QABL & 2)) __syncthreads();                    // patch(cc) complete and visible; slab cc-1 fully read
+        if (!(QABL & 16) || cc == 0) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) load_a(p, cc, 0);
+            for (int p = 0; p < 3; ++p) load_a(p, cc, 0);
+        }
         step(cc, 0); step(cc, 1); step(cc, 2);
         step(cc, 3); step(cc, 4); step(cc, 5);
         step(cc, 6); step(cc, 7); step(cc, 8);
@@ -391,13 +395,13 @@ __device__ __forceinline__ int x3p_item(int bid, int nitems) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <int BN, int WARPS_M, int WARPS_N>
+template <int BN, int WARPS_M, int WARPS_N, int QABL = 0>
 __global__ __launch_bounds__(256)
 void conv_x3q_kernel(X3Args a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
     const int tile_m = bid / a.tiles_n;
-    x3q_tile<BN, WARPS_M, WARPS_N>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+    x3q_tile<BN, WARPS_M, WARPS_N, QABL>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
 }
 
 template <int BN, int WARPS_M, int WARPS_N, bool FOLD = true, int ABL = 0>

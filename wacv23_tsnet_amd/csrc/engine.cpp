@@ -301,6 +301,12 @@ void launch_x3r(const X3Args& a, hipStream_t s) {
     else hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
+template <int QABL>
+void launch_x3q_abl(X3Args a, hipStream_t s) {    // diagnostic: x3q kernel, 128x64 tiles (the ResnetBlock configuration)
+    a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.Cout + 63) / 64;
+    hipLaunchKernelGGL((conv_x3q_kernel<64, 2, 2, QABL>), dim3(a.tiles_m * a.tiles_n), dim3(256), 2 * 3 * 7 * 1024 + 1024, s, a);
+}
+
 template <int ABL>
 void launch_x3p_abl(X3Args a, hipStream_t s) {    // diagnostic: patch kernel, 128x128 tiles
     a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.Cout + 127) / 128;
@@ -409,6 +415,20 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
     TimeScope ts(ctx, c.tclass);
     const int forced = c.variant >= 0 ? (c.variant & 63) : -1;
     const int abl = c.variant >= 0 ? (c.variant >> 16) & 127 : 0;
+    if (abl && L.ks == 3 && forced == 15) {
+        if (!x3p_ok<3>(g)) throw ArgError("ablation: layer not eligible for the patch kernel");
+        switch (abl) {
+            case 1: launch_x3q_abl<1>(g, ctx.stream); break;
+            case 2: launch_x3q_abl<2>(g, ctx.stream); break;
+            case 4: launch_x3q_abl<4>(g, ctx.stream); break;
+            case 8: launch_x3q_abl<8>(g, ctx.stream); break;
+            case 16: launch_x3q_abl<16>(g, ctx.stream); break;
+            case 24: launch_x3q_abl<24>(g, ctx.stream); break;
+            case 31: launch_x3q_abl<31>(g, ctx.stream); break;
+            default: throw ArgError("unsupported ablation mask");
+        }
+        return;
+    }
     if (abl && L.ks == 3 && forced == 11) {
         if (!x3p_ok<3>(g)) throw ArgError("ablation: layer not eligible for the patch kernel");
         switch (abl) {
