@@ -12,8 +12,11 @@
 //   l2norm x2 -> flow_kernel -> warp_mean_kernel                                 [A5, A6]
 //   fuse conv1 (cat on load) -> conv2 -> residual+mean -> 1x1 conv               [A7, A6]
 //   dec map 1x1 (cat on load) -> ResnetBlocks -> 3x (upsample, conv) -> 7x7+tanh [A8, A9]
-// InstanceNorm is split: statistics right after the producing conv (two tiny kernels), the
-// normalise+ReLU inside the consuming conv's loader.
+// Convolutions run on the bf16x3 kernels by default (every conv input as three bf16 planes written by its
+// producer): conv_x3p.hpp x3q tiles for 3x3 / stride 1, conv_x3r.hpp / conv_x3.hpp for the rest; TSNET_X3=0
+// selects the exact-fp32 MFMA schedule (conv_dma.hpp).  InstanceNorm is split: fp64 partial sums in the
+// producing conv's epilogue (finalised there by the last-arriving workgroup, or by in_finalize2), the
+// normalise + ReLU + bf16x3 split in one elementwise pass (norm_act / upsample2x) that feeds the next conv.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
