@@ -332,7 +332,7 @@ template <int KS>
 int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stats partials per image (0 = none)
     int best = forced_tile;
     if (best < 0) {
-        const char* e_tile = getenv("TSNET_X3_TILE");
+        static const char* const e_tile = getenv("TSNET_X3_TILE");     // in-situ A/B switch, read once
         double best_cost = 0;
         // the patch kernel sums K slab-major, the others tap-major: which of the two a layer runs on must depend on
         // the layer alone, never on the batch (results are identical for any batch size and any tile of one family)
