@@ -157,6 +157,20 @@ int tsnet_op_flow(const float* tar_fea, const float* src_fea, const float* tar_b
 int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, int C, float* out, void* stream);
 const char* tsnet_op_last_error(void);
 
+/* ---- demo post-processing (demo/demo_face.py:96-105,180-198 = demo/demo_pose.py:98-107,
+ * 186-203).  The reference does this per frame on the host with numpy + cv2; these entry points keep the frame on the
+ * device and hand back packed uint8 RGB.
+ * tsnet_frame_stats      <- x.view(B,C,-1) / div, then .mean(dim=2) and .std(dim=2) (unbiased): mean, std are (B*C) floats.
+ *                           div = 255 for the reference image (:180), 1 for a generated frame (:195-196).
+ * tsnet_demo_postprocess <- ((rec - gen_mean) / gen_std) * ref_std + ref_mean (:197-198), then sample_img (:96-105):
+ *                           + img_mean_over_255, clip to [0,1], * 255, BGR -> RGB, and the .astype('uint8') of :222.
+ *                           rec (B,3,H,W) fp32; gen_mean / gen_std (B*3); ref_mean / ref_std (3) device floats;
+ *                           img_mean_over_255: 3 HOST floats (IMG_MEAN / 255); out_rgb (B,H,W,3) bytes. */
+int tsnet_frame_stats(const float* x, int B, int C, int HW, float div, float* mean, float* std_unbiased, void* stream);
+int tsnet_demo_postprocess(const float* rec, int B, int H, int W, const float* gen_mean, const float* gen_std,
+                           const float* ref_mean, const float* ref_std, const float* img_mean_over_255,
+                           unsigned char* out_rgb, void* stream);
+
 /* Micro-benchmark of one convolution shape on synthetic (non-zero) data: average milliseconds per
  * launch over `iters` back-to-back launches, hipEvent-timed on `stream`.  variant: -1 = the engine's
  * own tile heuristic, else tile index + 8*(BK==32) (tools/conv_sweep.py).  Diagnostic only. */

@@ -38,6 +38,7 @@
 #include "flow_warp.hpp"
 #include "head_conv.hpp"
 #include "norm_elementwise.hpp"
+#include "postproc.hpp"
 
 using namespace tsnet;
 
@@ -1580,6 +1581,28 @@ int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, 
     if (C & 3) throw ArgError("warp op: C must be a multiple of 4");
     Ctx ctx; ctx.stream = (hipStream_t)stream;
     run_warp(ctx, src_fea, flow, out, B, 1, h, w, C);
+    OP_END
+}
+
+int tsnet_frame_stats(const float* x, int B, int C, int HW, float div, float* mean, float* std_unbiased, void* stream) {
+    OP_BEGIN
+    if (!x || !mean || !std_unbiased) throw ArgError("frame_stats: null tensor");
+    if (B < 1 || C < 1 || HW < 1 || B > 65535 || !(div > 0.f)) throw ArgError("frame_stats: bad shape or divisor");
+    hipLaunchKernelGGL(frame_stats_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, C, HW, div, mean, std_unbiased);
+    check_launch("frame_stats");
+    OP_END
+}
+
+int tsnet_demo_postprocess(const float* rec, int B, int H, int W, const float* gen_mean, const float* gen_std,
+                           const float* ref_mean, const float* ref_std, const float* img_mean_over_255,
+                           unsigned char* out_rgb, void* stream) {
+    OP_BEGIN
+    if (!rec || !gen_mean || !gen_std || !ref_mean || !ref_std || !img_mean_over_255 || !out_rgb) throw ArgError("demo_postprocess: null tensor");
+    if (B < 1 || H < 1 || W < 1) throw ArgError("demo_postprocess: bad shape");
+    DemoPostArgs a{rec, gen_mean, gen_std, ref_mean, ref_std, {img_mean_over_255[0], img_mean_over_255[1], img_mean_over_255[2]},
+                   out_rgb, B, H * W};
+    hipLaunchKernelGGL(demo_post_kernel, dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, a);
+    check_launch("demo_post");
     OP_END
 }
 

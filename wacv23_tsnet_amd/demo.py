@@ -1,0 +1,84 @@
+"""Demo-side post-processing on the device.
+
+Mirrors what demo/demo_face.py:180-231 and demo/demo_pose.py:186-242 do around `model.forward()`:
+the generated frame is re-normalised to the first source image's per-channel statistics, `sample_img`
+turns it into an RGB byte image, and PIL writes the three-panel strip and the clip.  The arithmetic runs
+in two HIP kernels behind the C ABI (`tsnet_frame_stats`, `tsnet_demo_postprocess`); only the packed
+uint8 frame crosses PCIe (3 bytes per pixel instead of the reference's 12).  PNG / GIF writing uses PIL
+only (the reference's cv2 / imageio are not needed)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+IMG_MEAN = np.array((101.84807705937696, 112.10832843463207, 111.65973036298041), dtype=np.float32)   # demo_face.py:27
+
+
+def _stream_of(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+
+class DemoPostprocessor:
+    """ref_img: (1,3,H,W) or (3,H,W) float32 -- the first source image as the demo feeds it (mean-subtracted, 0..255
+    scale).  Calling the object on generated frames (B,3,H,W) returns (B,H,W,3) uint8 RGB on the same device."""
+
+    def __init__(self, ref_img: torch.Tensor, lib=None):
+        self.lib = lib if lib is not None else _lib.load()
+        ref = ref_img.reshape(1, 3, -1).contiguous().float()
+        self.ref_mean = torch.empty(3, dtype=torch.float32, device=ref.device)
+        self.ref_std = torch.empty(3, dtype=torch.float32, device=ref.device)
+        rc = self.lib.tsnet_frame_stats(ref.data_ptr(), 1, 3, ref.shape[2], 255.0, self.ref_mean.data_ptr(),
+                                        self.ref_std.data_ptr(), _stream_of(ref))
+        self._check(rc, "tsnet_frame_stats")
+        # IMG_MEAN / 255 in float32, as `torch.from_numpy(IMG_MEAN).cuda() / 255` (demo_face.py:98)
+        self._img_mean = (C.c_float * 3)(*[float(v) for v in (torch.from_numpy(IMG_MEAN) / 255).tolist()])
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.tsnet_op_last_error().decode()}")
+
+    def __call__(self, rec: torch.Tensor) -> torch.Tensor:
+        if rec.dim() != 4 or rec.shape[1] != 3 or rec.dtype != torch.float32:
+            raise ValueError("expected generated frames of shape (B,3,H,W), float32")
+        if rec.device != self.ref_mean.device:
+            raise ValueError("frames and reference image must be on the same device")
+        rec = rec.contiguous()
+        B, _, H, W = rec.shape
+        gm = torch.empty(B * 3, dtype=torch.float32, device=rec.device)
+        gs = torch.empty(B * 3, dtype=torch.float32, device=rec.device)
+        out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=rec.device)
+        st = _stream_of(rec)
+        self._check(self.lib.tsnet_frame_stats(rec.data_ptr(), B, 3, H * W, 1.0, gm.data_ptr(), gs.data_ptr(), st), "tsnet_frame_stats")
+        self._check(self.lib.tsnet_demo_postprocess(rec.data_ptr(), B, H, W, gm.data_ptr(), gs.data_ptr(), self.ref_mean.data_ptr(),
+                                                    self.ref_std.data_ptr(), self._img_mean, out.data_ptr(), st), "tsnet_demo_postprocess")
+        return out
+
+
+def input_to_rgb(img: torch.Tensor) -> np.ndarray:
+    """A mean-subtracted BGR input image (3,H,W) as the uint8 RGB panel of the strip (demo_face.py:201-213)."""
+    a = img.detach().cpu().numpy().copy().transpose(1, 2, 0)
+    a = a + IMG_MEAN
+    return np.ascontiguousarray(a[:, :, ::-1]).astype("uint8")
+
+
+def save_strip(src_rgb: np.ndarray, tar_rgb: np.ndarray, rec_rgb: np.ndarray, path: str) -> np.ndarray:
+    """The source | driving | generated strip of demo_face.py:215-231; returns the strip as an array."""
+    from PIL import Image
+    h, w = rec_rgb.shape[:2]
+    strip = Image.new("RGB", (w * 3, h))
+    for i, a in enumerate((src_rgb, tar_rgb, rec_rgb)):
+        strip.paste(Image.fromarray(np.ascontiguousarray(a), "RGB"), (w * i, 0))
+    strip.save(path)
+    return np.asarray(strip)
+
+
+def save_gif(frames: Sequence[np.ndarray], path: str, duration_ms: int = 100):
+    """imageio.mimsave(video_pth, new_im_list) of demo_face.py:234-235, with PIL."""
+    from PIL import Image
+    ims = [Image.fromarray(np.ascontiguousarray(f), "RGB") for f in frames]
+    ims[0].save(path, save_all=True, append_images=ims[1:], duration=duration_ms, loop=0)
