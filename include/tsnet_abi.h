@@ -102,6 +102,14 @@ int tsnet_set_sources(tsnet_handle h, const float* const* src_img, const float* 
 int tsnet_forward_target(tsnet_handle h, const float* tar_lbl, const float* tar_bbox,
                          float* out_rgb, float* out_flow, int B, void* stream);
 
+/* Training-mode extras of the forward (model/TSNet.py:327-331, 372-390, 402-405), computed
+ * from the flows and features the LAST tsnet_forward / tsnet_forward_target left in the engine -- call it right after that
+ * forward, same B, same source images.  src_img: n_source x (B,3,H,W) raw (the /255 of set_train_input is applied inside);
+ * tar_img (B,3,H,W) raw.  warp_src_img (n_source,B,3,H,W): every source image warped patch-wise by its flow and
+ * re-normalised to the target image's statistics (warp_src_img_list); losses: 2 device floats {loss_warp, loss_align}. */
+int tsnet_train_extras(tsnet_handle h, const float* const* src_img, const float* tar_img, int B,
+                       float* warp_src_img, float* losses, void* stream);
+
 /* Device copies of the stage tensors of the last forward, for stage-wise parity tests
  * (NHWC fp32).  name: "src_fea" (K*B,h,w,c; n = i*B+b), "tar_fea" (B,h,w,c), "pg", "sg" (B,h,w,c),
  * "dec_map" (B,h,w,c), "dec_up<i>" (B, h<<(i+1), w<<(i+1), c>>(i+1)): RAW output of the i-th decoder

@@ -118,6 +118,42 @@ def run_case(ref_face, ref_pose, name, cfg, B, H, W, wseed, iseed, mask_mode="be
     return meta
 
 
+def run_train_case(ref_face, ref_pose, name, cfg, B, wseed, iseed):
+    """Training-mode forward extras: the reference model is built in test mode (no
+    discriminators / VGG), then driven through `set_train_input` + `forward` with `is_train` switched on --
+    exactly the extra branches TSNet.py:327-331, 372-390, 402-405.  256x256 only (F.fold(.., 256, ..), :379)."""
+    from oracle import tsnet_oracle as O
+    H = W = 256
+    sd = O.synth_state_dict(cfg, seed=wseed)
+    src_img, src_lbl, src_bbox, tar_lbl, tar_bbox = O.synth_inputs(cfg, B, H, W, seed=iseed, mask_mode="box")
+    tar_img = O.synth_inputs(cfg, B, H, W, seed=iseed + 1000, mask_mode="box")[0][0]      # another image tensor as the target frame
+    m = build_reference_model(ref_face, ref_pose, cfg, sd)
+    m.is_train = True
+    m.set_train_input([x.clone() for x in src_img], src_lbl, src_bbox, tar_img.clone(), tar_lbl, tar_bbox)
+    with torch.no_grad():
+        m.forward()
+    warp = [t.detach().clone() for t in m.warp_src_img_list]
+    lw, la = float(m.loss_warp), float(m.loss_align)
+    got = O.tsnet_forward(sd, cfg, src_img, src_lbl, src_bbox, tar_lbl, tar_bbox, tar_img=tar_img)
+    tr = got["train"]
+    d_warp = max((a - b).abs().max().item() for a, b in zip(tr["warp_src_img_list"], warp))
+    d_lw, d_la = abs(float(tr["loss_warp"]) - lw), abs(float(tr["loss_align"]) - la)
+    d_rec = (got["rec_tar_img"] - m.rec_tar_img).abs().max().item()
+    print(f"[{name}] oracle vs reference: max|d warp|={d_warp:.3e} d loss_warp={d_lw:.3e} d loss_align={d_la:.3e} max|d rec|={d_rec:.3e}")
+    assert d_warp <= 1e-6 and d_lw <= 1e-6 and d_la <= 1e-6 and d_rec <= 1e-6, "oracle restatement diverges from the reference"
+    meta = dict(name=name, B=B, H=H, W=W, wseed=wseed, iseed=iseed, mask_mode="box", bias_std=0.0, threads=THREADS,
+                torch=torch.__version__, loss_warp=lw, loss_align=la,
+                cfg=dict(label_nc=cfg.label_nc, n_blocks=cfg.n_blocks, n_downsampling=cfg.n_downsampling,
+                         n_source=cfg.n_source, pose=cfg.pose, use_mask=cfg.use_mask),
+                oracle_vs_ref=dict(warp=d_warp, loss_warp=d_lw, loss_align=d_la, rec=d_rec))
+    arrays = {}
+    for i, t in enumerate(warp):
+        arrays[f"warp{i}_crop"] = t[:, :, 96:160, 96:160].numpy()
+        arrays[f"warp{i}_rowsum64"] = t.double().sum(dim=3).numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), meta=json.dumps(meta), **arrays)
+    return meta
+
+
 def capture_modules(ref_face):
     """G1: standalone small Encoder / Decoder / FuseNet / ResnetBlock instances
     (they construct without init_net)."""
@@ -167,11 +203,21 @@ def capture_modules(ref_face):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only-train", action="store_true", help="(re)capture only the training-mode extras golden and merge it into the manifest")
     args = ap.parse_args()
     torch.set_num_threads(THREADS)
     os.makedirs(GOLD, exist_ok=True)
     ref_face, ref_pose = import_reference()
     from oracle.tsnet_oracle import TSNetConfig
+
+    train_case = lambda: run_train_case(ref_face, ref_pose, "g5_train_extras_256_k2", TSNetConfig(label_nc=2, n_blocks=0, n_source=2), 1, 11, 12)
+    if args.only_train:
+        mpath = os.path.join(GOLD, "MANIFEST.json")
+        metas = [m for m in json.load(open(mpath)) if m["name"] != "g5_train_extras_256_k2"]
+        metas.append(train_case())
+        with open(mpath, "w") as f:
+            json.dump(metas, f, indent=1)
+        return
 
     capture_modules(ref_face)
     metas = []
@@ -188,6 +234,7 @@ def main():
     if not args.skip_full:
         # G4: cfg0 -- TSNet(label_nc=2, n_blocks=0, n_downsampling=3, n_source=3), B=4, 256x256
         metas.append(run_case(ref_face, ref_pose, "g4_cfg0_full", TSNetConfig(label_nc=2, n_blocks=0, n_source=3), 4, 256, 256, 0, 1, full=True))
+    metas.append(train_case())
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(metas, f, indent=1)
 

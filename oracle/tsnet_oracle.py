@@ -174,9 +174,40 @@ def pose_composite(rec: torch.Tensor, cfg: TSNetConfig) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- forward
 @torch.no_grad()
+def train_extras(src_img: List[torch.Tensor], tar_img: torch.Tensor, flows: List[torch.Tensor],
+                 pg: torch.Tensor, sg: torch.Tensor) -> dict:
+    """The forward's training-mode extras, TSNet.py:327-331, 372-390, 402-405.
+    src_img / tar_img are already divided by 255 (set_train_input, :267,279).  Per source: the image is cut into
+    down x down patches (F.unfold), the patch grid is warped with the source's flow (F.grid_sample), folded back,
+    re-normalised to the target image's per-channel mean / unbiased std, and compared with the target (10 * L1).
+    loss_align = 1 - mean cosine similarity of the propagated and the synthesised features.
+    (The reference folds to a hard-coded 256 (:379); output_size is the image size here, identical at 256.)"""
+    b, _, h, w = pg.shape
+    ref_mean = tar_img.view(b, 3, -1).mean(dim=2).view(b, 3, 1, 1)             # :329
+    ref_std = tar_img.view(b, 3, -1).std(dim=2).view(b, 3, 1, 1)               # :330
+    warp_list, loss_list = [], []
+    for i in range(len(src_img)):
+        _, _, ori_h, ori_w = src_img[i].size()                                 # :373
+        down = ori_h // h
+        src_img_down = F.unfold(src_img[i], down, stride=down)                 # :375
+        src_img_down_reshape = src_img_down.view(b, -1, h, w)
+        pg_down = F.grid_sample(src_img_down_reshape, flows[i], align_corners=False)   # :377
+        warp_src_img = F.fold(pg_down.view(b, -1, h * w), (ori_h, ori_w), down, stride=down)   # :379
+        gen_mean = warp_src_img.view(b, 3, -1).mean(dim=2).view(b, 3, 1, 1)    # :381
+        gen_std = warp_src_img.view(b, 3, -1).std(dim=2).view(b, 3, 1, 1)
+        norm_warp_src_img = (warp_src_img - gen_mean) / gen_std
+        warp_src_img = norm_warp_src_img * ref_std + ref_mean                  # :384
+        warp_list.append(warp_src_img)
+        loss_list.append(10 * F.l1_loss(warp_src_img, tar_img))                # :386
+    loss_warp = sum(loss_list)                                                 # :390
+    loss_align = 1 - (F.cosine_similarity(pg, sg, dim=1)).mean()               # :403-405
+    return {"warp_src_img_list": warp_list, "loss_warp": loss_warp, "loss_align": loss_align}
+
+
 def tsnet_forward(sd: Dict[str, torch.Tensor], cfg: TSNetConfig,
                   src_img_list: List[torch.Tensor], src_lbl_list: List[torch.Tensor], src_bbox_list: List[torch.Tensor],
-                  tar_lbl: torch.Tensor, tar_bbox: torch.Tensor, want_stages: bool = False) -> dict:
+                  tar_lbl: torch.Tensor, tar_bbox: torch.Tensor, want_stages: bool = False,
+                  tar_img: torch.Tensor = None) -> dict:
     """set_test_input + forward of the reference (TSNet.py:283-294, 309-407).
 
     Inputs exactly as the reference's callers pass them: images (B,3,H,W) *before* the
@@ -200,6 +231,8 @@ def tsnet_forward(sd: Dict[str, torch.Tensor], cfg: TSNetConfig,
     if cfg.pose and cfg.use_mask:
         rec = pose_composite(rec, cfg)                              # TSNet_pose.py:416-417
     out = {"rec_tar_img": rec, "flows": flows}
+    if tar_img is not None:                                         # set_train_input + is_train branches of forward
+        out["train"] = train_extras(src_img, tar_img / 255.0, flows, pg, sg)
     if want_stages:
         stages.update({"src_fea": src_fea, "tar_fea": tar_fea, "pg": pg, "sg": sg, "dec_fea": fea})
         out["stages"] = stages

@@ -25,7 +25,7 @@ TIMING_NAMES = ("conv", "stats", "elementwise", "flow", "warp", "pack", "upsampl
 ABI_SYMBOLS = (
     "tsnet_abi_version", "tsnet_create", "tsnet_load_weights", "tsnet_finalize", "tsnet_destroy",
     "tsnet_last_error", "tsnet_num_params", "tsnet_param_info", "tsnet_packed_weights",
-    "tsnet_forward", "tsnet_set_sources", "tsnet_forward_target", "tsnet_stage_ptr",
+    "tsnet_forward", "tsnet_set_sources", "tsnet_forward_target", "tsnet_train_extras", "tsnet_stage_ptr",
     "tsnet_forward_macs", "tsnet_timing_enable", "tsnet_timing_read",
     "tsnet_op_conv2d", "tsnet_op_conv2d_x3", "tsnet_op_instnorm_stats", "tsnet_op_norm_act", "tsnet_op_upsample2x",
     "tsnet_op_flow", "tsnet_op_warp", "tsnet_op_last_error", "tsnet_frame_stats", "tsnet_demo_postprocess", "tsnet_bench_conv", "tsnet_debug_counters", "tsnet_linspace", "tsnet_coord_table",
@@ -62,6 +62,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.tsnet_forward.argtypes = [_vp, pp, pp, pp, _vp, _vp, _vp, _vp, C.c_int, _vp]
     lib.tsnet_set_sources.argtypes = [_vp, pp, pp, pp, C.c_int, _vp]
     lib.tsnet_forward_target.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
+    lib.tsnet_train_extras.argtypes = [_vp, pp, _vp, C.c_int, _vp, _vp, _vp]
     lib.tsnet_stage_ptr.argtypes = [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_size_t)]
     lib.tsnet_forward_macs.argtypes = [_vp, C.c_int]
     lib.tsnet_forward_macs.restype = C.c_double

@@ -39,6 +39,7 @@
 #include "head_conv.hpp"
 #include "norm_elementwise.hpp"
 #include "postproc.hpp"
+#include "train_extras.hpp"
 
 using namespace tsnet;
 
@@ -716,6 +717,7 @@ struct tsnet_engine {
     std::vector<float*> U, R;
     float* ab[4][2] = {{nullptr}};
     double* part = nullptr;
+    float* train_ws = nullptr;         // workspace of tsnet_train_extras, allocated on first use
     int* fin_counter = nullptr;        // arrival counters of the in-kernel statistics finalize (x3_epilogue), all zero between launches
     int ab_rr = 0;
 
@@ -1337,7 +1339,7 @@ int tsnet_finalize(tsnet_handle h, void* stream) {
 
 void tsnet_destroy(tsnet_handle h) {
     if (!h) return;
-    (void)hipFree(h->arena3); (void)hipFree(h->fin_counter);
+    (void)hipFree(h->arena3); (void)hipFree(h->fin_counter); (void)hipFree(h->train_ws);
     (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
     delete h;
 }
@@ -1383,6 +1385,43 @@ int tsnet_forward(tsnet_handle h, const float* const* src_img, const float* cons
     int rc = tsnet_set_sources(h, src_img, src_lbl, src_bbox, B, stream);
     if (rc != TSNET_OK) return rc;
     return tsnet_forward_target(h, tar_lbl, tar_bbox, out_rgb, out_flow, B, stream);
+}
+
+int tsnet_train_extras(tsnet_handle h, const float* const* src_img, const float* tar_img, int B,
+                       float* warp_src_img, float* losses, void* stream) {
+    API_BEGIN(h)
+    check_forward_args(h, B);
+    if (h->last_B != B) throw ArgError("train_extras: call tsnet_forward with the same batch first (uses its flows and features)");
+    if (!src_img || !tar_img || !warp_src_img || !losses) throw ArgError("train_extras: null tensor");
+    const int K = h->K, H = h->cfg.height, W = h->cfg.width, hh = h->h, ww = h->w, P = h->P, C = h->C;
+    for (int s = 0; s < K; ++s) if (!src_img[s]) throw ArgError("train_extras: null source image (need n_source entries)");
+    if (H % hh || W % ww || H / hh != W / ww) throw ArgError("train_extras: image size must be a multiple of the feature size");
+    hipStream_t st = (hipStream_t)stream;
+    const int N = K * B, HW = H * W, chunks = 16, ncos = 256;
+    // workspace: gen mean/std (2*N*3) + ref mean/std (2*B*3) floats, then doubles: l1 partials (N*3*chunks) + cos partials
+    const size_t nf = (size_t)2 * h->K * h->Bmax * 3 + 2 * h->Bmax * 3, nfp = (nf + 3) / 4 * 4;
+    const size_t nd = (size_t)h->K * h->Bmax * 3 * chunks + ncos;
+    if (!h->train_ws) HIP_TRY(hipMalloc((void**)&h->train_ws, nfp * sizeof(float) + nd * sizeof(double)));
+    float* gen_mean = h->train_ws; float* gen_std = gen_mean + N * 3;
+    float* ref_mean = h->train_ws + 2 * h->K * h->Bmax * 3; float* ref_std = ref_mean + B * 3;
+    double* l1_part = reinterpret_cast<double*>(h->train_ws + nfp); double* cos_part = l1_part + (size_t)h->K * h->Bmax * 3 * chunks;
+
+    PatchWarpArgs pa{};
+    for (int s = 0; s < K; ++s) pa.src[s] = src_img[s];
+    pa.flow = h->flow; pa.out = warp_src_img; pa.K = K; pa.B = B; pa.H = H; pa.W = W; pa.h = hh; pa.w = ww; pa.down = H / hh;
+    hipLaunchKernelGGL(patch_warp_kernel, dim3(ew_grid((size_t)N * HW)), dim3(256), 0, st, pa);
+    check_launch("patch_warp");
+    hipLaunchKernelGGL(frame_stats_kernel, dim3(3, B), dim3(256), 0, st, tar_img, 3, HW, 255.0f, ref_mean, ref_std);      // TSNet.py:329-330
+    check_launch("frame_stats(tar)");
+    hipLaunchKernelGGL(frame_stats_kernel, dim3(3, N), dim3(256), 0, st, warp_src_img, 3, HW, 1.0f, gen_mean, gen_std);   // :381-382
+    check_launch("frame_stats(warp)");
+    hipLaunchKernelGGL(renorm_l1_kernel, dim3(chunks, 3, N), dim3(256), 0, st, warp_src_img, tar_img, B, HW, gen_mean, gen_std, ref_mean, ref_std, l1_part);
+    check_launch("renorm_l1");
+    hipLaunchKernelGGL(cosine_partial_kernel, dim3(ncos), dim3(256), 0, st, h->pg, h->sg, B * P, C, cos_part);
+    check_launch("cosine_partial");
+    hipLaunchKernelGGL(train_losses_kernel, dim3(1), dim3(64), 0, st, l1_part, K, B * 3 * chunks, (double)B * 3 * HW, cos_part, ncos, (double)B * P, losses);
+    check_launch("train_losses");
+    API_END(h)
 }
 
 int tsnet_stage_ptr(tsnet_handle h, const char* name, const float** dev_ptr, size_t* count) {
