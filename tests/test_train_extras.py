@@ -67,3 +67,21 @@ def test_train_extras_emulated(emu_lib):
 def test_train_extras_gpu_golden_case():
     z, meta, cfg, sd, inp, tar_img = _golden_case()
     _engine_vs_oracle(None, "cuda", cfg, sd, inp, tar_img, 256, 256, meta["B"], 2e-4)
+
+
+@pytest.mark.gpu
+def test_train_extras_through_the_model_shell():
+    """TSNet.set_train_input + forward of the reference surface (wacv23_tsnet_amd/model.py) fill warp_src_img_list,
+    loss_warp and loss_align; values against the golden captured from the reference."""
+    from wacv23_tsnet_amd.model import TSNet
+    z, meta, cfg, sd, inp, tar_img = _golden_case()
+    m = TSNet(is_train=False, label_nc=2, n_blocks=0, n_downsampling=3, n_source=2)
+    m.load_checkpoint({net: {k[len(net) + 1:]: v for k, v in sd.items() if k.startswith(net + ".")} for net in ("img_enc", "lbl_enc", "fuse_net", "dec")})
+    m = m.cuda()
+    m.set_train_input(inp[0], inp[1], inp[2], tar_img, inp[3], inp[4])
+    m.forward()
+    torch.cuda.synchronize()
+    assert abs(float(m.loss_warp) - meta["loss_warp"]) <= 1e-4 and abs(float(m.loss_align) - meta["loss_align"]) <= 1e-5
+    for i in range(2):
+        assert np.abs(m.warp_src_img_list[i][:, :, 96:160, 96:160].cpu().numpy() - z[f"warp{i}_crop"]).max() <= 2e-4
+        assert np.abs(m.warp_src_img_list[i].double().sum(dim=3).cpu().numpy() - z[f"warp{i}_rowsum64"]).max() <= 5e-2

@@ -138,6 +138,9 @@ class TSNet(nn.Module):
         self.prev_tar_img = self.prev_tar_lbl = self.prev_tar_bbox = None
         self.rec_tar_img = None
         self.warp_grid2d_list = None
+        self.tar_img = None
+        self.warp_src_img_list = None
+        self.loss_warp = self.loss_align = 0.0
         self._engine: Optional[TSNetEngine] = None
         self._engine_key = None
 
@@ -157,6 +160,16 @@ class TSNet(nn.Module):
         if prev_tar_img is not None:
             self.prev_tar_img, self.prev_tar_lbl, self.prev_tar_bbox = prev_tar_img, prev_tar_lbl, prev_tar_bbox
 
+    def set_train_input(self, src_img_list, src_lbl_list, src_bbox_list, tar_img, tar_lbl, tar_bbox, use_prev=None):
+        """TSNet.set_train_input (TSNet.py:266-281): as set_test_input plus the ground-truth target frame.  forward()
+        then also fills warp_src_img_list, loss_warp and loss_align -- the training-mode outputs of the FORWARD
+        (TSNet.py:327-331, 372-390, 402-405).  The GAN / VGG losses and the backward pass are not part of this build;
+        use_prev (sources that are already in [0,1]) is not supported."""
+        if use_prev is not None:
+            raise NotImplementedError("use_prev: previously generated frames as sources are a training-loop feature")
+        self.set_test_input(src_img_list, src_lbl_list, src_bbox_list, tar_lbl, tar_bbox)
+        self.tar_img = tar_img.to(self._device(), dtype=torch.float32, non_blocking=True)
+
     def set_source_num(self, n_source):
         """TSNet.set_source_num (TSNet.py:296)."""
         self.n_source = n_source
@@ -173,6 +186,8 @@ class TSNet(nn.Module):
         self.rec_tar_img = rec
         if self.return_flow:
             self.warp_grid2d_list = flows
+        if self.tar_img is not None:           # set_train_input was used: the forward's training-mode outputs
+            self.warp_src_img_list, self.loss_warp, self.loss_align = eng.train_extras(self.src_img_list[:K], self.tar_img)
 
     # ------------------------------------------------------------------ engine management
     def _device(self):
