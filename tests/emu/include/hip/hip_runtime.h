@@ -109,6 +109,12 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }   // one queue: launches run in issue order
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

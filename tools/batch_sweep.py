@@ -1,0 +1,24 @@
+"""GPU box: frames/s of the full forward at other per-GPU batch sizes (the headline metric is quoted at B=4)."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import tsnet_oracle as O
+from wacv23_tsnet_amd.engine import TSNetEngine
+H = W = 256
+cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_downsampling=3, n_source=3)
+sd = O.synth_state_dict(cfg, seed=0)
+out = {}
+for B in (1, 2, 4, 8, 16, 32):
+    eng = TSNetEngine(label_nc=2, n_blocks=0, n_downsampling=3, n_source=3, height=H, width=W, max_batch=B)
+    eng.load_state_dict(sd); eng.finalize("cuda")
+    inp = O.synth_inputs(cfg, B, H, W, seed=1)
+    si, sl, sb, tl, tb = [[t.cuda() for t in x] if isinstance(x, list) else x.cuda() for x in inp]
+    for _ in range(3): eng.forward(si, sl, sb, tl, tb)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = max(3, 40 // B)
+    for _ in range(n): eng.forward(si, sl, sb, tl, tb)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    out[B] = {"ms": round(dt * 1e3, 3), "frames_per_s": round(B / dt, 1)}
+    eng.close(); del eng
+    torch.cuda.empty_cache()
+print(json.dumps(out))

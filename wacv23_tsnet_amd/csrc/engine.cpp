@@ -103,6 +103,7 @@ struct Timing {
 struct Ctx {            // what a launch helper needs
     hipStream_t stream = nullptr;
     Timing* timing = nullptr;
+    int lane = 0;       // 0 = the caller's stream; 1 = the engine's side stream (own statistics scratch, see tsnet_forward)
 };
 
 struct TimeScope {
@@ -716,6 +717,13 @@ struct tsnet_engine {
     float *D = nullptr, *DY1 = nullptr, *DY2 = nullptr;
     std::vector<float*> U, R;
     float* ab[4][2] = {{nullptr}};
+    float* ab_side[2][2] = {{nullptr}};   // (alpha, beta) buffers of the side lane (target-label encoder)
+    int ab_side_rr = 0;
+    double* part_side = nullptr;       // statistics partials / arrival counters of the side lane
+    int* fin_counter_side = nullptr;
+    hipStream_t side_stream = nullptr; // target-label chain of a full forward runs here, concurrently with the source encoder
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;               // TSNET_OVERLAP=0 turns the side stream off
     double* part = nullptr;
     float* train_ws = nullptr;         // workspace of tsnet_train_extras, allocated on first use
     int* fin_counter = nullptr;        // arrival counters of the in-kernel statistics finalize (x3_epilogue), all zero between launches
@@ -751,16 +759,17 @@ struct tsnet_engine {
     void resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float* y1, float* y2, int N, int hh, int ww);
     void forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
     void conv_stats_x3(Ctx& ctx, const ConvLayer& L, X3Call& c, int N, int HW, float* alpha, float* beta) {
-        c.stat_part = part;
-        c.fin_alpha = alpha; c.fin_beta = beta; c.fin_counter = fin_counter;
+        double* pt = ctx.lane ? part_side : part;
+        c.stat_part = pt;
+        c.fin_alpha = alpha; c.fin_beta = beta; c.fin_counter = ctx.lane ? fin_counter_side : fin_counter;
         run_conv_x3(ctx, L, c);
         if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
         if (c.stat_S > 0) {
             TimeScope ts(ctx, TSNET_T_STATS);
-            hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + 63) / 64, N), dim3(256), 0, ctx.stream, part, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
+            hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + 63) / 64, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
             check_launch("in_finalize2");
         } else {
-            run_stats(ctx, c.y, N, HW, L.cout, part, alpha, beta);
+            run_stats(ctx, c.y, N, HW, L.cout, pt, alpha, beta);
         }
     }
     void resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww);
@@ -776,6 +785,12 @@ struct tsnet_engine {
         run_norm_act(ctx, raw, alpha, beta, 1, nullptr, N, HW, Cc, raw);
     }
     std::pair<float*, float*> next_ab() { auto r = std::make_pair(ab[ab_rr][0], ab[ab_rr][1]); ab_rr = (ab_rr + 1) & 3; return r; }
+    std::pair<float*, float*> next_ab(const Ctx& ctx) {
+        if (!ctx.lane) return next_ab();
+        auto r = std::make_pair(ab_side[ab_side_rr][0], ab_side[ab_side_rr][1]); ab_side_rr ^= 1; return r;
+    }
+    void target_chain_x3(Ctx& ctx, const float* tar_lbl, int B);
+    void forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
 };
 
 void tsnet_engine::build_layers() {
@@ -952,6 +967,19 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     part = reinterpret_cast<double*>(part_f);
     HIP_TRY(hipMalloc((void**)&fin_counter, 65536 * sizeof(int)));
     HIP_TRY(hipMemsetAsync(fin_counter, 0, 65536 * sizeof(int), s));
+    if (x3) {      // side lane (tsnet_forward): own statistics scratch, counters, (alpha, beta) pairs, stream and events
+        const size_t part_bytes = (size_t)2 * std::max((size_t)NB * 64 * 2 * C * 2, (size_t)NB * H * W * cfg.ngf / 32 + 1024) * sizeof(float);
+        HIP_TRY(hipMalloc((void**)&part_side, part_bytes));
+        HIP_TRY(hipMalloc((void**)&fin_counter_side, 65536 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(fin_counter_side, 0, 65536 * sizeof(int), s));
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) HIP_TRY(hipMalloc((void**)&ab_side[i][j], (size_t)NB * 2 * C * sizeof(float)));
+        HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        const char* e = getenv("TSNET_OVERLAP");
+        overlap = !(e && atoi(e) == 0);
+    }
 
     if (x3) {    // ---- bf16x3 planes of every conv input (3 planes x 2 bytes per element)
         std::vector<std::pair<unsigned short**, size_t>> rq;
@@ -994,13 +1022,13 @@ void tsnet_engine::encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned
                              std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks) {
     int hh = cfg.height, ww = cfg.width;
     X3Call a; a.x3 = xin3; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
-    auto st = next_ab();
+    auto st = next_ab(ctx);
     conv_stats_x3(ctx, L[0], a, N, hh * ww, st.first, st.second);
     for (int l = 1; l <= cfg.n_downsampling; ++l) {
         run_norm_act(ctx, raw[l - 1], st.first, st.second, 1, nullptr, N, hh * ww, L[l].cin_pad, nullptr, raw3[l - 1]);
         X3Call d; d.x3 = raw3[l - 1]; d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
         hh /= 2; ww /= 2;
-        st = next_ab();
+        st = next_ab(ctx);
         conv_stats_x3(ctx, L[l], d, N, hh * ww, st.first, st.second);
     }
     run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea, out_fea3);
@@ -1009,7 +1037,14 @@ void tsnet_engine::encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned
 }
 
 void tsnet_engine::forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
-    const int H = cfg.height, W = cfg.width, NB = K * B;
+    target_chain_x3(ctx, tar_lbl, B);
+    forward_rest_x3(ctx, tar_bbox, out_rgb, out_flow, B);
+}
+
+// Everything that depends on the driving frame only: label encoder, its L2-normalised features and the target half of
+// FuseNet's first convolution.  Independent of the source encoder, so a full forward runs it on the side stream.
+void tsnet_engine::target_chain_x3(Ctx& ctx, const float* tar_lbl, int B) {
+    const int H = cfg.height, W = cfg.width;
     {
         TimeScope ts(ctx, TSNET_T_PACK);
         PackArgs p{};
@@ -1020,9 +1055,14 @@ void tsnet_engine::forward_target_x3(Ctx& ctx, const float* tar_lbl, const float
         check_launch("pack_input(lbl)");
     }
     encode_x3(ctx, lbl_enc, x_lbl3, B, raw_lbl, raw3_lbl, tar_fea, tar3, 0);
-
-    // ---- transformation branch (fp32 features; unchanged kernels)
     run_l2norm(ctx, tar_fea, that, B * P, C);
+    X3Call t; t.x3 = tar3; t.N = B; t.H = h; t.W = w; t.y = FT;                        // shared target half of fuse conv1
+    run_conv_x3(ctx, fuse_c1_tar, t);
+}
+
+void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
+    const int H = cfg.height, W = cfg.width, NB = K * B;
+    // ---- transformation branch (fp32 features; unchanged kernels)
     FlowArgs fa{};
     fa.that = that; fa.shat = shat; fa.tar_bbox = tar_bbox;
     for (int s = 0; s < K; ++s) fa.src_bbox[s] = bbox_copy + (size_t)s * Bmax * H * W;
@@ -1035,8 +1075,6 @@ void tsnet_engine::forward_target_x3(Ctx& ctx, const float* tar_lbl, const float
 
     // ---- synthesis branch
     {
-        X3Call t; t.x3 = tar3; t.N = B; t.H = h; t.W = w; t.y = FT;                    // shared target half of fuse conv1
-        run_conv_x3(ctx, fuse_c1_tar, t);
         X3Call a; a.x3 = X3; a.N = NB; a.H = h; a.W = w; a.y = F1; a.addend = FT; a.add_nmod = B;
         auto s1 = next_ab();
         conv_stats_x3(ctx, fuse_c1_src, a, NB, P, s1.first, s1.second);
@@ -1340,6 +1378,11 @@ int tsnet_finalize(tsnet_handle h, void* stream) {
 void tsnet_destroy(tsnet_handle h) {
     if (!h) return;
     (void)hipFree(h->arena3); (void)hipFree(h->fin_counter); (void)hipFree(h->train_ws);
+    (void)hipFree(h->part_side); (void)hipFree(h->fin_counter_side);
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) (void)hipFree(h->ab_side[i][j]);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
     delete h;
 }
@@ -1382,6 +1425,26 @@ int tsnet_forward_target(tsnet_handle h, const float* tar_lbl, const float* tar_
 
 int tsnet_forward(tsnet_handle h, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox,
                   const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B, void* stream) {
+    if (h && h->finalized && h->x3 && h->overlap && h->side_stream && !h->timing.on && tar_lbl && tar_bbox && out_rgb) {
+        // Full forward on two lanes: the driving-frame chain (label encoder, L2 norm, target half of FuseNet conv1 --
+        // small launches that leave most CUs idle at B = 4) runs on the engine's side stream while the caller's stream
+        // encodes the sources; they join before the flow kernel.  Same kernels, same arithmetic: the result is
+        // bit-identical to tsnet_set_sources + tsnet_forward_target (tested).  Per-kernel timing runs them in sequence.
+        API_BEGIN(h)
+        check_forward_args(h, B);
+        hipStream_t main = (hipStream_t)stream;
+        HIP_TRY(hipEventRecord(h->ev_fork, main));
+        HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        Ctx cs; cs.stream = h->side_stream; cs.lane = 1;
+        h->target_chain_x3(cs, tar_lbl, B);
+        HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
+        const int rc = tsnet_set_sources(h, src_img, src_lbl, src_bbox, B, stream);
+        HIP_TRY(hipStreamWaitEvent(main, h->ev_join, 0));        // also on the error path: the side lane must not outlive the call
+        if (rc != TSNET_OK) return rc;
+        Ctx ctx; ctx.stream = main;
+        h->forward_rest_x3(ctx, tar_bbox, out_rgb, out_flow, B);
+        API_END(h)
+    }
     int rc = tsnet_set_sources(h, src_img, src_lbl, src_bbox, B, stream);
     if (rc != TSNET_OK) return rc;
     return tsnet_forward_target(h, tar_lbl, tar_bbox, out_rgb, out_flow, B, stream);
