@@ -722,7 +722,7 @@ struct tsnet_engine {
     double* part_side = nullptr;       // statistics partials / arrival counters of the side lane
     int* fin_counter_side = nullptr;
     hipStream_t side_stream = nullptr; // target-label chain of a full forward runs here, concurrently with the source encoder
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
     bool overlap = true;               // TSNET_OVERLAP=0 turns the side stream off
     double* part = nullptr;
     float* train_ws = nullptr;         // workspace of tsnet_train_extras, allocated on first use
@@ -977,6 +977,8 @@ void tsnet_engine::alloc_all(hipStream_t s) {
         HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
         const char* e = getenv("TSNET_OVERLAP");
         overlap = !(e && atoi(e) == 0);
     }
@@ -1062,16 +1064,26 @@ void tsnet_engine::target_chain_x3(Ctx& ctx, const float* tar_lbl, int B) {
 
 void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
     const int H = cfg.height, W = cfg.width, NB = K * B;
-    // ---- transformation branch (fp32 features; unchanged kernels)
+    // ---- transformation branch (fp32 features; unchanged kernels).  Its result (pg) is first needed by the decoder, and
+    // its kernels are latency-bound (384 workgroups): with the side stream available it runs there, concurrently with the
+    // MFMA-bound synthesis branch below, and joins before dec_map.
+    const bool fork = overlap && side_stream && !ctx.timing && ctx.lane == 0;
+    Ctx cside; cside.stream = side_stream; cside.lane = 1;
+    Ctx& cx = fork ? cside : ctx;
+    if (fork) {
+        HIP_TRY(hipEventRecord(ev_fork2, ctx.stream));
+        HIP_TRY(hipStreamWaitEvent(side_stream, ev_fork2, 0));
+    }
     FlowArgs fa{};
     fa.that = that; fa.shat = shat; fa.tar_bbox = tar_bbox;
     for (int s = 0; s < K; ++s) fa.src_bbox[s] = bbox_copy + (size_t)s * Bmax * H * W;
     fa.gx = d_gx; fa.gy = d_gy; fa.flow = flow;
     fa.B = B; fa.P = P; fa.C = C; fa.h = h; fa.w = w; fa.H = H; fa.W = W; fa.sy = H / h; fa.sx = W / w;
-    run_flow(ctx, fa, NB);
+    run_flow(cx, fa, NB);
     if (out_flow)
-        HIP_TRY(hipMemcpyAsync(out_flow, flow, (size_t)NB * P * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
-    run_warp(ctx, X, flow, pg, B, K, h, w, C, pg3);
+        HIP_TRY(hipMemcpyAsync(out_flow, flow, (size_t)NB * P * 2 * sizeof(float), hipMemcpyDeviceToDevice, cx.stream));
+    run_warp(cx, X, flow, pg, B, K, h, w, C, pg3);
+    if (fork) HIP_TRY(hipEventRecord(ev_join2, side_stream));
 
     // ---- synthesis branch
     {
@@ -1093,6 +1105,7 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
     }
 
     // ---- decoder
+    if (fork) HIP_TRY(hipStreamWaitEvent(ctx.stream, ev_join2, 0));
     {
         X3Call a; a.x3 = pg3; a.x23 = sg3; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
         a.y3 = cfg.n_blocks > 0 ? D3 : nullptr;
@@ -1383,6 +1396,8 @@ void tsnet_destroy(tsnet_handle h) {
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
+    if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
     delete h;
 }
