@@ -155,6 +155,13 @@ int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin,
  * device first; tile = -1 (heuristic) or an index into the kernel's tile table.  No input transform. */
 int tsnet_op_conv2d_x3(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                        int ksize, int stride, int pad, int pad_mode, int tile, float* y, void* stream);
+/* The 3x3 / stride-1 / pad-1 convolution on the fp16x2 patch kernel (conv_h2.hpp): x stays fp32 and, when in_alpha / in_beta
+ * (N*Cin each) are given, x*alpha+beta (+ReLU) -- the producer's nn.InstanceNorm2d + nn.ReLU (TSNet.py:27-33,40-46) -- is applied
+ * while the input patch is staged.  bound = an upper bound of |operand| after that transform (it fixes the power-of-two operand
+ * scale); nprod = 3 (lo*hi, hi*lo, hi*hi) or 4 (+ lo*lo); tile_n = 0 (heuristic), 64 or 128. */
+int tsnet_op_conv2d_h2(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int pad_mode,
+                       const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, int tile_n,
+                       float* y, void* stream);
 int tsnet_op_instnorm_stats(const float* x, int N, int HW, int C, float* alpha, float* beta, void* stream);
 int tsnet_op_norm_act(const float* x, const float* alpha, const float* beta, int relu, const float* resid,
                       int N, int HW, int C, float* y, void* stream);

@@ -1,0 +1,114 @@
+"""Seed sweep of full-size goldens at BASELINE.json configs[1] -- authoring container only (needs /root/reference).
+
+Why: the 1e-3 parity budget of the north star is tight (the network amplifies fp32 rounding ~6000x), and
+one (weight seed, input seed) pair says little about the margin.  For every pair below this script runs the REAL
+reference twice -- in fp32 as shipped, and with the whole model and its inputs cast to fp64 (`m.double()`; the only shim
+on top of capture_goldens.py's is that `Tensor.float()` keeps fp64 during that run, because TSNet.get_grid / coord_conv
+call `.float()` on their constant tables, TSNet.py:306,110-120) -- and stores *data only*:
+
+    rec32_crop / rec64_crop      (B,3,32,32) centre crops of rec_tar_img, plus two border crops (reflection padding)
+    rec32_sub4 / rec64_sub4      (B,3,64,64) every fourth row and column of the whole frame
+    rec32_rowsum / rec64_rowsum  (B,3,H) fp64 checksums of every output row
+    flow32_i                     (B,32,32,2) the K flow fields of the fp32 run
+    meta                         seeds, max|ref32 - ref64| over the WHOLE image (the reference's own fp32 noise on this
+                                 pair), and the oracle-vs-reference deltas of both runs (the pin of oracle/tsnet_oracle.py
+                                 in fp32 and in fp64 on this pair)
+
+The GPU tier (tests/test_gpu_seed_sweep.py) regenerates weights and inputs from the PRNG, re-runs the oracle in fp32 and
+fp64 on the box, checks those runs against the crops and checksums stored here, and then gates the HIP path over the whole
+image:  |GPU - ref32| <= 1e-3  and  |GPU - ref64| <= |ref32 - ref64| + 1e-4.
+
+    python oracle/capture_seed_sweep.py            # ~25 s per pair on 8 threads
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import capture_goldens as CG  # noqa: E402
+
+# (weight seed, input seed, mask mode): quick_start1.py's Bernoulli masks and the box masks real clips have
+PAIRS = [(100, 200, "bernoulli"), (101, 201, "bernoulli"), (102, 202, "box"), (103, 203, "bernoulli"),
+         (104, 204, "box"), (105, 205, "bernoulli"), (106, 206, "soft"), (107, 207, "bernoulli")]
+B, H, W = 4, 256, 256
+CROPS = {"c": (slice(96, 128), slice(96, 128)), "tl": (slice(0, 16), slice(0, 16)), "br": (slice(240, 256), slice(240, 256))}
+
+
+def to64(x):
+    return [t.double() for t in x] if isinstance(x, list) else x.double()
+
+
+def main():
+    torch.set_num_threads(CG.THREADS)
+    ref_face, ref_pose = CG.import_reference()
+    from oracle import tsnet_oracle as O
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=3)
+    metas = []
+    for wseed, iseed, mask in PAIRS:
+        t0 = time.time()
+        name = f"g6_cfg1_w{wseed}_i{iseed}"
+        sd = O.synth_state_dict(cfg, seed=wseed)
+        inp = O.synth_inputs(cfg, B, H, W, seed=iseed, mask_mode=mask)
+        m = CG.build_reference_model(ref_face, ref_pose, cfg, sd)
+        m.set_test_input([x.clone() for x in inp[0]], inp[1], inp[2], inp[3], inp[4])
+        with torch.no_grad():
+            m.forward()
+        rec32 = m.rec_tar_img.detach().clone()
+        flows32 = [f.detach().clone() for f in m.warp_grid2d_list]
+        # the same model in fp64 (weights are the fp32 values, exactly representable)
+        m.double()
+        keep_float = torch.Tensor.float
+        torch.Tensor.float = lambda self, *a, **k: self.double()
+        try:
+            i64 = [to64(x) for x in inp]
+            m.set_test_input([x.clone() for x in i64[0]], i64[1], i64[2], i64[3], i64[4])
+            with torch.no_grad():
+                m.forward()
+        finally:
+            torch.Tensor.float = keep_float
+        rec64 = m.rec_tar_img.detach().clone()
+        assert rec64.dtype == torch.float64
+        # pin the oracle on this pair, in both precisions
+        o32 = O.tsnet_forward(sd, cfg, *inp)
+        o64 = O.tsnet_forward({k: v.double() for k, v in sd.items()}, cfg, *i64)
+        d32 = (o32["rec_tar_img"] - rec32).abs().max().item()
+        d64 = (o64["rec_tar_img"] - rec64).abs().max().item()
+        dfl = max((a - b).abs().max().item() for a, b in zip(o32["flows"], flows32))
+        noise = (rec32.double() - rec64).abs()
+        print(f"[{name}] oracle vs ref: fp32 {d32:.3e} flow {dfl:.3e} fp64 {d64:.3e} | ref32 vs ref64 max {noise.max().item():.3e} "
+              f"mean {noise.mean().item():.3e} | {time.time() - t0:.1f} s", flush=True)
+        assert d32 <= 1e-6 and dfl <= 1e-6 and d64 <= 1e-9, "oracle restatement diverges from the reference"
+        arrays = {}
+        for tag, (ys, xs) in CROPS.items():
+            arrays[f"rec32_{tag}"] = rec32[:, :, ys, xs].numpy()
+            arrays[f"rec64_{tag}"] = rec64[:, :, ys, xs].numpy()
+        arrays["rec32_sub4"] = rec32[:, :, ::4, ::4].numpy()          # a 64 x 64 lattice over the whole frame
+        arrays["rec64_sub4"] = rec64[:, :, ::4, ::4].numpy()
+        arrays["rec32_rowsum"] = rec32.double().sum(dim=3).numpy()
+        arrays["rec64_rowsum"] = rec64.sum(dim=3).numpy()
+        for i, f in enumerate(flows32):
+            arrays[f"flow32_{i}"] = f.numpy()
+        meta = dict(name=name, B=B, H=H, W=W, wseed=wseed, iseed=iseed, mask_mode=mask, bias_std=0.0, threads=CG.THREADS,
+                    torch=torch.__version__,
+                    cfg=dict(label_nc=2, n_blocks=0, n_downsampling=3, n_source=3, pose=False, use_mask=True),
+                    ref32_vs_ref64=dict(max=noise.max().item(), mean=noise.mean().item()),
+                    oracle_vs_ref=dict(rec=d32, flow=dfl, rec64=d64),
+                    rec64_mean=rec64.mean().item(), rec64_absmax=rec64.abs().max().item())
+        np.savez_compressed(os.path.join(CG.GOLD, name + ".npz"), meta=json.dumps(meta), **arrays)
+        metas.append(meta)
+    mpath = os.path.join(CG.GOLD, "MANIFEST.json")
+    old = [x for x in json.load(open(mpath)) if not x["name"].startswith("g6_cfg1_")]
+    with open(mpath, "w") as f:
+        json.dump(old + metas, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -41,7 +41,7 @@ def build_emu_lib() -> str:
             break
     if cxx is None:
         pytest.skip("no clang++ available for the emulation build")
-    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-psabi",
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-psabi", "-mf16c",
            "-I" + os.path.join(ROOT, "tests", "emu", "include")] + src + ["-o", out]
     subprocess.check_call(cmd)
     return out

@@ -133,6 +133,25 @@ f32x16_t mfma_bf16_32x32x16(const void* a16, const void* b16, f32x16_t c) {
     return d;
 }
 
+f32x16_t mfma_f16_32x32x16(const void* a16, const void* b16, f32x16_t c) {
+    // same fragment layout as the bf16 form; fp16 products are exact in fp32 (11 x 11 significand bits)
+    WaveState& w = g_waves[g_cur / 64];
+    const int lane = g_cur & 63, par = w.gen & 1;
+    memcpy(w.ha[par][lane], a16, 16);
+    memcpy(w.hb[par][lane], b16, 16);
+    wave_rendezvous(w);
+    const int j = lane & 31, hi = lane >> 5;
+    auto hf = [](unsigned short h) { _Float16 f; memcpy(&f, &h, 2); return (float)f; };
+    f32x16_t d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float t = d[r];
+        for (int k = 0; k < 16; ++k) t = fmaf(hf(w.ha[par][i + 32 * (k >> 3)][k & 7]), hf(w.hb[par][j + 32 * (k >> 3)][k & 7]), t);
+        d[r] = t;
+    }
+    return d;
+}
+
 void buf_dma16(const unsigned char* base, unsigned bytes, unsigned voff, unsigned soff, unsigned char* lds) {
     // raw-buffer LDS-DMA: range check on voffset against num_records - soffset (gfx9 raw-buffer rule);
     // destination = lane 0's LDS address + 16*lane (M0 semantics)

@@ -52,6 +52,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 f32x16_t mfma_32x32x2(float a, float b, f32x16_t c);
 void buf_dma16(const unsigned char* base, unsigned bytes, unsigned voff, unsigned soff, unsigned char* lds);
 f32x16_t mfma_bf16_32x32x16(const void* a16, const void* b16, f32x16_t c);
+f32x16_t mfma_f16_32x32x16(const void* a16, const void* b16, f32x16_t c);
 }  // namespace emu
 
 #define threadIdx (emu::g_threadIdx)
@@ -88,6 +89,8 @@ template <class T> static inline T emu_buf_load16(const tsnet_rsrc_t& r, unsigne
 #define TSNET_BUF_LOAD16(rsrc, voff, soff) emu_buf_load16<F4>((rsrc), (voff), (soff))
 // hook of conv_x3.hpp: v_mfma_f32_32x32x16_bf16 on raw 16-byte operands (8 bf16 per lane)
 #define TSNET_MFMA_BF16(a, b, c) emu::mfma_bf16_32x32x16(&(a), &(b), (c))
+// hook of conv_h2.hpp: v_mfma_f32_32x32x16_f16 on raw 16-byte operands (8 fp16 per lane)
+#define TSNET_MFMA_F16(a, b, c) emu::mfma_f16_32x32x16(&(a), &(b), (c))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 // device-scope atomics of the statistics hand-off (conv_x3.hpp x3_epilogue): workgroups run one after another here
 #define __HIP_MEMORY_SCOPE_AGENT 0

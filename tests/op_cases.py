@@ -59,6 +59,35 @@ def conv_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, norm=False,
     return (nchw(y.cpu()) - ref).abs().max().item()
 
 
+
+def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, nprod=3, tile_n=0, seed=0, scale=1.0):
+    """nn.Conv2d 3x3 / stride 1 (+ReflectionPad2d(1) or zero pad 1), optionally on relu(x*alpha+beta) -- the consumer side of
+    nn.InstanceNorm2d + nn.ReLU -- vs tsnet_op_conv2d_h2 (fp16x2 patch kernel, transform fused into the patch staging).
+    Returns max|d| relative to max|ref|."""
+    x = _rand(seed, "x", (N, Cin, H, W)) * scale
+    w = _rand(seed, "w", (Cout, Cin, 3, 3)) * (2.0 / (Cin * 9) ** 0.5)
+    b = _rand(seed, "b", (Cout,)) if bias else None
+    xin, al, be = x, None, None
+    if norm:
+        al = _rand(seed, "al", (N, Cin), 0.5, 1.5)
+        be = _rand(seed, "be", (N, Cin), -0.3, 0.3)
+        xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
+    if reflect:
+        ref = F.conv2d(F.pad(xin.double(), (1,) * 4, mode="reflect"), w.double(), None if b is None else b.double())
+    else:
+        ref = F.conv2d(xin.double(), w.double(), None if b is None else b.double(), padding=1)
+    bound = float(xin.abs().max()) * 1.0001 + 1e-30
+    xd = nhwc(x).to(dev)
+    y = torch.full((N, H, W, Cout), float("nan"), device=dev)
+    ald = al.contiguous().to(dev) if norm else None
+    bed = be.contiguous().to(dev) if norm else None
+    wd, bd = w.to(dev), (b.to(dev) if bias else None)
+    rc = lib.tsnet_op_conv2d_h2(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), _p(bd), Cout, int(reflect), _p(ald), _p(bed),
+                                1 if norm else 0, bound, nprod, tile_n, y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    return ((nchw(y.cpu()).double() - ref).abs().max() / ref.abs().max()).item()
+
 def instnorm_case(lib, dev, N, H, W, C, relu, resid, seed=0, offset=0.0):
     """InstanceNorm2d(eps=1e-5, biased var) [+ReLU] [+residual] vs stats + norm_act kernels."""
     x = _rand(seed, "x", (N, C, H, W), -2, 2) + offset

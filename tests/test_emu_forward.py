@@ -138,3 +138,38 @@ def test_bf16x3_schedule(emu_lib, monkeypatch):
     assert cnt[2] > 0 and cnt[3] == 0
     assert (rec - rec32).abs().max().item() < 2e-4
     eng32.close()
+
+
+def test_h2_schedule(emu_lib, monkeypatch):
+    """32 x 256 frames give 4 x 32 feature maps -- one patch tile of conv_h2.hpp -- so the h2 schedule engages: ResnetBlock, FuseNet and
+    the later decoder up-convolutions read fp32 and apply the producer's InstanceNorm + ReLU while staging (no norm_act pass, fp16x2
+    operands), the decoder's unbounded stream keeps the bf16x3 planes.  Must match the oracle like the bf16x3 schedule, agree with it
+    closely, and stay bit-identical between the one-shot forward and clip mode."""
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=1, n_source=1, ngf=32, enc_blocks=1, fuse_ngf=512)
+    sd = O.synth_state_dict(cfg, seed=14, bias_std=0.02)
+    sd = {k: (v * 2 if k.endswith("weight") else v) for k, v in sd.items()}
+    inp = O.synth_inputs(cfg, 1, 32, 256, seed=15, mask_mode="box")
+    ref = O.tsnet_forward(sd, cfg, *inp, want_stages=True)
+    eng = Hh.make_engine(cfg, sd, 32, 256, 1, "cpu", lib=emu_lib)
+    emu_lib.tsnet_debug_counters(None, 1)
+    rec, flows = Hh.run_engine(eng, inp, "cpu")
+    cnt = (C.c_int64 * 4)()
+    emu_lib.tsnet_debug_counters(cnt, 1)
+    # conv_h2: 2 (encoder block) + 1 (target half of fuse conv1) + 2 (fuse) + 1 (decoder block, second conv) + 1 (dec_up1) = 7
+    assert cnt[0] == 7 and cnt[3] > 0 and cnt[2] == 0 and cnt[1] == 0
+    assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
+    rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, 1, "cpu")
+    assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4
+    assert max(rep[k] for k in rep if k.startswith("dec_up")) < 2e-3
+    eng.set_sources(inp[0], inp[1], inp[2])
+    r2, _ = eng.forward_target(inp[3], inp[4])
+    assert torch.equal(rec, r2)
+    eng.close()
+    monkeypatch.setenv("TSNET_H2", "0")
+    eng3 = Hh.make_engine(cfg, sd, 32, 256, 1, "cpu", lib=emu_lib)
+    emu_lib.tsnet_debug_counters(None, 1)
+    rec3, _ = Hh.run_engine(eng3, inp, "cpu")
+    emu_lib.tsnet_debug_counters(cnt, 1)
+    assert cnt[0] == 0 and cnt[3] > 0
+    assert (rec - rec3).abs().max().item() < 2e-4
+    eng3.close()

@@ -33,6 +33,22 @@ def test_conv_ragged_m_and_no_bias(emu_lib):
     assert oc.conv_case(emu_lib, "cpu", 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL
 
 
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("reflect", [True, False])
+def test_conv_h2(emu_lib, norm, reflect):
+    """fp16x2 patch convolution (conv_h2.hpp): slab parity (1, 2 and 3 slabs), zero / reflection padding, fused IN + ReLU, 3 and 4 products"""
+    for cin in (16, 32, 48):
+        assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, cin, 64, reflect, norm=norm) < 2e-6
+    assert oc.conv_h2_case(emu_lib, "cpu", 2, 8, 32, 32, 96, reflect, norm=norm, bias=False, nprod=4) < 2e-6
+
+
+def test_conv_h2_wide_tile_and_scales(emu_lib):
+    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 64, 32, 128, True, norm=True, tile_n=128) < 2e-6
+    # operands far from 1: the power-of-two scales keep the fp16 planes in range (results relative to max|ref|)
+    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=300.0) < 2e-6
+    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=1e-4) < 2e-6
+
+
 @pytest.mark.parametrize("C,H,W", [(8, 6, 5), (64, 16, 16), (24, 9, 3), (1024, 2, 2)])
 @pytest.mark.parametrize("relu,resid", [(True, False), (False, True)])
 def test_instnorm(emu_lib, C, H, W, relu, resid):

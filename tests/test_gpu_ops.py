@@ -123,3 +123,22 @@ def test_conv_x3_big_layers(lib):
     assert oc.conv_x3_case(lib, DEV, 12, 32, 32, 512, 512, 3, 1, 1, True) < TOL
     assert oc.conv_x3_case(lib, DEV, 2, 16, 16, 1024, 1024, 3, 1, 1, True) < 1e-4
     assert oc.conv_x3_case(lib, DEV, 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL
+
+
+# ---- fp16x2 patch kernel with the producer's IN + ReLU fused into the staging (conv_h2.hpp); error relative to max|fp64 reference|
+@pytest.mark.parametrize("norm", [False, True])
+def test_conv_h2_layers(lib, norm):
+    """the shapes it runs on in the forward: ResnetBlock, FuseNet, decoder up-convolutions (3 products, 64-wide tiles)"""
+    assert oc.conv_h2_case(lib, DEV, 12, 32, 32, 512, 512, True, norm=norm) < 1e-6
+    assert oc.conv_h2_case(lib, DEV, 4, 32, 32, 1024, 1024, True, norm=norm) < 1e-6
+    assert oc.conv_h2_case(lib, DEV, 2, 128, 128, 256, 128, True, norm=norm) < 1e-6
+    assert oc.conv_h2_case(lib, DEV, 1, 256, 256, 128, 64, True, norm=norm, bias=False) < 1e-6
+
+
+def test_conv_h2_variants(lib):
+    """zero padding, odd slab counts, 128-wide tiles, four products, operand magnitudes far from 1"""
+    assert oc.conv_h2_case(lib, DEV, 3, 8, 64, 48, 96, False, norm=True) < 1e-6
+    assert oc.conv_h2_case(lib, DEV, 4, 32, 32, 512, 256, True, norm=True, tile_n=128) < 1e-6
+    assert oc.conv_h2_case(lib, DEV, 4, 32, 32, 512, 256, True, norm=True, nprod=4) < 1e-6
+    assert oc.conv_h2_case(lib, DEV, 2, 32, 32, 256, 128, True, scale=300.0) < 1e-6
+    assert oc.conv_h2_case(lib, DEV, 2, 32, 32, 256, 128, True, scale=1e-4) < 1e-6

@@ -32,6 +32,18 @@ for (name, N, H, W, Cin, Cout, k, s, p, refl, norm) in LAYERS:
     flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
     npad = (Cout + 127) // 128 * 128 if Cout >= 128 else (Cout + 31) // 32 * 32
     res = []
+    if len(sys.argv) > 1 and sys.argv[1] == "h2":
+        # conv_h2 (fp16x2, fused IN + ReLU when norm): variant 16384 + (1: 128-wide tiles) + (4: four products); next to x3q (X14 / X15)
+        if not (k == 3 and s == 1): continue
+        hres = []
+        for v in (8192 + 14, 8192 + 15, 16384, 16384 + 1, 16384 + 4):
+            for nrm in ((0, 1) if v & 16384 else (0,)):
+                if (v & 16384) and (v & 1) and npad % 128: continue
+                ms = C.c_float()
+                rc = lib.tsnet_bench_conv(N, H, W, Cin, Cout, k, s, p, refl, nrm, v, 8, C.byref(ms), None)
+                hres.append(f"{'H' if v & 16384 else 'X'}{v & 63}{'n' if nrm else ''}:" + (f"{ms.value:.3f}ms/{flops/ms.value/1e9:.0f}TF" if rc == 0 else "ERR " + lib.tsnet_op_last_error().decode()))
+        print(f"{name:10s} M={N*Ho*Wo:7d} N={Cout:5d} K={Cin*k*k:5d} GF={flops/1e9:7.1f} | " + " ".join(hres), flush=True)
+        continue
     for v in ([4096 + t for t in (0, 1)] + [8192 + t for t in (0, 4, 7, 14, 15, 16, 17)]):
         tl = XT if v & 8192 else (DT if v & 4096 else TILES)
         if npad % tl[v & 63][1] or (tl[v & 63][1] > 32 and Cout <= tl[v & 63][1] // 2):

@@ -2,7 +2,7 @@
 legacy (conv_x3.hpp) mask bits: 1 no DMA, 2 no barrier/vmcnt, 4 no fold, 8 no ds_read, 16 no B DMAs, 32 no A DMAs, 64 contiguous A DMAs.
 patch (conv_x3p.hpp x3p) mask bits: 1 no DMA, 2 no barrier/vmcnt, 4 no fold, 8 fragments read once.
 q (conv_x3p.hpp x3q, 128x64 tiles) mask bits: 1 no patch staging, 2 no slab barrier, 4 no fold, 8 weight fragments loaded once,
-16 A fragments read once.  (bits 4 and 16 let hipcc delete or reschedule the MFMAs -- only 1, 2, 8 are meaningful.)"""
+16 A fragments read once, 32 plane 1 unused (timing proxy of a two-plane / three-product scheme).  (bits 4 and 16 let hipcc delete or reschedule the MFMAs -- only 1, 2, 8 are meaningful.)"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ from wacv23_tsnet_amd import _lib
 lib = _lib.load(); torch.zeros(1, device="cuda")
 mode = sys.argv[1] if len(sys.argv) > 1 else "legacy"
 patch = mode == "patch"
-masks = {"patch": (0, 1, 2, 4, 8, 12, 15, 0), "q": (0, 1, 2, 8, 0)}.get(mode, (0, 16, 32, 64, 1, 0))
+masks = {"patch": (0, 1, 2, 4, 8, 12, 15, 0), "q": (0, 1, 2, 8, 32, 33, 40, 41, 0)}.get(mode, (0, 16, 32, 64, 1, 0))
 tile = {"patch": 11, "q": 15}.get(mode, 0)
 for (name, N, H, W, Cin, Cout) in [("res", 12, 32, 32, 512, 512), ("res_x16", 16, 32, 32, 512, 512), ("fuse_c2", 12, 32, 32, 1024, 1024), ("dec_up1", 4, 128, 128, 256, 128)]:
     flops = 2.0 * N * H * W * Cout * Cin * 9

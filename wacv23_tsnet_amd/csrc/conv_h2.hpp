@@ -1,0 +1,311 @@
+// conv_h2.hpp -- 3x3 / stride-1 convolution on the fp16 MFMA from fp32 input, fp32-class accuracy, with the producer's
+// InstanceNorm + ReLU applied while the input patch is staged.
+//
+// Numerics (tools/probes/split_probe.hip, profiles/round2_notes.md).  An fp32 value x scaled by a power of two s is
+// stored as two fp16 numbers  hi = rne(x*s),  lo = rne(x*s - hi):  the residual of a round-to-nearest hi has at most 12
+// significant bits left and lo rounds away at most the last one, so hi + lo = x*s up to 2^-24 |x*s| (or 2^-25 absolute
+// where lo is subnormal) -- the rounding class of fp32 itself.  A product a*w is the three exact fp16 products
+//   lo*hi + hi*lo + hi*hi      (dropped: lo*lo <= 2^-24 |a||w|, random sign)
+// on v_mfma_f32_32x32x16_f16, fp32 accumulate, two accumulation levels exactly like conv_x3p.hpp's x3q tile: 3 MFMAs per
+// 16-deep k-group where the bf16x3 scheme needs 6 and the fp32 MFMA the time of 16.  The power-of-two scales (exact)
+// keep |x*s| < 65504: activations are bounded by construction -- InstanceNorm output is <= sqrt(HW-1) in magnitude,
+// the residual stream <= (blocks+1) sqrt(HW) -- and the host derives s from that bound; weights are scaled per layer
+// from their maximum.  The epilogue multiplies by 2^-(sa+sw) (exact) before bias, statistics and store.
+//
+// Data flow of a tile (128 output positions = a 4 x 32 pixel rectangle of one image, BN output channels):
+//   * per 16-channel slab the (4+2) x (32+2) input patch is fetched ONCE as fp32 (two 16-byte buffer loads per thread
+//     and round, reflection / zero padding resolved in the lane's offset), transformed in registers
+//     (x*alpha+beta, ReLU, *s, split) and written to LDS as two fp16 planes in the swizzled image of conv_x3p.hpp; the
+//     nine taps are nine shifted views (immediate offsets of the ds_read).  norm_act_kernel's separate pass over the
+//     tensor (4 B read + 6 B written per element) disappears, and the conv reads 4 B per element instead of 6;
+//   * weight fragments (packed in MFMA fragment order by pack_weights_h2_kernel) go straight into registers, two steps
+//     ahead (three register sets); A fragments one step ahead (two sets) -- with three products per step a load has
+//     only half the cover it had in x3q, so the re-use-after-last-use trick is replaced by explicit double buffering;
+//   * one __syncthreads per slab; no inline asm: every load is compiler-visible.
+// K order is slab-major (slab, tap), chains = taps 0..3 and 4..8 of a slab, folded into the running total.
+#pragma once
+#include "conv_x3p.hpp"
+
+namespace tsnet {
+
+struct H2Args {
+    const float* x;            // (N,H,W,Cin) fp32 NHWC
+    const float* in_alpha;     // null, or (N*Cin): x*alpha+beta on load (the producer's InstanceNorm statistics)
+    const float* in_beta;
+    int in_relu;
+    float in_scale;            // 2^sa
+    const unsigned short* w;   // fp16 planes [2][K/16][Npad][2 swizzled octets][8] of w * 2^sw
+    float in_unscale;          // 2^-sa
+    const float* w_unscale;    // device scalar 2^-sw (lives in the packed weight buffer, so replicas receive it with the broadcast)
+    const float* bias;
+    float* y;
+    unsigned short* y3;        // always null here (member of the shared epilogue's contract)
+    double* stat_part;
+    const float* addend; int add_nmod;
+    int N, H, W, Cin, Ho, Wo, Cout, Npad, reflect, nchunks, M;
+    int tiles_m, tiles_n;
+    float* fin_alpha; float* fin_beta; int* fin_counter; int fin_S; float fin_eps;
+};
+
+#ifndef TSNET_MFMA_F16
+typedef _Float16 tsnet_f16x8 __attribute__((ext_vector_type(8)));
+#define TSNET_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tsnet_f16x8, a), __builtin_bit_cast(tsnet_f16x8, b), c, 0, 0, 0)
+#endif
+
+// x (already scaled) -> (hi, lo) fp16 bit patterns
+__device__ __forceinline__ void split_h2(float v, unsigned& hi, unsigned& lo) {
+    const _Float16 h = (_Float16)v;                              // round to nearest even
+    const _Float16 l = (_Float16)(v - (float)h);                 // exact residual, then RNE
+    hi = (unsigned)__builtin_bit_cast(unsigned short, h);
+    lo = (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+
+// eight consecutive channels (two float4) -> one 16-byte octet per plane
+__device__ __forceinline__ void split_h2_octet(const F4& x0, const F4& x1, F4& H, F4& L) {
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { split_h2(x0.v[e], h[e], l[e]); split_h2(x1.v[e], h[4 + e], l[4 + e]); }
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hw[e] = h[2 * e] | (h[2 * e + 1] << 16); lw[e] = l[2 * e] | (l[2 * e + 1] << 16); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { H.v[e] = __builtin_bit_cast(float, hw[e]); L.v[e] = __builtin_bit_cast(float, lw[e]); }
+}
+
+// NPROD = 3: lo*hi, hi*lo, hi*hi;  NPROD = 4: lo*lo first (kept for the accuracy comparison in the op tests)
+template <int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE>
+__device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
+    constexpr int BM = kPatchRows * kPatchCols;
+    constexpr int NW = WARPS_M * WARPS_N;
+    static_assert(NW == 4, "four waves: patch blocks are dealt w, w+4");
+    static_assert(NPROD == 3 || NPROD == 4, "three or four products");
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 32, NTL = WN / 32;
+    constexpr int PC = kPatchCols + 2, PP = (kPatchRows + 2) * PC;   // 34, 204 patch pixels
+    constexpr int PBLK = (PP + 31) / 32;                             // 7 blocks of 32 pixel slots
+    constexpr int REGION = PBLK * 512;                               // one octet region: 224 slots x 16 B
+    constexpr int PLANE_P = 2 * REGION, PATCH_BYTES = 2 * PLANE_P;   // two planes x 7 KiB per stage
+    constexpr int OFF_SCRATCH = 2 * PATCH_BYTES;                     // 2 KiB sink for the wave whose second block does not exist
+    constexpr int OFF_TAB = OFF_SCRATCH + 2048;                      // (alpha*s, beta*s) table of the image: 2 x Cin floats
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = TSNET_UNIFORM(tid >> 6);
+    const int wrow = wave / WARPS_N;
+    const int wn0 = (wave % WARPS_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tcols = a.Wo / kPatchCols, tper = (a.Ho / kPatchRows) * tcols;
+    const int img = tile_m / tper, tin = tile_m - img * tper;
+    const int oy0 = (tin / tcols) * kPatchRows, ox0 = (tin % tcols) * kPatchCols;
+    const int ncc = a.Cin >> 4;
+
+    const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
+    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
+    tsnet_brsrc_t rsw[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
+
+    // ---- LDS image of a patch stage: per plane two octet REGIONS (channels 0..7 / 8..15 of the slab), each one 16-byte entry per
+    //      pixel slot.  A fragment read of lane (li, lh) is region lh, slot p0 + tap shift: 16 consecutive lanes read 256
+    //      consecutive bytes (conflict-free without a swizzle) and the tap shift is an IMMEDIATE of the ds_read -- one
+    //      address register for all 18 (row, tap) combinations.
+    // ---- staging geometry: this wave owns pixel blocks wave and wave + 4; lane -> (slot b*32 + (lane & 31), octet lane >> 5):
+    //      the 8 lanes of a ds_write_b128 group write 128 consecutive bytes.
+    const int oct = lane >> 5;
+    unsigned vP[2];
+    float vM[2];                                                     // 1, or 0 for a zero-padded / unused slot
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int pp = (wave + 4 * r) * 32 + (lane & 31);
+        const int pr = pp / PC, pc = pp - pr * PC;
+        int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
+        bool ok = pp < PP;
+        if (a.reflect) {
+            iy = iy < 0 ? -iy : iy;
+            iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+            ix = ix < 0 ? -ix : ix;
+            ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+        } else {
+            ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        }
+        const int pix = iy * a.W + ix;
+        vP[r] = ok ? (unsigned)(((img * a.H * a.W + pix) * a.Cin + oct * 8) * 4) : kOOB;
+        vM[r] = ok ? 1.f : 0.f;
+    }
+    // per-(image, channel) transform table in LDS, pre-multiplied by the operand scale (a power of two: exact, and
+    // fl(x*(al*s) + be*s) == s * fl(x*al + be)); without a producer InstanceNorm: (s, 0)
+    float* tab = reinterpret_cast<float*>(smem_raw + OFF_TAB);       // [Cin] alpha*s, then [Cin] beta*s
+    if (AFFINE) {
+        for (int c = tid; c < a.Cin; c += 256) {
+            tab[c] = a.in_alpha[(size_t)img * a.Cin + c] * a.in_scale;
+            tab[a.Cin + c] = a.in_beta[(size_t)img * a.Cin + c] * a.in_scale;
+        }
+        __syncthreads();
+    }
+    const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();    // branch-free ReLU switch
+    F4 sx[2];                                                        // staging registers: one round of x
+    auto stage_load_x = [&](int cn, int r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) sx[q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(cn * 64 + q * 16));
+    };
+    auto stage_store = [&](int cn, int r) __attribute__((always_inline)) {
+        const int b = wave + 4 * r;
+        F4 t[2];
+        if (AFFINE) {
+            const float* ta = tab + (cn < ncc ? cn * 16 : 0) + oct * 8;     // past the last slab: any valid entry (result unused)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const F4 al = *reinterpret_cast<const F4*>(ta + q * 4), be = *reinterpret_cast<const F4*>(ta + a.Cin + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = __builtin_fmaf(sx[q].v[e], al.v[e], be.v[e]);
+                    v = v > relu_floor ? v : relu_floor;
+                    t[q].v[e] = v * vM[r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = sx[q].v[e] * a.in_scale;                  // a padded slot loaded zeros
+                    t[q].v[e] = v > relu_floor ? v : relu_floor;
+                }
+        }
+        F4 Hh, Ll;
+        split_h2_octet(t[0], t[1], Hh, Ll);
+        // block 7 does not exist: its wave writes into the sink (wave-uniform select, no branch)
+        unsigned char* dst = smem_raw + (b < PBLK ? (cn & 1) * PATCH_BYTES + oct * REGION + b * 512 : OFF_SCRATCH + oct * 512) + (lane & 31) * 16;
+        *reinterpret_cast<F4*>(dst) = Hh;
+        *reinterpret_cast<F4*>(dst + (b < PBLK ? PLANE_P : 1024)) = Ll;
+    };
+
+    // ---- fragments.  Weights: lane (li, lh) takes the 16 bytes of column wn0 + j*32 + li, logical octet lh
+    const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
+    F4 af[2][2][MT], bf[3][2][NTL];                                  // [register set][plane][tile]
+    auto load_b = [&](int set, int cc, int t) __attribute__((always_inline)) {     // past the end of K the descriptor returns zeros
+        const int kc = t * ncc + cc;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0 + j * 32) * 32));
+    };
+    const unsigned char* abase = smem_raw + lh * REGION + (wrow * MT * PC + li) * 16;
+    auto load_a = [&](int set, int cc, int t) __attribute__((always_inline)) {
+        const int ky = t / 3, kx = t - ky * 3;
+        const unsigned char* pbase = abase + (cc & 1) * PATCH_BYTES;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) af[set][p][i] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + ((i + ky) * PC + kx) * 16);
+    };
+
+    f32x16 acc[MT][NTL], tot[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+    auto product = [&](int sa, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                f32x16 c = acc[i][j];
+                if (fresh) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                }
+                acc[i][j] = TSNET_MFMA_F16(af[sa][pa][i], bf[sb][pb][j], c);
+            }
+    };
+    // step (cc, t): A(cc,t) in set SA, B(cc,t) in set t%3; issues A(cc,t+1) and B of two steps ahead first
+    auto step = [&](int cc, int t, int SA) __attribute__((always_inline)) {
+        const bool fresh = t == 0 || t == 4;                         // chains: taps 0..3 and 4..8 of the slab
+        const int t2 = (t + 2) % 9;
+        load_b(t2 % 3, cc + (t + 2 >= 9 ? 1 : 0), t2);
+        if (t < 8) load_a(SA ^ 1, cc, t + 1);
+        // staging of slab cc+1: round 0 fetched at tap 0 and written at tap 2, round 1 fetched at tap 3 and written at tap 5
+        // (past the last slab the loads run into the next pixel's channels or return zeros: written to the idle stage, never read)
+        if (t == 0) stage_load_x(cc + 1, 0);
+        if (t == 3) stage_load_x(cc + 1, 1);
+        const int SB = t % 3;
+        if (NPROD == 4) product(SA, SB, 1, 1, fresh);                // lo * lo
+        product(SA, SB, 1, 0, fresh && NPROD == 3);                  // lo * hi
+        product(SA, SB, 0, 1, false);                                // hi * lo
+        product(SA, SB, 0, 0, false);                                // hi * hi
+        if (t == 2) stage_store(cc + 1, 0);
+        if (t == 5) stage_store(cc + 1, 1);
+        if (t == 3 || t == 8) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];
+        }
+    };
+    auto slab = [&](int cc, int S0) __attribute__((always_inline)) {  // S0 = A register set of tap 0 = cc & 1 (9 taps: parity flips per slab)
+        __syncthreads();                                             // patch(cc) complete and visible; slab cc-1 fully read
+        load_a(S0, cc, 0);
+        step(cc, 0, S0); step(cc, 1, S0 ^ 1); step(cc, 2, S0);
+        step(cc, 3, S0 ^ 1); step(cc, 4, S0); step(cc, 5, S0 ^ 1);
+        step(cc, 6, S0); step(cc, 7, S0 ^ 1); step(cc, 8, S0);
+    };
+
+    // prologue: patch of slab 0, weight fragments of steps (0,0) and (0,1)
+    stage_load_x(0, 0); stage_store(0, 0);
+    stage_load_x(0, 1); stage_store(0, 1);
+    load_b(0, 0, 0);
+    load_b(1, 0, 1);
+    int cc = 0;
+    for (; cc + 2 <= ncc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
+    if (cc < ncc) slab(cc, 0);
+
+    const float unscale = a.in_unscale * a.w_unscale[0];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[i][j][r] *= unscale;    // exact: power of two
+    const int m_img = img * a.Ho * a.Wo;
+    x3_epilogue<BN, WARPS_M, WARPS_N, MT, NTL>(a, tot, smem_raw, tid, wave, n0, (size_t)img * tper + tin,
+                                               [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
+}
+
+template <int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE>
+__global__ __launch_bounds__(256, BN <= 64 ? 3 : 2)   // three workgroups per CU with 64-wide tiles (768 tiles = 3 per CU on the ResnetBlock layers)
+void conv_h2_kernel(H2Args a) {
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
+    const int tile_m = bid / a.tiles_n;
+    h2_tile<BN, WARPS_M, WARPS_N, NPROD, AFFINE>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+}
+
+// OIHW fp32 -> two fp16 planes of w * scale in the fragment order of pack_weights_x3_kernel:
+//   out[p][((kc*Npad + n)*2 + o)*8 + e] = part_p( scale * W[k = kc*16 + (o ^ ((n>>3)&1))*8 + e][n] ),  k = tap*cin_pad + c
+__global__ void pack_weights_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, float scale,
+                                       int cout, int cin_real, int cin_pad, int ks, int kpad, int npad, int cin_total, int cin_off) {
+    const size_t plane = (size_t)kpad * npad;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 7;
+        const int o = (idx >> 3) & 1;
+        const size_t rest = idx >> 4;
+        const int n = (int)(rest % npad);
+        const int kc = (int)(rest / npad);
+        const int k = kc * 16 + (o ^ ((n >> 3) & 1)) * 8 + e;
+        const int tap = k / cin_pad, c = k - tap * cin_pad;
+        float v = 0.f;
+        if (tap < ks * ks && c < cin_real && n < cout) {
+            const int ky = tap / ks, kx = tap - ky * ks;
+            v = w[(((size_t)n * cin_total + cin_off + c) * ks + ky) * ks + kx];
+        }
+        unsigned hi, lo;
+        split_h2(v * scale, hi, lo);
+        out[idx] = (unsigned short)hi; out[plane + idx] = (unsigned short)lo;
+    }
+}
+
+}  // namespace tsnet

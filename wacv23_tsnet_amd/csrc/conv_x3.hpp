@@ -46,8 +46,8 @@ typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
 
 // Shared epilogue of the bf16x3 kernels: bias, optional per-pixel addend, fp64 InstanceNorm partial sums of the tile,
 // fp32 store and/or split-plane store.  m_of(l) maps the local row l of the tile to the output position m (or -1).
-template <int BN, int WARPS_M, int WARPS_N, int MT, int NTL, typename MOf>
-__device__ __forceinline__ void x3_epilogue(const X3Args& a, f32x16 (&tot)[MT][NTL], unsigned char* smem_raw, int tid, int wave, int n0,
+template <int BN, int WARPS_M, int WARPS_N, int MT, int NTL, typename Args, typename MOf>
+__device__ __forceinline__ void x3_epilogue(const Args& a, f32x16 (&tot)[MT][NTL], unsigned char* smem_raw, int tid, int wave, int n0,
                                             size_t stat_tile, MOf m_of) {
     constexpr int WM = MT * 32, WN = NTL * 32;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;

@@ -227,7 +227,7 @@ __device__ __forceinline__ tsnet_brsrc_t tsnet_make_brsrc(const void* p, unsigne
 #endif
 
 // QABL (tools/x3_ablate.py q only; non-zero computes garbage): bit0 no patch staging, bit1 no slab barrier, bit2 no fold,
-// bit3 weight fragments loaded once, bit4 A fragments read once
+// bit3 weight fragments loaded once, bit4 A fragments read once, bit5 plane 1 unused (two planes, three products)
 template <int BN, int WARPS_M, int WARPS_N, int QABL = 0>
 __device__ __forceinline__ void x3q_tile(const X3Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
     constexpr int BM = kPatchRows * kPatchCols;
@@ -346,20 +346,22 @@ __device__ __forceinline__ void x3q_tile(const X3Args& a, unsigned char* smem_ra
         const bool last = t == 8;
         const int nc = last ? cc + 1 : cc, nt = last ? 0 : t + 1;
         F4 stage;
-        if (t < 6 && !(QABL & 1)) stage = patch_load(cc + 1, t);
+        constexpr bool TWO = (QABL & 32) != 0;               // timing proxy of a two-plane / three-product scheme: plane 1 unused
+        const bool stage_on = t < 6 && !(QABL & 1) && !(TWO && (t % 3) == 1);
+        if (stage_on) stage = patch_load(cc + 1, t);
         product(2, 0, fresh && !(QABL & 4));                 // lo  * hi
         if (!last && !(QABL & 16)) load_a(2, nc, nt);
-        product(1, 0, false);                                // mid * hi
+        if (!TWO) product(1, 0, false);                      // mid * hi
         product(0, 0, false);                                // hi  * hi
         if (!(QABL & 8)) load_b(0, nc, nt);
-        product(1, 1, false);                                // mid * mid
-        if (!last && !(QABL & 16)) load_a(1, nc, nt);
-        product(0, 1, false);                                // hi  * mid
-        if (!(QABL & 8)) load_b(1, nc, nt);
+        if (!TWO) product(1, 1, false);                      // mid * mid
+        if (!last && !(QABL & 16) && !TWO) load_a(1, nc, nt);
+        if (!TWO) product(0, 1, false);                      // hi  * mid
+        if (!(QABL & 8) && !TWO) load_b(1, nc, nt);
         product(0, 2, false);                                // hi  * lo
         if (!last && !(QABL & 16)) load_a(0, nc, nt);
         if (!(QABL & 8)) load_b(2, nc, nt);
-        if (t < 6 && !(QABL & 1)) patch_store(cc + 1, t, stage);
+        if (stage_on) patch_store(cc + 1, t, stage);
         if ((t == 3 || t == 8) && !(QABL & 4)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)

@@ -35,6 +35,7 @@
 #include "conv_x3.hpp"
 #include "conv_x3p.hpp"
 #include "conv_x3r.hpp"
+#include "conv_h2.hpp"
 #include "flow_warp.hpp"
 #include "head_conv.hpp"
 #include "norm_elementwise.hpp"
@@ -46,7 +47,7 @@ using namespace tsnet;
 namespace {
 
 thread_local std::string g_op_error;
-int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] unused, [1] conv_igemm, [2] conv_dma, [3] conv_x3
+int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] conv_h2, [1] conv_igemm, [2] conv_dma, [3] conv_x3
 std::string g_create_error;
 
 #define HIP_TRY(expr)                                                                               \
@@ -137,6 +138,8 @@ struct ConvLayer {
     const float* w2 = nullptr;    // device, packed for conv_dma_kernel    [K/16][Npad][4 swizzled quads][4]
     const unsigned short* w3 = nullptr;   // device, bf16x3 planes for conv_x3_kernel [3][K/16][Npad][2 octets][8]
     const float* bias = nullptr;  // device (cout)
+    const unsigned short* wh = nullptr;   // device, fp16x2 planes for conv_h2_kernel [2][K/16][Npad][2 octets][8] of w * 2^sw, or null
+    const float* wh_unscale = nullptr;    // device scalar 2^-sw (in the packed buffer: replicas receive it with the broadcast)
 };
 
 constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded to an even number of 16-deep chunks (ring prefetch may run one past the end)
@@ -431,6 +434,10 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
             case 16: launch_x3q_abl<16>(g, ctx.stream); break;
             case 24: launch_x3q_abl<24>(g, ctx.stream); break;
             case 31: launch_x3q_abl<31>(g, ctx.stream); break;
+            case 32: launch_x3q_abl<32>(g, ctx.stream); break;
+            case 33: launch_x3q_abl<33>(g, ctx.stream); break;
+            case 40: launch_x3q_abl<40>(g, ctx.stream); break;
+            case 41: launch_x3q_abl<41>(g, ctx.stream); break;
             default: throw ArgError("unsupported ablation mask");
         }
         return;
@@ -474,6 +481,73 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
     }
     check_launch("conv_x3");
     ++g_launch_counters[3];
+}
+
+// ---- fp16x2 patch convolution from fp32 input with the producer's InstanceNorm + ReLU fused into the patch staging (conv_h2.hpp)
+struct H2Call {
+    const float* x = nullptr;
+    const float* alpha = nullptr; const float* beta = nullptr; int relu = 0;   // x*alpha+beta (+ReLU) on load, or the raw tensor
+    float bound = 0.f;          // max |operand| after the transform (InstanceNorm output: sqrt(HW); residual stream: (blocks+1) sqrt(HW))
+    int N = 0, H = 0, W = 0;
+    float* y = nullptr;
+    const float* addend = nullptr; int add_nmod = 1;
+    double* stat_part = nullptr; mutable int stat_S = 0;
+    float* fin_alpha = nullptr; float* fin_beta = nullptr; int* fin_counter = nullptr;
+    int nprod = 3, bn = 0;      // products per k-group (3; 4 adds lo*lo), tile width (0 = heuristic)
+    int tclass = TSNET_T_CONV;
+};
+
+inline bool h2_layer_ok(const ConvLayer& L) {
+    return L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && L.npad % 64 == 0;
+}
+// power-of-two operand scale: |x| <= bound  ->  |x * 2^sa| <= 2^15 < 65504 (fp16 max)
+inline int h2_scale_log2(float bound) {
+    if (!(bound > 0.f) || !std::isfinite(bound)) throw ArgError("conv(h2): the operand bound must be positive and finite");
+    int e = 0;
+    (void)std::frexp(bound, &e);          // bound = m * 2^e, m in [0.5, 1)  ->  bound <= 2^e
+    int sa = 15 - e;
+    if (sa > 24) sa = 24;
+    if (sa < -24) sa = -24;
+    return sa;
+}
+
+template <int BN, int NPROD>
+void launch_h2(const H2Args& a, hipStream_t s) {
+    const size_t lds = 2 * 2 * 7168 + 2048 + (size_t)2 * a.Cin * 4;
+    if (a.in_alpha) hipLaunchKernelGGL((conv_h2_kernel<BN, 2, 2, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_h2_kernel<BN, 2, 2, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+}
+
+void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
+    if (!h2_layer_ok(L) || !L.wh) throw ArgError("conv(h2): layer is not a 3x3 / stride-1 / pad-1 layer with fp16x2 weights");
+    H2Args g{};
+    g.x = c.x; g.in_alpha = c.alpha; g.in_beta = c.alpha ? c.beta : nullptr; g.in_relu = c.relu;
+    const int sa = h2_scale_log2(c.bound);
+    g.in_scale = std::ldexp(1.0f, sa); g.in_unscale = std::ldexp(1.0f, -sa);
+    g.w = L.wh; g.w_unscale = L.wh_unscale; g.bias = L.bias; g.y = c.y; g.y3 = nullptr;
+    g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
+    g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.Ho = c.H; g.Wo = c.W; g.Cout = L.cout; g.Npad = L.npad;
+    g.reflect = L.reflect; g.nchunks = (9 * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
+    if (g.Ho % kPatchRows || g.Wo % kPatchCols) throw ArgError("conv(h2): output must split into 4 x 32 rectangles");
+    if (L.reflect && (c.H < 2 || c.W < 2)) throw ArgError("conv: reflection pad needs pad < input size");
+    if (c.alpha && !c.beta) throw ArgError("conv(h2): alpha without beta");
+    if ((double)c.N * c.H * c.W * L.cin_pad * 4 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
+        throw ArgError("conv(h2): tensor too large for 32-bit buffer offsets");
+    if ((size_t)2 * g.Cin * 4 + 2 * 2 * 7168 + 2048 > 64 * 1024) throw ArgError("conv(h2): too many input channels for the transform table");
+    int bn = c.bn ? c.bn : 64;
+    if (bn != 64 && bn != 128) throw ArgError("conv(h2): tile width must be 64 or 128");
+    if (g.Npad % bn) bn = 64;
+    g.tiles_m = g.M / 128; g.tiles_n = (g.Cout + bn - 1) / bn;
+    const int hw = g.Ho * g.Wo;
+    g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f; g.fin_S = hw / 128;
+    g.fin_counter = (c.stat_part && c.fin_counter && hw / 128 <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= 65536) ? c.fin_counter : nullptr;
+    TimeScope ts(ctx, c.tclass);
+    if (c.nprod == 3) { if (bn == 64) launch_h2<64, 3>(g, ctx.stream); else launch_h2<128, 3>(g, ctx.stream); }
+    else if (c.nprod == 4) { if (bn == 64) launch_h2<64, 4>(g, ctx.stream); else launch_h2<128, 4>(g, ctx.stream); }
+    else throw ArgError("conv(h2): 3 or 4 products");
+    check_launch("conv_h2");
+    c.stat_S = !c.stat_part ? 0 : (g.fin_counter ? -1 : hw / 128);
+    ++g_launch_counters[0];
 }
 
 void run_split3(Ctx& ctx, const float* x, unsigned short* out, size_t elems) {
@@ -693,6 +767,8 @@ struct tsnet_engine {
     float* FT = nullptr;                  // (B,P,2C) target half of fuse_c1, computed once per forward
     // ---- bf16x3 mode (conv_x3.hpp): every conv input exists as three bf16 planes
     bool x3 = true;
+    bool h2 = true;                       // fp16x2 patch convolution (conv_h2.hpp) for the 3x3 / stride-1 layers whose input is bounded; TSNET_H2=0: round-1 schedule
+    float* U_f32[8] = {nullptr};          // fp32 upsampled decoder inputs (h2 schedule; the bf16x3 schedule writes planes only)
     unsigned short* wpack3 = nullptr; size_t wpack3_elems = 0;
     unsigned short* arena3 = nullptr;
     unsigned short *x_img3 = nullptr, *x_lbl3 = nullptr, *X3 = nullptr, *T3 = nullptr, *tar3 = nullptr, *zbar3 = nullptr,
@@ -772,6 +848,19 @@ struct tsnet_engine {
             run_stats(ctx, c.y, N, HW, L.cout, pt, alpha, beta);
         }
     }
+    void conv_stats_h2(Ctx& ctx, const ConvLayer& L, H2Call& c, int N, int HW, float* alpha, float* beta) {
+        double* pt = ctx.lane ? part_side : part;
+        c.stat_part = pt;
+        c.fin_alpha = alpha; c.fin_beta = beta; c.fin_counter = ctx.lane ? fin_counter_side : fin_counter;
+        run_conv_h2(ctx, L, c);
+        if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
+        TimeScope ts(ctx, TSNET_T_STATS);
+        hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + 63) / 64, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
+        check_launch("in_finalize2");
+    }
+    // ResnetBlock on the h2 schedule.  stream_bound > 0: the residual stream Xs is bounded (encoder: (blocks+1) sqrt(HW)) and the first
+    // convolution reads it as fp32; otherwise (decoder: the stream starts at a raw convolution output) it reads the bf16x3 planes Xs3.
+    void resblock_h2(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float stream_bound, float* y1, float* y2, int N, int hh, int ww);
     void resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww);
     void set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B);
     void forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
@@ -789,6 +878,8 @@ struct tsnet_engine {
         if (!ctx.lane) return next_ab();
         auto r = std::make_pair(ab_side[ab_side_rr][0], ab_side[ab_side_rr][1]); ab_side_rr ^= 1; return r;
     }
+    bool h2_feat() const { return h2 && h % kPatchRows == 0 && w % kPatchCols == 0; }   // the feature-resolution layers run on conv_h2
+    float enc_bound() const { return (float)(cfg.enc_blocks + 1) * std::sqrt((float)P); }  // bound of the source features (encode_x3)
     void target_chain_x3(Ctx& ctx, const float* tar_lbl, int B);
     void forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
 };
@@ -866,6 +957,16 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     off = (off + 63) / 64 * 64;
     const size_t x3_off = off;
     off += (o3 + 1) / 2;                   // two bf16 per float slot
+    // fp16x2 planes (conv_h2.hpp) of the 3x3 / stride-1 layers + one un-scale factor per layer
+    off = (off + 63) / 64 * 64;
+    const size_t h2tab_off = off;
+    off += round_up((int)all_layers.size(), 64);
+    size_t oh = 0;
+    std::vector<size_t> offs_h(all_layers.size(), 0);
+    if (x3 && h2) for (size_t i = 0; i < all_layers.size(); ++i) if (h2_layer_ok(*all_layers[i])) { offs_h[i] = oh; oh += 2 * (size_t)all_layers[i]->kpad * all_layers[i]->npad; }
+    off = (off + 63) / 64 * 64;
+    const size_t h2_off = off;
+    off += (oh + 1) / 2;
     wpack_floats = off;
     HIP_TRY(hipMalloc((void**)&wpack, wpack_floats * sizeof(float)));
     HIP_TRY(hipMemsetAsync(wpack, 0, wpack_floats * sizeof(float), s));
@@ -899,6 +1000,27 @@ void tsnet_engine::alloc_all(hipStream_t s) {
             HIP_TRY(hipStreamSynchronize(s));
             L->w3 = wpack3 + offs[li];
             ++li;
+        }
+    }
+    if (x3 && h2) {                        // fp16x2 planes: per layer a power-of-two scale from the largest |weight|
+        unsigned short* wh_base = reinterpret_cast<unsigned short*>(wpack + h2_off);
+        for (size_t i = 0; i < all_layers.size(); ++i) {
+            ConvLayer* L = all_layers[i];
+            if (!h2_layer_ok(*L)) continue;
+            const Param& pw = params[pindex[L->wparam]];
+            float mx = 0.f;
+            for (float v : pw.host) { const float av = std::fabs(v); if (av > mx) mx = av; }
+            if (!std::isfinite(mx)) throw WeightError("parameter '" + L->wparam + "' holds a non-finite value");
+            const int sw = mx > 0.f ? h2_scale_log2(mx) : 0;
+            const float unscale = std::ldexp(1.0f, -sw);
+            HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(wpack + h2tab_off + i, &unscale, sizeof(float), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(pack_weights_h2_kernel, dim3(ew_grid((size_t)L->kpad * L->npad)), dim3(256), 0, s, stage, wh_base + offs_h[i], std::ldexp(1.0f, sw),
+                               L->cout, L->cin_real, L->cin_pad, L->ks, L->kpad, L->npad, L->cin_total > 0 ? L->cin_total : L->cin_real, L->cin_off);
+            check_launch("pack_weights_h2");
+            HIP_TRY(hipStreamSynchronize(s));
+            L->wh = wh_base + offs_h[i];
+            L->wh_unscale = wpack + h2tab_off + i;
         }
     }
     if (want_head) {                       // RGB head weights for the vector kernel (else the MFMA path is used)
@@ -953,6 +1075,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
         want(&U[i], B * sp * (C >> i));
         want(&R[i], B * sp * (C >> (i + 1)));
     }
+    if (x3 && h2) for (int i = 1; i < cfg.n_downsampling && i < 8; ++i) want(&U_f32[i], B * (size_t)(h << (i + 1)) * (w << (i + 1)) * (C >> i));
     for (int i = 0; i < 4; ++i) { want(&ab[i][0], NB * 2 * C); want(&ab[i][1], NB * 2 * C); }
     want(&bbox_copy, NB * H * W);
     float* part_f = nullptr;
@@ -1007,6 +1130,25 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     }
 }
 
+// ---- h2 schedule: the 3x3 / stride-1 convolutions read fp32 and apply the producer's InstanceNorm + ReLU while staging (conv_h2.hpp)
+void tsnet_engine::resblock_h2(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float stream_bound,
+                               float* y1, float* y2, int N, int hh, int ww) {
+    const int Cc = c1.cout, HW = hh * ww;
+    auto s1 = next_ab();
+    if (stream_bound > 0.f) {
+        H2Call a; a.x = Xs; a.bound = stream_bound; a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
+        conv_stats_h2(ctx, c1, a, N, HW, s1.first, s1.second);
+    } else {
+        X3Call a; a.x3 = Xs3; a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
+        conv_stats_x3(ctx, c1, a, N, HW, s1.first, s1.second);
+    }
+    H2Call b; b.x = y1; b.alpha = s1.first; b.beta = s1.second; b.relu = 1; b.bound = std::sqrt((float)HW);   // |IN(.)| <= sqrt(HW - 1)
+    b.N = N; b.H = hh; b.W = ww; b.y = y2; b.tclass = TSNET_T_CONV_RES;
+    auto s2 = next_ab();
+    conv_stats_h2(ctx, c2, b, N, HW, s2.first, s2.second);
+    run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs, stream_bound > 0.f ? nullptr : Xs3);   // X += IN(y2)
+}
+
 // ---- bf16x3 schedule: same graph as the fp32 one; every conv reads planes, producers write planes
 void tsnet_engine::resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float* y1, float* y2, int N, int hh, int ww) {
     const int Cc = c1.cout, HW = hh * ww;
@@ -1033,9 +1175,15 @@ void tsnet_engine::encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned
         st = next_ab(ctx);
         conv_stats_x3(ctx, L[l], d, N, hh * ww, st.first, st.second);
     }
-    run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea, out_fea3);
-    for (int i = 0; i < nblocks; ++i)
-        resblock_x3(ctx, L[cfg.n_downsampling + 1 + 2 * i], L[cfg.n_downsampling + 2 + 2 * i], out_fea, out_fea3, Y1, Y2, N, hh, ww);
+    const bool use_h2 = h2 && (hh % kPatchRows == 0) && (ww % kPatchCols == 0);
+    run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea, use_h2 ? nullptr : out_fea3);
+    // |relu(IN(.))| <= sqrt(HW) and every block adds one more InstanceNorm output: the stream stays below (blocks + 1) sqrt(HW)
+    const float bound = (float)(nblocks + 1) * std::sqrt((float)(hh * ww));
+    for (int i = 0; i < nblocks; ++i) {
+        const ConvLayer &c1 = L[cfg.n_downsampling + 1 + 2 * i], &c2 = L[cfg.n_downsampling + 2 + 2 * i];
+        if (use_h2) resblock_h2(ctx, c1, c2, out_fea, nullptr, bound, Y1, Y2, N, hh, ww);
+        else resblock_x3(ctx, c1, c2, out_fea, out_fea3, Y1, Y2, N, hh, ww);
+    }
 }
 
 void tsnet_engine::forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
@@ -1058,8 +1206,13 @@ void tsnet_engine::target_chain_x3(Ctx& ctx, const float* tar_lbl, int B) {
     }
     encode_x3(ctx, lbl_enc, x_lbl3, B, raw_lbl, raw3_lbl, tar_fea, tar3, 0);
     run_l2norm(ctx, tar_fea, that, B * P, C);
-    X3Call t; t.x3 = tar3; t.N = B; t.H = h; t.W = w; t.y = FT;                        // shared target half of fuse conv1
-    run_conv_x3(ctx, fuse_c1_tar, t);
+    if (h2_feat()) {                                                                   // shared target half of fuse conv1
+        H2Call t; t.x = tar_fea; t.bound = std::sqrt((float)P); t.N = B; t.H = h; t.W = w; t.y = FT;
+        run_conv_h2(ctx, fuse_c1_tar, t);
+    } else {
+        X3Call t; t.x3 = tar3; t.N = B; t.H = h; t.W = w; t.y = FT;
+        run_conv_x3(ctx, fuse_c1_tar, t);
+    }
 }
 
 void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
@@ -1087,13 +1240,21 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
 
     // ---- synthesis branch
     {
-        X3Call a; a.x3 = X3; a.N = NB; a.H = h; a.W = w; a.y = F1; a.addend = FT; a.add_nmod = B;
         auto s1 = next_ab();
-        conv_stats_x3(ctx, fuse_c1_src, a, NB, P, s1.first, s1.second);
-        run_norm_act(ctx, F1, s1.first, s1.second, 1, nullptr, NB, P, 2 * C, nullptr, T3);
-        X3Call b; b.x3 = T3; b.N = NB; b.H = h; b.W = w; b.y = F2;
         auto s2 = next_ab();
-        conv_stats_x3(ctx, fuse_c2, b, NB, P, s2.first, s2.second);
+        if (h2_feat()) {
+            H2Call a; a.x = X; a.bound = enc_bound(); a.N = NB; a.H = h; a.W = w; a.y = F1; a.addend = FT; a.add_nmod = B;
+            conv_stats_h2(ctx, fuse_c1_src, a, NB, P, s1.first, s1.second);
+            H2Call b; b.x = F1; b.alpha = s1.first; b.beta = s1.second; b.relu = 1; b.bound = std::sqrt((float)P);
+            b.N = NB; b.H = h; b.W = w; b.y = F2;
+            conv_stats_h2(ctx, fuse_c2, b, NB, P, s2.first, s2.second);
+        } else {
+            X3Call a; a.x3 = X3; a.N = NB; a.H = h; a.W = w; a.y = F1; a.addend = FT; a.add_nmod = B;
+            conv_stats_x3(ctx, fuse_c1_src, a, NB, P, s1.first, s1.second);
+            run_norm_act(ctx, F1, s1.first, s1.second, 1, nullptr, NB, P, 2 * C, nullptr, T3);
+            X3Call b; b.x3 = T3; b.N = NB; b.H = h; b.W = w; b.y = F2;
+            conv_stats_x3(ctx, fuse_c2, b, NB, P, s2.first, s2.second);
+        }
         {
             TimeScope ts(ctx, TSNET_T_ELEMWISE);
             FuseTailArgs t2{X, tar_fea, F2, s2.first, s2.second, nullptr, B, K, P, C, zbar3};
@@ -1111,16 +1272,29 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
         a.y3 = cfg.n_blocks > 0 ? D3 : nullptr;
         run_conv_x3(ctx, dec_map, a);
     }
-    for (int i = 0; i < cfg.n_blocks; ++i) resblock_x3(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, DY1, DY2, B, h, w);
+    for (int i = 0; i < cfg.n_blocks; ++i) {
+        // the decoder's stream starts at dec_map's raw output (no bound): its first convolutions stay on the bf16x3 planes
+        if (h2_feat()) resblock_h2(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, 0.f, DY1, DY2, B, h, w);
+        else resblock_x3(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, DY1, DY2, B, h, w);
+    }
     const float* cur = D; const float* cal = nullptr; const float* cbe = nullptr;
     int hh = h, ww = w, cc = C;
     for (int i = 0; i < cfg.n_downsampling; ++i) {
-        run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, nullptr, U3[i]);
+        // input of up-convolution i = bilinear x2 of relu(IN(previous)) -- a convex combination of InstanceNorm outputs, bounded by
+        // sqrt(HW) of the low-resolution map; the first one upsamples the unnormalised decoder stream and keeps the bf16x3 path
+        const bool via_h2 = h2 && cal && i < 8 && U_f32[i] && (2 * hh) % kPatchRows == 0 && (2 * ww) % kPatchCols == 0 && h2_layer_ok(dec_up[i]);
+        const float in_bound = std::sqrt((float)(hh * ww));
+        run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, via_h2 ? U_f32[i] : nullptr, via_h2 ? nullptr : U3[i]);
         hh *= 2; ww *= 2;
-        X3Call a; a.x3 = U3[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
         cc /= 2;
         auto st = next_ab();
-        conv_stats_x3(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
+        if (via_h2) {
+            H2Call a; a.x = U_f32[i]; a.bound = in_bound; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
+            conv_stats_h2(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
+        } else {
+            X3Call a; a.x3 = U3[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
+            conv_stats_x3(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
+        }
         cur = R[i]; cal = st.first; cbe = st.second;
     }
     if (!vector_head) throw ArgError("bf16x3 mode needs the vector RGB head (ngf % 16 == 0)");
@@ -1334,6 +1508,7 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
         { const char* x = getenv("TSNET_X3");
           // bf16x3 convs (conv_x3.hpp): needs 16-channel granularity everywhere except the stems, and the vector head
           e->x3 = !(x && !atoi(x)) && (cfg->ngf % 16 == 0) && e->vector_head && !e->fuse_norm_in_loader; }
+        { const char* hh2 = getenv("TSNET_H2"); e->h2 = e->x3 && !(hh2 && !atoi(hh2)); }
         { const char* sf = getenv("TSNET_SPLIT_FUSE"); e->split_fuse = !e->fuse_norm_in_loader && !(sf && !atoi(sf)); }
         *out = e;
     } catch (const std::exception& ex) { g_create_error = ex.what(); return TSNET_ERR_NOMEM; }
@@ -1636,6 +1811,45 @@ int tsnet_op_conv2d_x3(const float* x, int N, int H, int W, int Cin, const float
     OP_END
 }
 
+int tsnet_op_conv2d_h2(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int pad_mode,
+                       const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, int tile_n, float* y, void* stream) {
+    OP_BEGIN
+    if (!x || !w_oihw || !y) throw ArgError("null tensor");
+    if (Cin < 16 || (Cin & 15)) throw ArgError("conv2d_h2 op: Cin must be a multiple of 16");
+    hipStream_t s = (hipStream_t)stream;
+    Ctx ctx; ctx.stream = s;
+    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = 3; L.stride = 1; L.pad = 1;
+    L.reflect = pad_mode; L.kpad = conv_kpad(3, Cin); L.npad = conv_npad(Cout);
+    if (L.npad % 64) L.npad = round_up(Cout, 64);
+    const size_t wn = (size_t)Cout * Cin * 9;
+    std::vector<float> hw(wn);
+    HIP_TRY(hipMemcpy(hw.data(), w_oihw, wn * sizeof(float), hipMemcpyDefault));
+    float mx = 0.f;
+    for (float v : hw) mx = std::max(mx, std::fabs(v));
+    const int sw = mx > 0.f ? h2_scale_log2(mx) : 0;
+    float *wd = nullptr, *bd = nullptr, *un = nullptr; unsigned short* wh = nullptr;
+    HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&wh, (size_t)L.kpad * L.npad * 4));
+    HIP_TRY(hipMalloc((void**)&un, sizeof(float)));
+    HIP_TRY(hipMemcpy(wd, hw.data(), wn * sizeof(float), hipMemcpyHostToDevice));
+    const float unscale = std::ldexp(1.0f, -sw);
+    HIP_TRY(hipMemcpy(un, &unscale, sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pack_weights_h2_kernel, dim3(ew_grid((size_t)L.kpad * L.npad)), dim3(256), 0, s, wd, wh, std::ldexp(1.0f, sw),
+                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, Cin, 0);
+    check_launch("pack_weights_h2");
+    if (bias) {
+        HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
+        HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
+    }
+    L.wh = wh; L.wh_unscale = un; L.bias = bd;
+    H2Call c; c.x = x; c.alpha = in_alpha; c.beta = in_beta; c.relu = in_relu; c.bound = bound; c.N = N; c.H = H; c.W = W; c.y = y;
+    c.nprod = nprod; c.bn = tile_n;
+    run_conv_h2(ctx, L, c);
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(wd); (void)hipFree(wh); (void)hipFree(un); (void)hipFree(bd);
+    OP_END
+}
+
 int tsnet_op_instnorm_stats(const float* x, int N, int HW, int C, float* alpha, float* beta, void* stream) {
     OP_BEGIN
     if (!x || !alpha || !beta) throw ArgError("null tensor");
@@ -1734,7 +1948,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const size_t xn = (size_t)N * H * W * Cin, yn = (size_t)N * Ho * Wo * Cout, wn = (size_t)L.kpad * L.npad;
     float *x = nullptr, *y = nullptr, *w = nullptr, *al = nullptr, *be = nullptr;
-    if (norm && variant >= 0 && (variant & (4096 | 8192))) throw ArgError("bench_conv: the LDS-DMA kernels take no input transform");
+    if (norm && variant >= 0 && (variant & (4096 | 8192)) && !(variant & 16384)) throw ArgError("bench_conv: the LDS-DMA kernels take no input transform");
     HIP_TRY(hipMalloc((void**)&x, xn * 4)); HIP_TRY(hipMalloc((void**)&y, yn * 4)); HIP_TRY(hipMalloc((void**)&w, wn * 4));
     HIP_TRY(hipMalloc((void**)&al, (size_t)N * Cin * 4)); HIP_TRY(hipMalloc((void**)&be, (size_t)N * Cin * 4));
     // pseudo-random fill (not zeros: MI355X clocks higher on zero operands, cdna_hip_programming.md rule 25)
@@ -1764,6 +1978,34 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
         *ms_out = ms / iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(al); (void)hipFree(be); (void)hipFree(x3); (void)hipFree(w3);
+        return TSNET_OK;
+    }
+    if (variant >= 0 && (variant & 16384)) {       // conv_h2: fp32 input (optionally normalised on load), fp16x2 weight planes
+        unsigned short* wh = nullptr; float* un = nullptr;
+        HIP_TRY(hipMalloc((void**)&wh, wn * 4)); HIP_TRY(hipMalloc((void**)&un, 4));
+        const float unscale = 1.0f / 262144.f;
+        HIP_TRY(hipMemcpy(un, &unscale, 4, hipMemcpyHostToDevice));
+        {   // the random buffer is already laid out [K][Npad]-like: split it in place order (timing only)
+            hipLaunchKernelGGL(pack_weights_h2_kernel, dim3(ew_grid(wn)), dim3(256), 0, s, w, wh, 262144.f, L.npad, L.kpad / (ksize * ksize), L.kpad / (ksize * ksize), ksize, L.kpad, L.npad,
+                               L.kpad / (ksize * ksize), 0);
+            check_launch("pack_weights_h2(bench)");
+        }
+        L.wh = wh; L.wh_unscale = un;
+        H2Call hc; hc.x = x; hc.N = N; hc.H = H; hc.W = W; hc.y = y; hc.bound = norm ? 64.f : 1.f;
+        hc.bn = (variant & 1) ? 128 : 64; hc.nprod = (variant & 4) ? 4 : 3;
+        if (norm) { hc.alpha = al; hc.beta = be; hc.relu = 1; }
+        for (int i = 0; i < 2; ++i) run_conv_h2(ctx, L, hc);
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) run_conv_h2(ctx, L, hc);
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(al); (void)hipFree(be); (void)hipFree(wh); (void)hipFree(un);
         return TSNET_OK;
     }
     ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.variant = variant;
