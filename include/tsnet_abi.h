@@ -93,6 +93,11 @@ int tsnet_forward(tsnet_handle h,
                   const float* tar_lbl, const float* tar_bbox,
                   float* out_rgb, float* out_flow, int B, void* stream);
 
+/* Per-source divisor applied to the source IMAGES on load: 255 (default; the `/255.0` of set_test_input / set_train_input,
+ * TSNet.py:267,286) or 1 for a source that is a previously generated frame already in [0,1] (`use_prev`, TSNet.py:269-276).
+ * div: n host floats (n <= n_source; the rest reset to 255).  Drops the clip-mode source cache. */
+int tsnet_set_source_divisors(tsnet_handle h, const float* div, int n);
+
 /* Clip mode (caller pattern demo/demo_face.py:185-192: the same K
  * sources for every driving frame).  tsnet_set_sources runs img_enc once and caches its features;
  * tsnet_forward_target then costs only lbl_enc + both branches + decoder and returns the same

@@ -92,6 +92,7 @@ template <class T> static inline T emu_buf_load16(const tsnet_rsrc_t& r, unsigne
 // hook of conv_h2.hpp: v_mfma_f32_32x32x16_f16 on raw 16-byte operands (8 fp16 per lane)
 #define TSNET_MFMA_F16(a, b, c) emu::mfma_f16_32x32x16(&(a), &(b), (c))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define TSNET_DRAIN_VMEM() ((void)0)
 // device-scope atomics of the statistics hand-off (conv_x3.hpp x3_epilogue): workgroups run one after another here
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))

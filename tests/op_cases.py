@@ -60,7 +60,7 @@ def conv_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, norm=False,
 
 
 
-def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, nprod=3, tile_n=0, seed=0, scale=1.0):
+def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, nprod=3, tile_n=0, seed=0, scale=1.0, return_output=False):
     """nn.Conv2d 3x3 / stride 1 (+ReflectionPad2d(1) or zero pad 1), optionally on relu(x*alpha+beta) -- the consumer side of
     nn.InstanceNorm2d + nn.ReLU -- vs tsnet_op_conv2d_h2 (fp16x2 patch kernel, transform fused into the patch staging).
     Returns max|d| relative to max|ref|."""
@@ -86,6 +86,8 @@ def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, n
                                 1 if norm else 0, bound, nprod, tile_n, y.data_ptr(), None)
     assert rc == 0, lib.tsnet_op_last_error().decode()
     _sync(dev)
+    if return_output:
+        return y.cpu()
     return ((nchw(y.cpu()).double() - ref).abs().max() / ref.abs().max()).item()
 
 def instnorm_case(lib, dev, N, H, W, C, relu, resid, seed=0, offset=0.0):

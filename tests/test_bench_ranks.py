@@ -1,0 +1,63 @@
+"""bench.py's N>1 branch, executed: world size 2 over gloo, every rank an engine on the CPU emulation build of the kernels, tiny
+shapes.  bench.run_rank is the code `python bench.py --gpus N` runs on every rank; here its collectives are logged in order:
+exactly ONE broadcast (the packed weight buffer, dist.build_replica), then the warm-up steps, a barrier, the timed steps with
+NO collective between them, a barrier, and one MAX all-reduce of the elapsed time.  (No 8-GPU node was available to the build:
+the scaling curve itself is the driver's to measure; this pins that the path it will run is the intended one.)"""
+import json
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS, WARMUP = 3, 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, emu_path, out_dir):
+    sys.path.insert(0, ROOT)
+    import ctypes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from wacv23_tsnet_amd import _lib
+    from wacv23_tsnet_amd.engine import TSNetEngine
+    log = []
+    for name in ("broadcast", "all_reduce", "barrier", "all_gather", "reduce_scatter", "all_to_all", "send", "recv"):
+        orig = getattr(dist, name)
+        setattr(dist, name, (lambda o, n: (lambda *a, **k: (log.append(n), o(*a, **k))[1]))(orig, name))
+    fwd = TSNetEngine.forward
+    TSNetEngine.forward = lambda self, *a, **k: (log.append("step"), fwd(self, *a, **k))[1]
+    lib = _lib.bind(ctypes.CDLL(emu_path))
+    line = bench.run_rank(rank=rank, world=world, device="cpu", steps=STEPS, warmup=WARMUP, lib=lib, batch=1, height=32, width=32,
+                          model_kw=dict(n_source=2, ngf=8, enc_blocks=1, fuse_ngf=128), cpu_baseline=False, timing_probe=False)
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump({"log": log, "line": line}, f)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_broadcast_no_collective_per_step(emu_lib, tmp_path):
+    from conftest import build_emu_lib
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), build_emu_lib(), str(tmp_path)), nprocs=world, join=True)
+    want = ["broadcast"] + ["step"] * WARMUP + ["barrier"] + ["step"] * STEPS + ["barrier", "all_reduce"]
+    for r in range(world):
+        got = json.load(open(tmp_path / f"rank{r}.json"))
+        assert got["log"] == want, (r, got["log"])
+        if r == 0:
+            line = got["line"]
+            assert line["n_gpus"] == 2 and line["steps"] == STEPS and line["warmup"] == WARMUP and line["scaling"] == "weak"
+            assert line["config"]["global_batch"] == 2 and line["value"] > 0
+            assert abs(line["value"] - 2 * STEPS / (line["ms_per_step"] * STEPS / 1e3)) / line["value"] < 1e-2
+        else:
+            assert got["line"] is None

@@ -18,7 +18,7 @@ def load(dbdir):
     return agg
 
 def short(n):
-    m = re.search(r"(conv_x3q|conv_x3p_mixed|conv_x3p|conv_x3|conv_dma)_kernel(?:<([^>]*)>)?", n)
+    m = re.search(r"(conv_h2|conv_x3q|conv_x3r|conv_x3p_mixed|conv_x3p|conv_x3|conv_dma)_kernel(?:<([^>]*)>)?", n)
     if m: return m.group(1) + ("<" + m.group(2).replace(" ", "").replace("false", "f").replace("true", "t") + ">" if m.group(2) else "")
     return re.sub(r"\(.*", "", n).split("::")[-1][:34]
 

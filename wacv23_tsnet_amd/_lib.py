@@ -25,7 +25,7 @@ TIMING_NAMES = ("conv", "stats", "elementwise", "flow", "warp", "pack", "upsampl
 ABI_SYMBOLS = (
     "tsnet_abi_version", "tsnet_create", "tsnet_load_weights", "tsnet_finalize", "tsnet_destroy",
     "tsnet_last_error", "tsnet_num_params", "tsnet_param_info", "tsnet_packed_weights",
-    "tsnet_forward", "tsnet_set_sources", "tsnet_forward_target", "tsnet_train_extras", "tsnet_stage_ptr",
+    "tsnet_forward", "tsnet_set_source_divisors", "tsnet_set_sources", "tsnet_forward_target", "tsnet_train_extras", "tsnet_stage_ptr",
     "tsnet_forward_macs", "tsnet_timing_enable", "tsnet_timing_read",
     "tsnet_op_conv2d", "tsnet_op_conv2d_x3", "tsnet_op_conv2d_h2", "tsnet_op_instnorm_stats", "tsnet_op_norm_act", "tsnet_op_upsample2x",
     "tsnet_op_flow", "tsnet_op_warp", "tsnet_op_last_error", "tsnet_frame_stats", "tsnet_demo_postprocess", "tsnet_bench_conv", "tsnet_debug_counters", "tsnet_linspace", "tsnet_coord_table",
@@ -60,6 +60,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.tsnet_packed_weights.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]
     pp = C.POINTER(_vp)
     lib.tsnet_forward.argtypes = [_vp, pp, pp, pp, _vp, _vp, _vp, _vp, C.c_int, _vp]
+    lib.tsnet_set_source_divisors.argtypes = [_vp, _fp, C.c_int]
     lib.tsnet_set_sources.argtypes = [_vp, pp, pp, pp, C.c_int, _vp]
     lib.tsnet_forward_target.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
     lib.tsnet_train_extras.argtypes = [_vp, pp, _vp, C.c_int, _vp, _vp, _vp]
@@ -91,6 +92,15 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 
 _cached = None
+
+
+def load_tools() -> C.CDLL:
+    """The tools flavour of the library (build.py --tools): product kernels + superseded generations + ablation variants.
+    For tools/*.py on the GPU box only; the package itself never opens it."""
+    from . import build as _b
+    if not os.path.exists(_b.OUT_TOOLS):
+        raise RuntimeError(f"{_b.OUT_TOOLS} is missing: run `python -m wacv23_tsnet_amd.build --tools`")
+    return bind(C.CDLL(_b.OUT_TOOLS))
 
 
 def load() -> C.CDLL:

@@ -16,6 +16,9 @@ SRC = os.path.join(HERE, "csrc", "engine.cpp")
 DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("conv_igemm.hpp", "conv_dma.hpp", "conv_x3.hpp", "conv_x3p.hpp", "conv_x3r.hpp", "conv_h2.hpp", "split3.hpp", "head_conv.hpp", "flow_warp.hpp", "norm_elementwise.hpp", "postproc.hpp", "train_extras.hpp")] + \
        [os.path.join(os.path.dirname(HERE), "include", "tsnet_abi.h")]
 OUT = os.path.join(HERE, "lib", "libtsnet_hip.so")
+# the same sources with -DTSNET_TOOLS: the product kernels PLUS the superseded convolution generations and the ablation
+# instantiations ("computes garbage" variants) that tools/x3_ablate.py and tools/conv_sweep.py time.  Never loaded by the package.
+OUT_TOOLS = os.path.join(HERE, "lib", "libtsnet_tools.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
          "-fhip-fp32-correctly-rounded-divide-sqrt",   # IEEE / and sqrt: the /255, F.normalize and softmax divisions
@@ -25,6 +28,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x",
 
 def up_to_date() -> bool:
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build_tools(force: bool = False, verbose: bool = True) -> str:
+    if not force and os.path.exists(OUT_TOOLS) and all(os.path.getmtime(OUT_TOOLS) >= os.path.getmtime(d) for d in DEPS):
+        return OUT_TOOLS
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + ["-DTSNET_TOOLS", SRC, "-o", OUT_TOOLS]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT_TOOLS
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -42,5 +56,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    if "--tools" in sys.argv:
+        print(build_tools(force="--force" in sys.argv))
+    else:
+        build(force="--force" in sys.argv)
+        print(OUT)

@@ -73,7 +73,9 @@ __device__ __forceinline__ void split_h2_octet(const F4& x0, const F4& x1, F4& H
 }
 
 // NPROD = 3: lo*hi, hi*lo, hi*hi;  NPROD = 4: lo*lo first (kept for the accuracy comparison in the op tests)
-template <int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE>
+// HABL (tools build only, tools/x3_ablate.py h2; non-zero computes garbage): bit0 no patch staging in the loop, bit1 weight fragments
+// loaded once, bit2 A fragments read once, bit3 no fold, bit4 no slab barrier
+template <int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int HABL = 0>
 __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
     constexpr int BM = kPatchRows * kPatchCols;
     constexpr int NW = WARPS_M * WARPS_N;
@@ -226,20 +228,20 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
     auto step = [&](int cc, int t, int SA) __attribute__((always_inline)) {
         const bool fresh = t == 0 || t == 4;                         // chains: taps 0..3 and 4..8 of the slab
         const int t2 = (t + 2) % 9;
-        load_b(t2 % 3, cc + (t + 2 >= 9 ? 1 : 0), t2);
-        if (t < 8) load_a(SA ^ 1, cc, t + 1);
+        if (!(HABL & 2)) load_b(t2 % 3, cc + (t + 2 >= 9 ? 1 : 0), t2);
+        if (t < 8 && !(HABL & 4)) load_a(SA ^ 1, cc, t + 1);
         // staging of slab cc+1: round 0 fetched at tap 0 and written at tap 2, round 1 fetched at tap 3 and written at tap 5
         // (past the last slab the loads run into the next pixel's channels or return zeros: written to the idle stage, never read)
-        if (t == 0) stage_load_x(cc + 1, 0);
-        if (t == 3) stage_load_x(cc + 1, 1);
+        if (t == 0 && !(HABL & 1)) stage_load_x(cc + 1, 0);
+        if (t == 3 && !(HABL & 1)) stage_load_x(cc + 1, 1);
         const int SB = t % 3;
         if (NPROD == 4) product(SA, SB, 1, 1, fresh);                // lo * lo
         product(SA, SB, 1, 0, fresh && NPROD == 3);                  // lo * hi
         product(SA, SB, 0, 1, false);                                // hi * lo
         product(SA, SB, 0, 0, false);                                // hi * hi
-        if (t == 2) stage_store(cc + 1, 0);
-        if (t == 5) stage_store(cc + 1, 1);
-        if (t == 3 || t == 8) {
+        if (t == 2 && !(HABL & 1)) stage_store(cc + 1, 0);
+        if (t == 5 && !(HABL & 1)) stage_store(cc + 1, 1);
+        if ((t == 3 || t == 8) && !(HABL & 8)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -247,8 +249,8 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
         }
     };
     auto slab = [&](int cc, int S0) __attribute__((always_inline)) {  // S0 = A register set of tap 0 = cc & 1 (9 taps: parity flips per slab)
-        __syncthreads();                                             // patch(cc) complete and visible; slab cc-1 fully read
-        load_a(S0, cc, 0);
+        if (!(HABL & 16)) __syncthreads();                           // patch(cc) complete and visible; slab cc-1 fully read
+        if (!(HABL & 4) || cc == 0) load_a(S0, cc, 0);
         step(cc, 0, S0); step(cc, 1, S0 ^ 1); step(cc, 2, S0);
         step(cc, 3, S0 ^ 1); step(cc, 4, S0); step(cc, 5, S0 ^ 1);
         step(cc, 6, S0); step(cc, 7, S0 ^ 1); step(cc, 8, S0);
@@ -259,6 +261,8 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
     stage_load_x(0, 1); stage_store(0, 1);
     load_b(0, 0, 0);
     load_b(1, 0, 1);
+    if (HABL & 2) load_b(2, 0, 2);
+    if (HABL & 4) { __syncthreads(); load_a(0, 0, 0); load_a(1, 0, 1); }
     int cc = 0;
     for (; cc + 2 <= ncc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
     if (cc < ncc) slab(cc, 0);
@@ -275,13 +279,13 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
                                                [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
 }
 
-template <int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE>
+template <int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int HABL = 0>
 __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2)   // three workgroups per CU with 64-wide tiles (768 tiles = 3 per CU on the ResnetBlock layers)
 void conv_h2_kernel(H2Args a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
     const int tile_m = bid / a.tiles_n;
-    h2_tile<BN, WARPS_M, WARPS_N, NPROD, AFFINE>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+    h2_tile<BN, WARPS_M, WARPS_N, NPROD, AFFINE, HABL>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
 }
 
 // OIHW fp32 -> two fp16 planes of w * scale in the fragment order of pack_weights_x3_kernel:

@@ -39,6 +39,10 @@ struct X3Args {
     float* fin_alpha; float* fin_beta; int* fin_counter; int fin_S; float fin_eps;
 };
 
+#ifndef TSNET_DRAIN_VMEM
+#define TSNET_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 #ifndef TSNET_MFMA_BF16
 typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
 #define TSNET_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tsnet_bf16x8, a), __builtin_bit_cast(tsnet_bf16x8, b), c, 0, 0, 0)
@@ -119,7 +123,10 @@ __device__ __forceinline__ void x3_epilogue(const Args& a, f32x16 (&tot)[MT][NTL
             const int img = (int)(stat_tile / (size_t)S);
             int* counter = a.fin_counter + (size_t)img * ((a.Npad + 31) / 32) + n0 / 32;   // 32 = narrowest tile
             int* flag = reinterpret_cast<int*>(smem_raw + 8192);
-            TSNET_VMCNT(0);
+            // Hand-off form (MI355X_MICROARCH.md, "valid forms"): 8-byte agent-scope atomics on BOTH sides (write-through sc1 stores
+            // above, sc1 loads below: never served from a stale L1 / another XCD's L2), the producer's stores drained before it
+            // counts itself.  The drain is inline asm on purpose: the compiler may drop a builtin s_waitcnt it can prove redundant.
+            TSNET_DRAIN_VMEM();
             __syncthreads();
             if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();

@@ -107,6 +107,13 @@ struct Ctx {            // what a launch helper needs
     int lane = 0;       // 0 = the caller's stream; 1 = the engine's side stream (own statistics scratch, see tsnet_forward)
 };
 
+// Scope guard of a fork onto the engine's side stream: if the scope is left before the explicit join (an exception between fork
+// and join), the caller's stream still waits for whatever the side lane has in flight.
+struct SideJoin {
+    hipStream_t side, main; hipEvent_t ev; bool done = false;
+    ~SideJoin() { if (!done && side && hipEventRecord(ev, side) == hipSuccess) (void)hipStreamWaitEvent(main, ev, 0); }
+};
+
 struct TimeScope {
     Ctx& c;
     TimeScope(Ctx& c_, int cls) : c(c_) { if (c.timing) c.timing->begin(cls, c.stream); }
@@ -142,6 +149,7 @@ struct ConvLayer {
     const float* wh_unscale = nullptr;    // device scalar 2^-sw (in the packed buffer: replicas receive it with the broadcast)
 };
 
+constexpr size_t kFinCounterInts = 65536;   // size of the arrival-counter arrays of the in-kernel statistics finalize
 constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded to an even number of 16-deep chunks (ring prefetch may run one past the end)
 constexpr int FLUSH_K = 64;      // fold the MFMA chain into the running total every 64 products (conv_igemm.hpp)
 
@@ -253,18 +261,28 @@ int launch_dma_ks(DmaArgs a, int forced_tile, hipStream_t s) {   // returns stat
 // ---- bf16x3 kernel (conv_x3.hpp)
 struct XTileCfg { int bm, bn, wm, wn, kc, nstage; double eff; bool patch = false; };
 // eff: per-tile efficiency relative to 128x128 measured by tools/conv_sweep.py (profiles/round1_notes.md); 0 = sweep only
-const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, 1.0}, {128, 128, 2, 2, 1, 4, 0.0}, {128, 128, 2, 2, 2, 3, 0.0},
-                            {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, 0.55}, {64, 64, 2, 2, 1, 4, 0.52},
-                            {64, 128, 2, 2, 1, 4, 0.62}, {96, 128, 1, 4, 1, 3, 0.81}, {128, 32, 4, 1, 1, 4, 0.3},
+// Tiles 0..13 are the superseded generations (conv_x3.hpp LDS-DMA tiles, conv_x3p.hpp x3p / mixed launch): kept for the sweep and
+// ablation tools, compiled only into the tools build (-DTSNET_TOOLS -> lib/libtsnet_tools.so); the product library has 14..17.
+#ifdef TSNET_TOOLS
+#define TSNET_OLD_EFF(x) (x)
+#else
+#define TSNET_OLD_EFF(x) 0.0
+#endif
+const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, TSNET_OLD_EFF(1.0)}, {128, 128, 2, 2, 1, 4, 0.0}, {128, 128, 2, 2, 2, 3, 0.0},
+                            {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, TSNET_OLD_EFF(0.55)}, {64, 64, 2, 2, 1, 4, TSNET_OLD_EFF(0.52)},
+                            {64, 128, 2, 2, 1, 4, TSNET_OLD_EFF(0.62)}, {96, 128, 1, 4, 1, 3, TSNET_OLD_EFF(0.81)}, {128, 32, 4, 1, 1, 4, TSNET_OLD_EFF(0.3)},
                             {128, 128, 4, 2, 1, 3, 0.0}, {128, 128, 2, 4, 1, 3, 0.0},
                             // conv_x3p.hpp, LDS-resident input patch.  11-13: x3p (weights through an LDS-DMA ring; 13 = mixed
-                            // 128/64 launch), kept for the sweep / ablation tools.  14, 15: x3q (weights in registers), the default
+                            // 128/64 launch).  14, 15: x3q (weights in registers), the default for 3x3 / stride 1 on the bf16x3 schedule
                             {128, 128, 2, 2, 1, 3, 0.0, true}, {128, 64, 2, 2, 1, 3, 0.0, true}, {128, 128, 2, 2, 1, 3, 0.0, true},
                             {128, 128, 2, 2, 1, 3, 1.4, true}, {128, 64, 2, 2, 1, 3, 1.25, true},
                             // 16, 17: conv_x3r.hpp (register-staged A tile, weights in registers), same arithmetic as 0..10
-                            {128, 128, 2, 2, 1, 2, 1.02}, {128, 64, 2, 2, 1, 2, 0.75}};
-constexpr int kNumXTiles = 18;
+                            {128, 128, 2, 2, 1, 2, 1.02}, {128, 64, 2, 2, 1, 2, 0.75},
+                            // 18: conv_x3r.hpp with 32-wide tiles (narrow layers: Cout <= 32)
+                            {128, 32, 4, 1, 1, 2, 0.3}};
+constexpr int kNumXTiles = 19;
 
+#ifdef TSNET_TOOLS
 template <int KS, int BM, int BN, int WM_, int WN_, int KC, int NST>
 void launch_x3_t(const X3Args& a, hipStream_t s) {
     const size_t lds = (size_t)NST * ((size_t)KC * 3 * (BM + BN) * 32 + 1024);
@@ -274,6 +292,8 @@ void launch_x3_t(const X3Args& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
 }
 
+#endif
+
 // conv_x3p.hpp applies to 3x3 / stride 1 / pad 1 layers whose output splits into 4 x 32 rectangles
 template <int KS>
 bool x3p_ok(const X3Args& a) {
@@ -281,6 +301,7 @@ bool x3p_ok(const X3Args& a) {
            a.Ho % kPatchRows == 0 && a.Wo % kPatchCols == 0 && a.H == a.Ho && a.W == a.Wo;
 }
 
+#ifdef TSNET_TOOLS
 template <int BN, int WM_, int WN_>
 void launch_x3p(const X3Args& a, hipStream_t s) {
     const size_t lds = 2 * 3 * 7 * 1024 + 3 * 3 * (size_t)BN * 32 + 1024;
@@ -289,12 +310,15 @@ void launch_x3p(const X3Args& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
+#endif
+
 template <int BN, int WM_, int WN_>
 void launch_x3q(const X3Args& a, hipStream_t s) {
     const size_t lds = 2 * 3 * 7 * 1024 + 1024;
     hipLaunchKernelGGL((conv_x3q_kernel<BN, WM_, WN_>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
+#ifdef TSNET_TOOLS
 // a.tiles_n counts 128-wide units; the last `nsplit` units run as two 128 x 64 halves (conv_x3p_mixed_kernel)
 void launch_x3p_mixed(const X3Args& a, int nsplit, hipStream_t s) {
     const size_t lds = 2 * 3 * 7 * 1024 + 3 * 3 * (size_t)128 * 32 + 1024;
@@ -303,6 +327,8 @@ void launch_x3p_mixed(const X3Args& a, int nsplit, hipStream_t s) {
     hipLaunchKernelGGL(conv_x3p_mixed_kernel, dim3(nbig + 2 * nsplit), dim3(256), lds, s, a, nbig);
 }
 
+#endif
+
 template <int KS, int BN, int WM_, int WN_>
 void launch_x3r(const X3Args& a, hipStream_t s) {
     const size_t lds = 2 * 3 * 128 * 32;
@@ -310,6 +336,7 @@ void launch_x3r(const X3Args& a, hipStream_t s) {
     else hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
+#ifdef TSNET_TOOLS
 template <int QABL>
 void launch_x3q_abl(X3Args a, hipStream_t s) {    // diagnostic: x3q kernel, 128x64 tiles (the ResnetBlock configuration)
     a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.Cout + 63) / 64;
@@ -333,6 +360,8 @@ void launch_x3_abl(X3Args a, hipStream_t s) {     // diagnostic: 3x3, tile 0 (12
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
+
+#endif
 
 template <int KS>
 int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stats partials per image (0 = none)
@@ -359,6 +388,7 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         throw ArgError("conv(x3): no tile configuration");
     // tile 13 (sweep tool only): x3p launch with the last third of the 128-wide units cut into two 128 x 64 halves
     const int mixed_split = best == 13 ? (int)(((a.M + 127) / 128) * ((a.Cout + 127) / 128) / 3) : 0;
+    (void)mixed_split;
     a.tiles_m = (a.M + kXTiles[best].bm - 1) / kXTiles[best].bm;
     a.tiles_n = (a.Cout + kXTiles[best].bn - 1) / kXTiles[best].bn;
     const int hw = a.Ho * a.Wo;
@@ -366,9 +396,10 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
     // few tiles per image: the last workgroup of each (image, channel tile) finalises the statistics (x3_epilogue);
     // many tiles per image (the 128^2 / 256^2 layers): a serial tail of hundreds of partials would cost more than the
     // in_finalize2 launch it saves.  The mixed x3p launch (tile 13) has two tile widths per launch: not counted.
-    if (!a.stat_part || hw / kXTiles[best].bm > 32 || best == 13 || (size_t)a.N * ((a.Npad + 31) / 32) > 65536) a.fin_counter = nullptr;
+    if (!a.stat_part || hw / kXTiles[best].bm > 32 || best == 13 || (size_t)a.N * ((a.Npad + 31) / 32) > kFinCounterInts) a.fin_counter = nullptr;
     a.fin_S = hw / kXTiles[best].bm;
     switch (best) {
+#ifdef TSNET_TOOLS
         case 0: launch_x3_t<KS, 128, 128, 2, 2, 1, 3>(a, s); break;
         case 1: launch_x3_t<KS, 128, 128, 2, 2, 1, 4>(a, s); break;
         case 2: launch_x3_t<KS, 128, 128, 2, 2, 2, 3>(a, s); break;
@@ -378,15 +409,18 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         case 6: launch_x3_t<KS, 64, 128, 2, 2, 1, 4>(a, s); break;
         case 7: launch_x3_t<KS, 96, 128, 1, 4, 1, 3>(a, s); break;
         case 8: launch_x3_t<KS, 128, 32, 4, 1, 1, 4>(a, s); break;
+        case 9: launch_x3_t<KS, 128, 128, 4, 2, 1, 3>(a, s); break;
+        case 10: launch_x3_t<KS, 128, 128, 2, 4, 1, 3>(a, s); break;
         case 11: launch_x3p<128, 2, 2>(a, s); break;
         case 12: launch_x3p<64, 2, 2>(a, s); break;
         case 13: launch_x3p_mixed(a, mixed_split, s); break;
-        case 16: launch_x3r<KS, 128, 2, 2>(a, s); break;
-        case 17: launch_x3r<KS, 64, 2, 2>(a, s); break;
+#endif
         case 14: launch_x3q<128, 2, 2>(a, s); break;
         case 15: launch_x3q<64, 2, 2>(a, s); break;
-        case 9: launch_x3_t<KS, 128, 128, 4, 2, 1, 3>(a, s); break;
-        default: launch_x3_t<KS, 128, 128, 2, 4, 1, 3>(a, s); break;
+        case 16: launch_x3r<KS, 128, 2, 2>(a, s); break;
+        case 17: launch_x3r<KS, 64, 2, 2>(a, s); break;
+        case 18: launch_x3r<KS, 32, 4, 1>(a, s); break;
+        default: throw ArgError("conv(x3): this tile is only built into the tools library (superseded kernel generation)");
     }
     if (a.stat_part && a.fin_counter) return -1;     // statistics complete: alpha / beta written by the kernel
     return a.stat_part ? hw / kXTiles[best].bm : 0;
@@ -424,6 +458,7 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
     TimeScope ts(ctx, c.tclass);
     const int forced = c.variant >= 0 ? (c.variant & 63) : -1;
     const int abl = c.variant >= 0 ? (c.variant >> 16) & 127 : 0;
+#ifdef TSNET_TOOLS
     if (abl && L.ks == 3 && forced == 15) {
         if (!x3p_ok<3>(g)) throw ArgError("ablation: layer not eligible for the patch kernel");
         switch (abl) {
@@ -473,6 +508,9 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
         check_launch("conv_x3(abl)");
         return;
     }
+#else
+    if (abl) throw ArgError("ablation variants are only built into the tools library");
+#endif
     switch (L.ks) {
         case 1: c.stat_S = launch_x3_ks<1>(g, forced, ctx.stream); break;
         case 3: c.stat_S = launch_x3_ks<3>(g, forced, ctx.stream); break;
@@ -494,6 +532,7 @@ struct H2Call {
     double* stat_part = nullptr; mutable int stat_S = 0;
     float* fin_alpha = nullptr; float* fin_beta = nullptr; int* fin_counter = nullptr;
     int nprod = 3, bn = 0;      // products per k-group (3; 4 adds lo*lo), tile width (0 = heuristic)
+    int abl = 0;                // tools build: ablation mask of h2_tile (computes garbage)
     int tclass = TSNET_T_CONV;
 };
 
@@ -534,14 +573,40 @@ void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
     if ((double)c.N * c.H * c.W * L.cin_pad * 4 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
         throw ArgError("conv(h2): tensor too large for 32-bit buffer offsets");
     if ((size_t)2 * g.Cin * 4 + 2 * 2 * 7168 + 2048 > 64 * 1024) throw ArgError("conv(h2): too many input channels for the transform table");
-    int bn = c.bn ? c.bn : 64;
+    int bn = c.bn;
+    if (bn == 0) {
+        // 256 CUs each run ceil(tiles / 256) tiles (co-resident workgroups share the MFMA pipe): minimise that count x tile area / efficiency.
+        // 128-wide tiles (wave tile 64 x 64) move half the LDS / L1 bytes per MFMA: measured 1.07-1.15x per unit area without the
+        // fused transform, 1.03x with it (tools/conv_sweep.py h2, profiles/round2_notes.md); the 384-tile ResnetBlock layers at
+        // batch 4 are the case where 768 64-wide tiles = exactly three per CU win.
+        const long tm = g.M / 128;
+        const double c64 = (double)((tm * ((g.Cout + 63) / 64) + 255) / 256) * 64.0;
+        const double c128 = (double)((tm * ((g.Cout + 127) / 128) + 255) / 256) * 128.0 / (c.alpha ? 1.03 : 1.10);
+        bn = (g.Npad % 128 == 0 && g.Cout > 64 && c128 < c64) ? 128 : 64;
+    }
     if (bn != 64 && bn != 128) throw ArgError("conv(h2): tile width must be 64 or 128");
     if (g.Npad % bn) bn = 64;
     g.tiles_m = g.M / 128; g.tiles_n = (g.Cout + bn - 1) / bn;
     const int hw = g.Ho * g.Wo;
     g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f; g.fin_S = hw / 128;
-    g.fin_counter = (c.stat_part && c.fin_counter && hw / 128 <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= 65536) ? c.fin_counter : nullptr;
+    g.fin_counter = (c.stat_part && c.fin_counter && hw / 128 <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= kFinCounterInts) ? c.fin_counter : nullptr;
     TimeScope ts(ctx, c.tclass);
+    if (c.abl) {
+#ifdef TSNET_TOOLS
+        const size_t lds = 2 * 2 * 7168 + 2048 + (size_t)2 * g.Cin * 4;
+        g.tiles_n = (g.Cout + 63) / 64;
+#define TSNET_H2_ABL(m) case m: hipLaunchKernelGGL((conv_h2_kernel<64, 2, 2, 3, false, m>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, ctx.stream, g); break;
+        switch (c.abl) {
+            TSNET_H2_ABL(1) TSNET_H2_ABL(2) TSNET_H2_ABL(3) TSNET_H2_ABL(4) TSNET_H2_ABL(6) TSNET_H2_ABL(7) TSNET_H2_ABL(8) TSNET_H2_ABL(15) TSNET_H2_ABL(16) TSNET_H2_ABL(31)
+            default: throw ArgError("unsupported ablation mask");
+        }
+#undef TSNET_H2_ABL
+        check_launch("conv_h2(abl)");
+        return;
+#else
+        throw ArgError("ablation variants are only built into the tools library");
+#endif
+    }
     if (c.nprod == 3) { if (bn == 64) launch_h2<64, 3>(g, ctx.stream); else launch_h2<128, 3>(g, ctx.stream); }
     else if (c.nprod == 4) { if (bn == 64) launch_h2<64, 4>(g, ctx.stream); else launch_h2<128, 4>(g, ctx.stream); }
     else throw ArgError("conv(h2): 3 or 4 products");
@@ -810,6 +875,7 @@ struct tsnet_engine {
     const float* cached_bbox[TSNET_MAX_SOURCES] = {nullptr};
     float* bbox_copy = nullptr;     // (K, Bmax, H, W) device copies of the source bboxes
     int last_B = 0;
+    float src_div[TSNET_MAX_SOURCES];  // per-source image divisor (255; 1 for use_prev sources), tsnet_set_source_divisors
 
     Timing timing;
 
@@ -1088,13 +1154,15 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     size_t o = 0;
     for (auto& r : req) { *r.first = arena + o; o += r.second; }
     part = reinterpret_cast<double*>(part_f);
-    HIP_TRY(hipMalloc((void**)&fin_counter, 65536 * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(fin_counter, 0, 65536 * sizeof(int), s));
+    // arrival counters: one per (image, 32-channel group) of a launch; launches with more (image, group) pairs than kFinCounterInts
+    // fall back to the in_finalize2 kernel (launch_x3_ks / run_conv_h2 check the index range against this size)
+    HIP_TRY(hipMalloc((void**)&fin_counter, kFinCounterInts * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(fin_counter, 0, kFinCounterInts * sizeof(int), s));
     if (x3) {      // side lane (tsnet_forward): own statistics scratch, counters, (alpha, beta) pairs, stream and events
         const size_t part_bytes = (size_t)2 * std::max((size_t)NB * 64 * 2 * C * 2, (size_t)NB * H * W * cfg.ngf / 32 + 1024) * sizeof(float);
         HIP_TRY(hipMalloc((void**)&part_side, part_bytes));
-        HIP_TRY(hipMalloc((void**)&fin_counter_side, 65536 * sizeof(int)));
-        HIP_TRY(hipMemsetAsync(fin_counter_side, 0, 65536 * sizeof(int), s));
+        HIP_TRY(hipMalloc((void**)&fin_counter_side, kFinCounterInts * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(fin_counter_side, 0, kFinCounterInts * sizeof(int), s));
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < 2; ++j) HIP_TRY(hipMalloc((void**)&ab_side[i][j], (size_t)NB * 2 * C * sizeof(float)));
         HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
@@ -1223,6 +1291,7 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
     const bool fork = overlap && side_stream && !ctx.timing && ctx.lane == 0;
     Ctx cside; cside.stream = side_stream; cside.lane = 1;
     Ctx& cx = fork ? cside : ctx;
+    SideJoin join2{fork ? side_stream : nullptr, ctx.stream, ev_join2};
     if (fork) {
         HIP_TRY(hipEventRecord(ev_fork2, ctx.stream));
         HIP_TRY(hipStreamWaitEvent(side_stream, ev_fork2, 0));
@@ -1267,6 +1336,7 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
 
     // ---- decoder
     if (fork) HIP_TRY(hipStreamWaitEvent(ctx.stream, ev_join2, 0));
+    join2.done = true;
     {
         X3Call a; a.x3 = pg3; a.x23 = sg3; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
         a.y3 = cfg.n_blocks > 0 ? D3 : nullptr;
@@ -1353,7 +1423,7 @@ void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const floa
     {
         TimeScope ts(ctx, TSNET_T_PACK);
         PackArgs p{};
-        for (int s = 0; s < K; ++s) { p.img[s] = src_img[s]; p.lbl[s] = src_lbl[s]; }
+        for (int s = 0; s < K; ++s) { p.img[s] = src_img[s]; p.lbl[s] = src_lbl[s]; p.img_div[s] = src_div[s]; }
         p.coords = cfg.addcoords ? d_coords : nullptr;
         p.out = x3 ? nullptr : x_img; p.out3 = x3 ? x_img3 : nullptr;
         p.S = K; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 3; p.Cp = cp_img;
@@ -1500,6 +1570,7 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
         tsnet_engine* e = new tsnet_engine();
         e->cfg = *cfg;
         e->K = cfg->n_source; e->Bmax = cfg->max_batch;
+        for (int s = 0; s < TSNET_MAX_SOURCES; ++s) e->src_div[s] = 255.0f;
         e->C = cfg->ngf << cfg->n_downsampling;
         e->h = cfg->height / ds; e->w = cfg->width / ds; e->P = e->h * e->w;
         e->build_layers();
@@ -1590,6 +1661,18 @@ static void check_forward_args(tsnet_handle h, int B) {
     if (B < 1 || B > h->Bmax) throw ArgError("batch size outside 1..max_batch");
 }
 
+int tsnet_set_source_divisors(tsnet_handle h, const float* div, int n) {
+    API_BEGIN(h)
+    if (n < 0 || n > TSNET_MAX_SOURCES || (n > 0 && !div)) throw ArgError("set_source_divisors: bad argument");
+    for (int s = 0; s < TSNET_MAX_SOURCES; ++s) {
+        const float d = s < n ? div[s] : 255.0f;
+        if (!(d > 0.f) || !std::isfinite(d)) throw ArgError("set_source_divisors: divisors must be positive and finite");
+        h->src_div[s] = d;
+    }
+    h->cached_B = 0;                   // cached source features were encoded with the previous divisors
+    API_END(h)
+}
+
 int tsnet_set_sources(tsnet_handle h, const float* const* src_img, const float* const* src_lbl,
                       const float* const* src_bbox, int B, void* stream) {
     API_BEGIN(h)
@@ -1626,10 +1709,14 @@ int tsnet_forward(tsnet_handle h, const float* const* src_img, const float* cons
         HIP_TRY(hipEventRecord(h->ev_fork, main));
         HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
         Ctx cs; cs.stream = h->side_stream; cs.lane = 1;
+        // from here on the side lane has work in flight: whatever happens below (an exception included), the caller's stream waits
+        // for it before this call returns -- the side lane must not outlive the call
+        SideJoin join{h->side_stream, main, h->ev_join};
         h->target_chain_x3(cs, tar_lbl, B);
         HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
         const int rc = tsnet_set_sources(h, src_img, src_lbl, src_bbox, B, stream);
-        HIP_TRY(hipStreamWaitEvent(main, h->ev_join, 0));        // also on the error path: the side lane must not outlive the call
+        HIP_TRY(hipStreamWaitEvent(main, h->ev_join, 0));
+        join.done = true;
         if (rc != TSNET_OK) return rc;
         Ctx ctx; ctx.stream = main;
         h->forward_rest_x3(ctx, tar_bbox, out_rgb, out_flow, B);
@@ -1660,7 +1747,7 @@ int tsnet_train_extras(tsnet_handle h, const float* const* src_img, const float*
     double* l1_part = reinterpret_cast<double*>(h->train_ws + nfp); double* cos_part = l1_part + (size_t)h->K * h->Bmax * 3 * chunks;
 
     PatchWarpArgs pa{};
-    for (int s = 0; s < K; ++s) pa.src[s] = src_img[s];
+    for (int s = 0; s < K; ++s) { pa.src[s] = src_img[s]; pa.div[s] = h->src_div[s]; }
     pa.flow = h->flow; pa.out = warp_src_img; pa.K = K; pa.B = B; pa.H = H; pa.W = W; pa.h = hh; pa.w = ww; pa.down = H / hh;
     hipLaunchKernelGGL(patch_warp_kernel, dim3(ew_grid((size_t)N * HW)), dim3(256), 0, st, pa);
     check_launch("patch_warp");
@@ -1992,7 +2079,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
         }
         L.wh = wh; L.wh_unscale = un;
         H2Call hc; hc.x = x; hc.N = N; hc.H = H; hc.W = W; hc.y = y; hc.bound = norm ? 64.f : 1.f;
-        hc.bn = (variant & 1) ? 128 : 64; hc.nprod = (variant & 4) ? 4 : 3;
+        hc.bn = (variant & 1) ? 128 : 64; hc.nprod = (variant & 4) ? 4 : 3; hc.abl = (variant >> 16) & 127;
         if (norm) { hc.alpha = al; hc.beta = be; hc.relu = 1; }
         for (int i = 0; i < 2; ++i) run_conv_h2(ctx, L, hc);
         hipEvent_t e0, e1;

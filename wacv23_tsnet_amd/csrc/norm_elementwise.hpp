@@ -295,6 +295,7 @@ struct PackArgs {
     float* out;            // (S*B, H, W, Cp) fp32 or null
     int S, B, H, W, L, nimg, Cp;
     unsigned short* out3;  // null, or bf16x3 planes of the packed input
+    float img_div[8];      // per source: 255 (set_test_input's /255, TSNet.py:286) or 1 (use_prev: a frame already in [0,1], TSNet.py:269-276)
 };
 
 __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
             for (int e = 0; e < 4; ++e) {
                 const int c = c0 + e;
                 float t = 0.f;
-                if (c < a.nimg) t = a.img[s][((size_t)b * a.nimg + c) * HW + pix] / 255.0f;
+                if (c < a.nimg) t = a.img[s][((size_t)b * a.nimg + c) * HW + pix] / a.img_div[s];
                 else if (c < a.nimg + a.L) t = a.lbl[s][((size_t)b * a.L + (c - a.nimg)) * HW + pix];
                 else if (c < creal) t = a.coords[pix * 3 + (c - a.nimg - a.L)];
                 v[e] = t;

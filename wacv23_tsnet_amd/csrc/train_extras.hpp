@@ -20,6 +20,7 @@ struct PatchWarpArgs {
     const float* flow;     // (K*B, P, 2), n = s*B + b
     float* out;            // (K, B, 3, H, W)
     int K, B, H, W, h, w, down;
+    float div[8];          // per source: 255, or 1 for a source that is already in [0,1] (use_prev, TSNet.py:269-276)
 };
 
 // one thread per output pixel (s, b, Y, X), three channels
@@ -44,14 +45,15 @@ __global__ __launch_bounds__(256) void patch_warp_kernel(PatchWarpArgs a) {
         const bool xin0 = x0 >= 0 && x0 < a.w, xin1 = x1 >= 0 && x1 < a.w;
         const bool yin0 = y0 >= 0 && y0 < a.h, yin1 = y1 >= 0 && y1 < a.h;
         const float* img = a.src[s] + (size_t)b * 3 * HW;
+        const float dv = a.div[s];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float* pl = img + (size_t)c * HW;
             float v = 0.f;
-            if (yin0 && xin0) v = (pl[(size_t)(y0 * a.down + dy) * a.W + x0 * a.down + dx] / 255.0f) * wnw;
-            if (yin0 && xin1) v = __builtin_fmaf(pl[(size_t)(y0 * a.down + dy) * a.W + x1 * a.down + dx] / 255.0f, wne, v);
-            if (yin1 && xin0) v = __builtin_fmaf(pl[(size_t)(y1 * a.down + dy) * a.W + x0 * a.down + dx] / 255.0f, wsw, v);
-            if (yin1 && xin1) v = __builtin_fmaf(pl[(size_t)(y1 * a.down + dy) * a.W + x1 * a.down + dx] / 255.0f, wse, v);
+            if (yin0 && xin0) v = (pl[(size_t)(y0 * a.down + dy) * a.W + x0 * a.down + dx] / dv) * wnw;
+            if (yin0 && xin1) v = __builtin_fmaf(pl[(size_t)(y0 * a.down + dy) * a.W + x1 * a.down + dx] / dv, wne, v);
+            if (yin1 && xin0) v = __builtin_fmaf(pl[(size_t)(y1 * a.down + dy) * a.W + x0 * a.down + dx] / dv, wsw, v);
+            if (yin1 && xin1) v = __builtin_fmaf(pl[(size_t)(y1 * a.down + dy) * a.W + x1 * a.down + dx] / dv, wse, v);
             a.out[((size_t)n * 3 + c) * HW + pix] = v;
         }
     }

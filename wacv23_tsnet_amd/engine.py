@@ -25,6 +25,14 @@ def _stream_of(t: torch.Tensor) -> Optional[int]:
     return None
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class TSNetEngine:
     """One model replica on one device.
 
@@ -54,15 +62,31 @@ class TSNetEngine:
         if rc != 0:
             raise RuntimeError(f"tsnet_create failed ({rc}): {self.lib.tsnet_last_error(None).decode()}")
         self.finalized = False
+        self.device: Optional[torch.device] = None     # fixed at finalize(): every allocation, stream and launch of this handle lives there
 
     # ------------------------------------------------------------------ helpers
+    def _on_device(self, dev=None):
+        """Context that makes the engine's GPU the current HIP device for the duration of an ABI call.  The library allocates
+        (hipMalloc), creates its side stream / events and launches on the CURRENT device; the caller's current device may be
+        another one (model on cuda:1, torch.cuda.current_device() == 0)."""
+        d = torch.device(dev) if dev is not None else self.device
+        if d is not None and d.type == "cuda":
+            return torch.cuda.device(d)
+        return _NullCtx()
+
+    def _same_device(self, *tensors):
+        for t in tensors:
+            if t is not None and self.device is not None and t.device != self.device:
+                raise ValueError(f"tensor on {t.device}, engine finalized on {self.device}")
+
     def _check(self, rc: int, what: str):
         if rc != 0:
             raise RuntimeError(f"{what} failed ({rc}): {self.lib.tsnet_last_error(self._h).decode()}")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self.lib.tsnet_destroy(self._h)
+            with self._on_device():
+                self.lib.tsnet_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -94,14 +118,20 @@ class TSNetEngine:
                 continue
             t = v.detach().to(torch.float32).contiguous()
             shp = (C.c_int64 * t.dim())(*t.shape)
-            self._check(self.lib.tsnet_load_weights(self._h, k.encode(), t.data_ptr(), shp, t.dim()), f"load_weights({k})")
-            if t.is_cuda:
+            if t.is_cuda:      # the cast / copy above is queued on torch's stream; tsnet_load_weights does a blocking hipMemcpy on the null stream
                 torch.cuda.current_stream(t.device).synchronize()
+            with self._on_device(t.device if t.is_cuda else None):
+                self._check(self.lib.tsnet_load_weights(self._h, k.encode(), t.data_ptr(), shp, t.dim()), f"load_weights({k})")
         return self
 
     def finalize(self, device: Optional[torch.device] = None):
-        stream = torch.cuda.current_stream(device).cuda_stream if (device is not None and torch.device(device).type == "cuda") else None
-        self._check(self.lib.tsnet_finalize(self._h, stream), "tsnet_finalize")
+        dev = torch.device(device) if device is not None else None
+        if dev is not None and dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        stream = torch.cuda.current_stream(dev).cuda_stream if (dev is not None and dev.type == "cuda") else None
+        with self._on_device(dev):
+            self._check(self.lib.tsnet_finalize(self._h, stream), "tsnet_finalize")
+        self.device = dev
         self.finalized = True
         return self
 
@@ -109,7 +139,8 @@ class TSNetEngine:
         """Alias the engine's packed weight buffer as a flat uint8 torch tensor (for the RCCL broadcast)."""
         p = C.c_void_p()
         n = C.c_size_t()
-        self._check(self.lib.tsnet_packed_weights(self._h, C.byref(p), C.byref(n)), "tsnet_packed_weights")
+        with self._on_device():
+            self._check(self.lib.tsnet_packed_weights(self._h, C.byref(p), C.byref(n)), "tsnet_packed_weights")
         return _alias_device_bytes(p.value, n.value, device)
 
     # ------------------------------------------------------------------ forward
@@ -141,11 +172,21 @@ class TSNetEngine:
         tb = self._prep(tar_bbox, (B, H, W), "tar_bbox")
         out = torch.empty((B, 3, H, W), dtype=torch.float32, device=tl.device)
         flow = torch.empty((K, B, self.h, self.w, 2), dtype=torch.float32, device=tl.device) if return_flow else None
-        rc = self.lib.tsnet_forward(self._h, self._ptr_array(si), self._ptr_array(sl), self._ptr_array(sb),
-                                    tl.data_ptr(), tb.data_ptr(), out.data_ptr(), _ptr(flow), B, _stream_of(tl))
+        self._same_device(*si, *sl, *sb, tl, tb)
+        with self._on_device():
+            rc = self.lib.tsnet_forward(self._h, self._ptr_array(si), self._ptr_array(sl), self._ptr_array(sb),
+                                        tl.data_ptr(), tb.data_ptr(), out.data_ptr(), _ptr(flow), B, _stream_of(tl))
         self._check(rc, "tsnet_forward")
         self._keep = (si, sl, sb, tl, tb)   # keep inputs alive until the stream has consumed them
         return out, ([flow[i] for i in range(K)] if return_flow else None)
+
+    def set_source_divisors(self, divisors: Optional[Sequence[float]] = None):
+        """tsnet_set_source_divisors: per-source divisor of the source images on load -- 255 (default: the reference's `/255.0`,
+        TSNet.py:267,286) or 1 for `use_prev` sources that are already in [0,1] (TSNet.py:269-276).  None resets all to 255."""
+        d = list(divisors or [])
+        arr = (C.c_float * max(len(d), 1))(*([float(x) for x in d] or [255.0]))
+        with self._on_device():
+            self._check(self.lib.tsnet_set_source_divisors(self._h, arr, len(d)), "tsnet_set_source_divisors")
 
     def set_sources(self, src_img, src_lbl, src_bbox):
         B = src_img[0].shape[0]
@@ -153,7 +194,9 @@ class TSNetEngine:
         si = [self._prep(src_img[i], (B, 3, H, W), f"src_img[{i}]") for i in range(K)]
         sl = [self._prep(src_lbl[i], (B, L, H, W), f"src_lbl[{i}]") for i in range(K)]
         sb = [self._prep(src_bbox[i], (B, H, W), f"src_bbox[{i}]") for i in range(K)]
-        rc = self.lib.tsnet_set_sources(self._h, self._ptr_array(si), self._ptr_array(sl), self._ptr_array(sb), B, _stream_of(si[0]))
+        self._same_device(*si, *sl, *sb)
+        with self._on_device():
+            rc = self.lib.tsnet_set_sources(self._h, self._ptr_array(si), self._ptr_array(sl), self._ptr_array(sb), B, _stream_of(si[0]))
         self._check(rc, "tsnet_set_sources")
         self._keep_src = (si, sl, sb)
 
@@ -164,7 +207,9 @@ class TSNetEngine:
         tb = self._prep(tar_bbox, (B, H, W), "tar_bbox")
         out = torch.empty((B, 3, H, W), dtype=torch.float32, device=tl.device)
         flow = torch.empty((K, B, self.h, self.w, 2), dtype=torch.float32, device=tl.device) if return_flow else None
-        rc = self.lib.tsnet_forward_target(self._h, tl.data_ptr(), tb.data_ptr(), out.data_ptr(), _ptr(flow), B, _stream_of(tl))
+        self._same_device(tl, tb)
+        with self._on_device():
+            rc = self.lib.tsnet_forward_target(self._h, tl.data_ptr(), tb.data_ptr(), out.data_ptr(), _ptr(flow), B, _stream_of(tl))
         self._check(rc, "tsnet_forward_target")
         self._keep = (tl, tb)
         return out, ([flow[i] for i in range(K)] if return_flow else None)
@@ -179,7 +224,9 @@ class TSNetEngine:
         ti = self._prep(tar_img, (B, 3, H, W), "tar_img")
         warp = torch.empty((K, B, 3, H, W), dtype=torch.float32, device=ti.device)
         losses = torch.empty(2, dtype=torch.float32, device=ti.device)
-        rc = self.lib.tsnet_train_extras(self._h, self._ptr_array(si), ti.data_ptr(), B, warp.data_ptr(), losses.data_ptr(), _stream_of(ti))
+        self._same_device(*si, ti)
+        with self._on_device():
+            rc = self.lib.tsnet_train_extras(self._h, self._ptr_array(si), ti.data_ptr(), B, warp.data_ptr(), losses.data_ptr(), _stream_of(ti))
         self._check(rc, "tsnet_train_extras")
         self._keep_train = (si, ti)
         return [warp[i] for i in range(K)], losses[0], losses[1]

@@ -143,6 +143,7 @@ class TSNet(nn.Module):
         self.loss_warp = self.loss_align = 0.0
         self._engine: Optional[TSNetEngine] = None
         self._engine_key = None
+        self._use_prev = None
 
     # ------------------------------------------------------------------ reference protocol
     def set_test_input(self, src_img_list, src_lbl_list, src_bbox_list, tar_lbl, tar_bbox,
@@ -159,16 +160,20 @@ class TSNet(nn.Module):
         self.tar_bbox = mv(tar_bbox)
         if prev_tar_img is not None:
             self.prev_tar_img, self.prev_tar_lbl, self.prev_tar_bbox = prev_tar_img, prev_tar_lbl, prev_tar_bbox
+        # a test-mode input ends any training-mode state: no stale target frame, no per-source divisors
+        self.tar_img = None
+        self.warp_src_img_list = None
+        self.loss_warp = self.loss_align = 0.0
+        self._use_prev = None
 
     def set_train_input(self, src_img_list, src_lbl_list, src_bbox_list, tar_img, tar_lbl, tar_bbox, use_prev=None):
         """TSNet.set_train_input (TSNet.py:266-281): as set_test_input plus the ground-truth target frame.  forward()
         then also fills warp_src_img_list, loss_warp and loss_align -- the training-mode outputs of the FORWARD
-        (TSNet.py:327-331, 372-390, 402-405).  The GAN / VGG losses and the backward pass are not part of this build;
-        use_prev (sources that are already in [0,1]) is not supported."""
-        if use_prev is not None:
-            raise NotImplementedError("use_prev: previously generated frames as sources are a training-loop feature")
+        (TSNet.py:327-331, 372-390, 402-405).  The GAN / VGG losses and the backward pass are not part of this build.
+        use_prev[i] marks source i as a previously generated frame that is already in [0,1]: it skips the /255 (TSNet.py:269-276)."""
         self.set_test_input(src_img_list, src_lbl_list, src_bbox_list, tar_lbl, tar_bbox)
         self.tar_img = tar_img.to(self._device(), dtype=torch.float32, non_blocking=True)
+        self._use_prev = None if use_prev is None else [bool(x) for x in use_prev]
 
     def set_source_num(self, n_source):
         """TSNet.set_source_num (TSNet.py:296)."""
@@ -181,6 +186,10 @@ class TSNet(nn.Module):
             raise RuntimeError("call set_test_input() before forward()")
         eng = self._get_engine(self.tar_lbl.shape[0])
         K = self.n_source
+        use_prev = getattr(self, "_use_prev", None)
+        if use_prev != getattr(eng, "_use_prev_applied", None):
+            eng.set_source_divisors(None if use_prev is None else [1.0 if p else 255.0 for p in use_prev[:K]])
+            eng._use_prev_applied = use_prev
         rec, flows = eng.forward(self.src_img_list[:K], self.src_lbl_list[:K], self.src_bbox_list[:K],
                                  self.tar_lbl, self.tar_bbox, return_flow=self.return_flow)
         self.rec_tar_img = rec
@@ -242,3 +251,9 @@ class TSNetPose(TSNet):
         super().__init__(*args, **kw)
         self.use_mask = use_mask
         self.mean = tuple(float(x) for x in np.asarray(mean, dtype=np.float32))
+
+    def set_train_input(self, *args, **kw):
+        """The pose model's training-mode forward composites warp_src_img with the fixed foreground mask before the L1 and has no
+        loss_align (TSNet_pose.py:396-404); the engine's train extras implement the face model's (TSNet.py:372-405).  Not built:
+        fail loudly instead of returning the face model's numbers."""
+        raise NotImplementedError("TSNetPose: the training-mode forward extras are built for the face model only; use set_test_input()")
