@@ -191,6 +191,14 @@ int tsnet_demo_postprocess(const float* rec, int B, int H, int W, const float* g
                            const float* ref_mean, const float* ref_std, const float* img_mean_over_255,
                            unsigned char* out_rgb, void* stream);
 
+/* Input rasterisation, one call per clip.
+ * tsnet_raster_face <- FaceDatasetTest.get_face_image + get_bbox_image (dataset/dataset_video_face.py:466-495; utils/keypoint2img.py
+ *                      interp_points :319-354, draw_edge :298-316).  keypoints: (F,68,2) device doubles, (x, y) already relative to
+ *                      the crop (read_keypoints, :497-505); edges / bbox: (F,h,w) device bytes, 0 / 255, either may be NULL.
+ * tsnet_vl2ch       <- utils/misc.py vl2ch (:50-67): labels (B,HW) class indices as floats -> out (B,num_classes,HW) one-hot floats. */
+int tsnet_raster_face(const double* keypoints, int F, int h, int w, int bw, unsigned char* edges, unsigned char* bbox, void* stream);
+int tsnet_vl2ch(const float* labels, int B, int HW, int num_classes, float* out, void* stream);
+
 /* Micro-benchmark of one convolution shape on synthetic (non-zero) data: average milliseconds per
  * launch over `iters` back-to-back launches, hipEvent-timed on `stream`.  variant: -1 = the engine's
  * own tile heuristic, else tile index + 8*(BK==32) (tools/conv_sweep.py).  Diagnostic only. */

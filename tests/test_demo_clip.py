@@ -1,0 +1,46 @@
+"""GPU tier: the clip harness (wacv23_tsnet_amd.demo.ClipRunner; caller pattern of demo/demo_face.py:166-231) drives the real path --
+checkpoint dict -> device rasterisation -> set_sources once -> forward_target per driving frame -> device post-processing -> PNG /
+GIF -- and every frame it produces equals the one-shot forward + post-processing of that frame, byte for byte."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_clip_harness_equals_one_shot_forward(tmp_path):
+    import demo_clip
+    from PIL import Image
+    from wacv23_tsnet_amd import demo, raster
+    from wacv23_tsnet_amd.model import TSNet
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = TSNet(is_train=False, label_nc=2, n_blocks=1, n_downsampling=3, n_source=3)
+    ckpt = {net: getattr(model, net).state_dict() for net in ("img_enc", "lbl_enc", "dec", "fuse_net")}
+    torch.save(ckpt, tmp_path / "TSNet_B0004_S000000.pth")                      # the reference's checkpoint schema (train_face.py:350-355)
+    model.load_checkpoint(torch.load(tmp_path / "TSNet_B0004_S000000.pth", map_location="cpu"))
+    model = model.cuda()
+    K, F = 3, 3
+    kp = demo_clip.synthetic_face_keypoints(K + F)
+    rs = raster.FaceRasteriser(dev)
+    edges, bbox, crop, bw = rs.rasterise(list(kp))
+    lbl, box = rs.vl2ch(demo.resize_nearest(edges), 2), demo.resize_nearest(bbox)
+    assert lbl.shape == (K + F, 2, 256, 256) and torch.equal(lbl.sum(dim=1), torch.ones_like(lbl[:, 0])) and lbl[:, 1].sum() > 1000
+    g = torch.Generator().manual_seed(1)
+    src_img = [(torch.rand((1, 3, 256, 256), generator=g) * 255.0 - torch.from_numpy(demo.IMG_MEAN).view(1, 3, 1, 1)) for _ in range(K)]
+    runner = demo.ClipRunner(model, src_img, [lbl[i:i + 1] for i in range(K)], [box[i:i + 1] for i in range(K)])
+    frames = runner.run(lbl[K:], box[K:], out_dir=str(tmp_path / "out"), name="t")
+    assert frames.shape == (F, 256, 256, 3) and frames.dtype == np.uint8
+    assert Image.open(tmp_path / "out" / "t.gif").n_frames == F
+    strip = np.asarray(Image.open(tmp_path / "out" / "000001_t.png").convert("RGB"))
+    assert strip.shape == (256, 768, 3) and np.array_equal(strip[:, 512:], frames[1])
+    # the reference's protocol for the same frame: set_test_input with the same sources + forward, then the post-processing
+    model.set_test_input([x for x in src_img], [lbl[i:i + 1] for i in range(K)], [box[i:i + 1] for i in range(K)], lbl[K + 1:K + 2], box[K + 1:K + 2])
+    model.forward()
+    want = runner.post(model.rec_tar_img)[0].cpu().numpy()
+    assert np.array_equal(frames[1], want)

@@ -1,0 +1,102 @@
+"""Demo clip harness (the caller pattern of demo/demo_face.py:108-236) on one MI355X:
+
+    checkpoint dict -> TSNet(n_blocks=4) -> key points of a synthetic talking-head clip -> label maps ON THE DEVICE (rank 3 kernels)
+    -> set_sources once -> per driving frame: forward_target (batch 1) + device post-processing -> strips (PNG) + clip (GIF)
+
+and the demo-shaped throughput figure (B=1, n_blocks=4, K=3, clip mode).  No pretrained checkpoint is reachable from this image
+(README.md:36-39 links to Google Drive), so the checkpoint is a randomly initialised generator saved and re-loaded through the
+reference's .pth schema {'img_enc','lbl_enc','dec','fuse_net'} (train_face.py:350-355): the frames are noise, the path is the real one.
+
+    python tools/demo_clip.py --out gpurun_out/demo --frames 16
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from wacv23_tsnet_amd import demo, raster
+from wacv23_tsnet_amd.model import TSNet
+
+
+def synthetic_face_keypoints(n_frames: int, seed: int = 0) -> np.ndarray:
+    """68 landmarks of a schematic face in a 640 x 480 frame (the demo clips' size) that nods and opens its mouth: (F,68,2) integers."""
+    t = np.linspace(0, 2 * np.pi, n_frames, endpoint=False)
+    out = np.zeros((n_frames, 68, 2))
+    for f, ph in enumerate(t):
+        cx, cy, s = 320 + 12 * np.sin(ph), 240 + 8 * np.cos(ph), 70.0
+        a = np.linspace(np.pi * 0.05, np.pi * 0.95, 17)
+        out[f, 0:17] = np.stack([cx - 1.05 * s * np.cos(a), cy - 0.1 * s + 1.25 * s * np.sin(a)], 1)          # contour
+        for k, (x0, x1) in enumerate(((-0.8, -0.2), (0.2, 0.8))):                                            # eyebrows
+            xs = np.linspace(x0, x1, 5)
+            out[f, 17 + 5 * k:22 + 5 * k] = np.stack([cx + s * xs, cy - 0.55 * s - 0.12 * s * np.sin(np.pi * (xs - x0) / (x1 - x0))], 1)
+        out[f, 27:31] = np.stack([np.full(4, cx), cy - 0.35 * s + np.linspace(0, 0.45 * s, 4)], 1)           # nose bridge
+        out[f, 31:36] = np.stack([cx + s * np.linspace(-0.22, 0.22, 5), cy + 0.2 * s + 0.05 * s * np.sin(np.linspace(0, np.pi, 5))], 1)
+        for k, ex in enumerate((-0.5, 0.5)):                                                                 # eyes
+            ang = np.linspace(np.pi, -np.pi, 6, endpoint=False)
+            out[f, 36 + 6 * k:42 + 6 * k] = np.stack([cx + s * (ex + 0.2 * np.cos(ang)), cy - 0.3 * s - 0.09 * s * np.sin(ang)], 1)
+        op = 0.08 + 0.1 * (1 + np.sin(2 * ph)) / 2                                                           # mouth opening
+        ang = np.linspace(np.pi, -np.pi, 12, endpoint=False)
+        out[f, 48:60] = np.stack([cx + 0.42 * s * np.cos(ang), cy + 0.6 * s - (op + 0.1) * s * np.sin(ang)], 1)
+        ang = np.linspace(np.pi, -np.pi, 8, endpoint=False)
+        out[f, 60:68] = np.stack([cx + 0.28 * s * np.cos(ang), cy + 0.6 * s - op * s * np.sin(ang)], 1)
+    return np.round(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/demo")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--n-blocks", type=int, default=4)
+    ap.add_argument("--timing-frames", type=int, default=200)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    os.makedirs(args.out, exist_ok=True)
+
+    # ---- checkpoint through the reference's .pth schema (demo_face.py:123-129)
+    torch.manual_seed(0)
+    m0 = TSNet(is_train=False, label_nc=2, n_blocks=args.n_blocks, n_downsampling=3, n_source=3)
+    ckpt = {net: getattr(m0, net).state_dict() for net in ("img_enc", "lbl_enc", "dec", "fuse_net")}
+    ckpt["example"] = 0
+    path = os.path.join(args.out, "TSNet_B0004_S000000.pth")
+    torch.save(ckpt, path)
+    model = TSNet(is_train=False, label_nc=2, n_blocks=args.n_blocks, n_downsampling=3, n_source=3)
+    model.load_checkpoint(torch.load(path, map_location="cpu"))
+    model = model.cuda()
+
+    # ---- labels on the device: key points -> edge map / bbox at crop resolution -> 256 x 256 -> one-hot (rank 3 kernels)
+    K, F = 3, args.frames
+    kp = synthetic_face_keypoints(F + K, seed=0)
+    rs = raster.FaceRasteriser(dev)
+    t0 = time.perf_counter()
+    edges, bbox, crop, bw = rs.rasterise(list(kp))
+    lbl = rs.vl2ch(demo.resize_nearest(edges), 2)                  # vl2ch(label map, "face") (demo_face.py:158,164)
+    box = demo.resize_nearest(bbox)
+    torch.cuda.synchronize()
+    t_raster = time.perf_counter() - t0
+    g = torch.Generator().manual_seed(1)
+    src_img = [(torch.rand((1, 3, 256, 256), generator=g) * 255.0 - torch.from_numpy(demo.IMG_MEAN).view(1, 3, 1, 1)) for _ in range(K)]
+    runner = demo.ClipRunner(model, src_img, [lbl[i:i + 1] for i in range(K)], [box[i:i + 1] for i in range(K)])
+    frames = runner.run(lbl[K:], box[K:], out_dir=args.out, name="synthetic_face")
+    print(f"[demo_clip] {frames.shape[0]} frames written to {args.out} (crop {crop}, brush {bw}); rasterisation of {F + K} frames: {t_raster * 1e3:.2f} ms")
+
+    # ---- the demo-shaped figure: B = 1, n_blocks = 4, K = 3, clip mode, post-processing included, frames stay on the device
+    for _ in range(20):
+        runner.frame(lbl[K:K + 1], box[K:K + 1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.timing_frames):
+        j = K + i % F
+        runner.frame(lbl[j:j + 1], box[j:j + 1])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"[demo_clip] clip mode, B=1, n_blocks={args.n_blocks}, K=3: {args.timing_frames / dt:.1f} frames/s ({dt / args.timing_frames * 1e3:.3f} ms per driving frame, "
+          "device post-processing included)")
+
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "engine.cpp")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("conv_igemm.hpp", "conv_dma.hpp", "conv_x3.hpp", "conv_x3p.hpp", "conv_x3r.hpp", "conv_h2.hpp", "split3.hpp", "head_conv.hpp", "flow_warp.hpp", "norm_elementwise.hpp", "postproc.hpp", "train_extras.hpp")] + \
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("conv_igemm.hpp", "conv_dma.hpp", "conv_x3.hpp", "conv_x3p.hpp", "conv_x3r.hpp", "conv_h2.hpp", "split3.hpp", "head_conv.hpp", "flow_warp.hpp", "norm_elementwise.hpp", "postproc.hpp", "raster.hpp", "train_extras.hpp")] + \
        [os.path.join(os.path.dirname(HERE), "include", "tsnet_abi.h")]
 OUT = os.path.join(HERE, "lib", "libtsnet_hip.so")
 # the same sources with -DTSNET_TOOLS: the product kernels PLUS the superseded convolution generations and the ablation

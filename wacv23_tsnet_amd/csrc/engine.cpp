@@ -40,6 +40,7 @@
 #include "head_conv.hpp"
 #include "norm_elementwise.hpp"
 #include "postproc.hpp"
+#include "raster.hpp"
 #include "train_extras.hpp"
 
 using namespace tsnet;
@@ -2021,6 +2022,32 @@ int tsnet_demo_postprocess(const float* rec, int B, int H, int W, const float* g
                    out_rgb, B, H * W};
     hipLaunchKernelGGL(demo_post_kernel, dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, a);
     check_launch("demo_post");
+    OP_END
+}
+
+int tsnet_raster_face(const double* keypoints, int F, int h, int w, int bw, unsigned char* edges, unsigned char* bbox, void* stream) {
+    OP_BEGIN
+    if (!keypoints || (!edges && !bbox)) throw ArgError("raster_face: null tensor");
+    if (F < 1 || F > 65535 || h < 1 || w < 1 || bw < 1 || (double)h * w >= 2147483647.0) throw ArgError("raster_face: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (edges) {
+        HIP_TRY(hipMemsetAsync(edges, 0, (size_t)F * h * w, s));
+        hipLaunchKernelGGL(face_edges_kernel, dim3(kFaceSubEdges, F), dim3(64), 0, s, keypoints, edges, h, w, bw);
+        check_launch("face_edges");
+    }
+    if (bbox) {
+        hipLaunchKernelGGL(face_bbox_kernel, dim3(F), dim3(256), 0, s, keypoints, bbox, h, w);
+        check_launch("face_bbox");
+    }
+    OP_END
+}
+
+int tsnet_vl2ch(const float* labels, int B, int HW, int num_classes, float* out, void* stream) {
+    OP_BEGIN
+    if (!labels || !out) throw ArgError("vl2ch: null tensor");
+    if (B < 1 || HW < 1 || num_classes < 1) throw ArgError("vl2ch: bad shape");
+    hipLaunchKernelGGL(onehot_kernel, dim3(ew_grid((size_t)B * num_classes * HW)), dim3(256), 0, (hipStream_t)stream, labels, out, B, HW, num_classes);
+    check_launch("onehot");
     OP_END
 }
 

@@ -82,3 +82,59 @@ def save_gif(frames: Sequence[np.ndarray], path: str, duration_ms: int = 100):
     from PIL import Image
     ims = [Image.fromarray(np.ascontiguousarray(f), "RGB") for f in frames]
     ims[0].save(path, save_all=True, append_images=ims[1:], duration=duration_ms, loop=0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Clip harness: what demo/demo_face.py:108-236 does around the model, with the per-frame work on the device.
+def resize_nearest(x: torch.Tensor, size=(256, 256)) -> torch.Tensor:
+    """(F,h,w) byte maps -> (F,H,W) {0,1} floats by nearest-neighbour sampling.  STAND-IN, not parity-pinned: the reference resizes
+    its label maps with skimage.transform.resize + img_as_bool (dataset_video_face.py:316-317), which this image cannot run."""
+    F_, h, w = x.shape
+    H, W = size
+    yi = (torch.arange(H, device=x.device) * h) // H
+    xi = (torch.arange(W, device=x.device) * w) // W
+    return (x[:, yi][:, :, xi] > 0).to(torch.float32)
+
+
+class ClipRunner:
+    """One (source set, driving clip) job in the reference's demo protocol (demo_face.py:166-231):
+      * the K source frames are encoded ONCE (`tsnet_set_sources`; the reference re-encodes them for every driving frame, :187-192);
+      * every driving frame is one `tsnet_forward_target` at batch 1, re-normalised to the first source image's statistics and turned
+        into RGB bytes on the device (`DemoPostprocessor`); only the bytes cross PCIe;
+      * the three-panel strips and the GIF are written with PIL.
+    model: a wacv23_tsnet_amd.model.TSNet on the GPU."""
+
+    def __init__(self, model, src_img: Sequence[torch.Tensor], src_lbl: Sequence[torch.Tensor], src_bbox: Sequence[torch.Tensor]):
+        self.model = model
+        self.eng = model._get_engine(1)
+        K = model.n_source
+        dev = model._device()
+        mv = lambda t: t.to(dev, dtype=torch.float32).contiguous()
+        self.src_img = [mv(x) for x in src_img[:K]]
+        self.eng.set_sources(self.src_img, [mv(x) for x in src_lbl[:K]], [mv(x) for x in src_bbox[:K]])
+        self.post = DemoPostprocessor(self.src_img[0])              # ref_img_list[0] (:180)
+
+    def frame(self, tar_lbl: torch.Tensor, tar_bbox: torch.Tensor) -> torch.Tensor:
+        """one driving frame (1,L,H,W), (1,H,W) -> (H,W,3) uint8 RGB on the device"""
+        dev = self.src_img[0].device
+        rec, _ = self.eng.forward_target(tar_lbl.to(dev, dtype=torch.float32), tar_bbox.to(dev, dtype=torch.float32))
+        return self.post(rec)[0]
+
+    def run(self, tar_lbls: torch.Tensor, tar_bboxs: torch.Tensor, out_dir: str = None, tar_imgs: torch.Tensor = None, name: str = "clip"):
+        """tar_lbls (F,L,H,W), tar_bboxs (F,H,W); returns the generated frames (F,H,W,3) uint8 (host).  With out_dir: strips + GIF."""
+        import os
+        frames = [self.frame(tar_lbls[i:i + 1], tar_bboxs[i:i + 1]) for i in range(tar_lbls.shape[0])]
+        out = torch.stack(frames).cpu().numpy()
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+            strips = []
+            src_rgb = input_to_rgb(self.src_img[0][0])
+            for i in range(out.shape[0]):
+                if tar_imgs is not None:
+                    tar_rgb = input_to_rgb(tar_imgs[i])
+                else:                                               # no ground-truth driving frame: show the label map instead
+                    m = (tar_lbls[i, -1].detach().cpu().numpy() > 0).astype(np.uint8) * 255
+                    tar_rgb = np.repeat(m[:, :, None], 3, axis=2)
+                strips.append(save_strip(src_rgb, tar_rgb, out[i], os.path.join(out_dir, f"{i:06d}_{name}.png")))
+            save_gif(strips, os.path.join(out_dir, f"{name}.gif"))
+        return out
