@@ -66,7 +66,7 @@ def _pmc_traffic_bytes(kernel_prefix: str):
 
 
 def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None, batch: int = B_PER_GPU, height: int = H,
-             width: int = W, model_kw=None, cpu_baseline: bool = True, timing_probe: bool = True) -> dict | None:
+             width: int = W, model_kw=None, cpu_baseline: bool = True, timing_probe: bool = True, secondary: bool = False) -> dict | None:
     """Everything one rank does: replica from rank 0's weights (ONE broadcast), its own batch of independent pairs, W warm-up steps,
     K timed steps between barriers, MAX over ranks.  Returns the result line on rank 0, None elsewhere."""
     from oracle import tsnet_oracle as O            # cpu_baseline leg + parity check only
@@ -195,6 +195,32 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
         cpu_base = {"value": round(batch / med, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                     "sample": f"{len(times)} timed forwards (median) of the same B={batch}, K={cfg.n_source}, {height}x{width} workload after 1 warm-up; torch {torch.__version__} CPU oneDNN"}
 
+    # ---- secondary figure, never the headline: BASELINE.json configs[2] (face-checkpoint shape n_blocks=4, bs=8) in the bf16-operand mode
+    second = None
+    if secondary and world == 1 and cuda:
+        eng.close()
+        cfg2 = O.TSNetConfig(label_nc=2, n_blocks=4, n_downsampling=3, n_source=3)
+        e2 = TSNetEngine(label_nc=2, n_blocks=4, n_downsampling=3, n_source=3, height=height, width=width, max_batch=8, operands="bf16", lib=lib)
+        build_replica(e2, O.synth_state_dict(cfg2, seed=0), dev, src=0)
+        i2 = [[t.to(dev) for t in x] if isinstance(x, list) else x.to(dev) for x in O.synth_inputs(cfg2, 8, height, width, seed=3)]
+        for _ in range(5):
+            e2.forward(*i2)
+        sync()
+        n2 = 30
+        t2 = time.perf_counter()
+        for _ in range(n2):
+            e2.forward(*i2)
+        sync()
+        d2 = time.perf_counter() - t2
+        g2 = 2.0 * e2.forward_macs(1) / 1e9
+        second = {"workload": "BASELINE.json configs[2]: TSNet(n_blocks=4) forward, bs=8, 256x256, n_source=3, bf16 conv operands / fp32 accumulate (tsnet_cfg.operand_mode=1)",
+                  "value": round(8 * n2 / d2, 2), "unit": "frames/s", "ms_per_step": round(d2 / n2 * 1e3, 3), "steps": n2,
+                  "algorithmic_gflop_per_frame": round(g2, 3),
+                  "frac_of_bf16_mfma_peak": round(8 * n2 / d2 * g2 / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
+                  "parity": "own tolerance, tests/test_gpu_forward.py::test_cfg2_bf16_face_checkpoint_shape_b8 (helpers.bf16_mode_report)"}
+        e2.close()
+        eng = TSNetEngine(height=height, width=width, max_batch=batch, lib=lib, **eng_kw)      # forward_macs below
+
     frames = world * batch * steps
     gflop_frame = 2.0 * eng.forward_macs(1) / 1e9
     x3on = os.environ.get("TSNET_X3", "1") != "0"
@@ -213,7 +239,7 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
         "ms_per_step_hipevent_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)] if step_ms else None,
         "algorithmic_gflop_per_frame": round(gflop_frame, 3),
         "whole_forward_frac_of_fp32_mfma_peak": round(frames / dt * gflop_frame / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4),
-        "roofline": roofline, "cpu_baseline": cpu_base,
+        "roofline": roofline, "cpu_baseline": cpu_base, "secondary_bf16_cfg2": second,
     }
     eng.close()
     return line
@@ -225,6 +251,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs[2] bf16-operand figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,7 +266,8 @@ def main():
         # the box shares one 16-CPU cgroup between the ranks: one host thread per rank is all a launch loop needs
         torch.set_num_threads(1)
         dist.init_process_group("nccl", device_id=dev)
-    line = run_rank(rank=rank, world=world, device=dev, steps=args.steps, warmup=args.warmup, cpu_baseline=not args.no_cpu_baseline)
+    line = run_rank(rank=rank, world=world, device=dev, steps=args.steps, warmup=args.warmup, cpu_baseline=not args.no_cpu_baseline,
+                    secondary=not args.no_secondary)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TSNET_ABI_VERSION 1
+#define TSNET_ABI_VERSION 2
 #define TSNET_MAX_SOURCES 8
 
 enum {
@@ -50,6 +50,9 @@ typedef struct tsnet_cfg {
     float pose_mean[3];  /* BGR mean of the pose model (TSNet_pose.py:215) */
     int height, width;   /* input frame size (256x256 in the reference) */
     int max_batch;       /* largest B a forward will be called with (workspace is sized once) */
+    int operand_mode;    /* 0 = fp32-class arithmetic (default: split operands, parity 1e-3 with the fp32 reference);
+                          * 1 = bf16 operands (BASELINE.json configs[2] / [4]): every convolution input and weight is rounded to bf16,
+                          *     one MFMA product, fp32 accumulate, fp32 InstanceNorm / softmax / RGB head.  Own tolerance. */
 } tsnet_cfg;
 
 /* ---- lifecycle ---------------------------------------------------------------------------

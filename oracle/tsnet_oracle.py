@@ -55,6 +55,35 @@ class TSNetConfig:
         return self.ngf * (2 ** self.n_downsampling)
 
 
+# --------------------------------------------------------------------------- operand rounding (bf16-operand mode)
+_ROUND_BF16 = False     # set by tsnet_forward(round_operands="bf16") for the duration of one call
+
+
+def _r(t: torch.Tensor) -> torch.Tensor:
+    """bf16-operand mode of the engine (tsnet_cfg.operand_mode = 1; BASELINE.json configs[2] / [4]): every convolution input and weight is
+    rounded to bfloat16 (round to nearest even) where the convolution reads it; products and sums stay fp32.  Identity otherwise."""
+    return t.to(torch.bfloat16).to(t.dtype) if _ROUND_BF16 else t
+
+
+def _conv(x, w, b=None, **kw):
+    return F.conv2d(_r(x), _r(w), b, **kw)
+
+
+class bf16_operands:
+    """context manager: the layer functions of this module (encoder, fuse_net, decoder, ...) round their convolution operands to
+    bf16 inside it -- for checks of one stage of the engine's bf16-operand mode in isolation"""
+
+    def __enter__(self):
+        global _ROUND_BF16
+        self._old, _ROUND_BF16 = _ROUND_BF16, True
+        return self
+
+    def __exit__(self, *a):
+        global _ROUND_BF16
+        _ROUND_BF16 = self._old
+        return False
+
+
 # --------------------------------------------------------------------------- layers
 def coord_conv(x: torch.Tensor) -> torch.Tensor:
     """Append xx, yy, rr channels (Encoder.coord_conv, TSNet.py:107-125).
@@ -79,9 +108,9 @@ def _in(x: torch.Tensor) -> torch.Tensor:
 
 def resnet_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
     """x + IN(conv3(reflpad1(relu(IN(conv3(reflpad1(x))))))) (ResnetBlock, TSNet.py:15-49)."""
-    y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[prefix + "conv_block.1.weight"], sd[prefix + "conv_block.1.bias"])
+    y = _conv(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[prefix + "conv_block.1.weight"], sd[prefix + "conv_block.1.bias"])
     y = F.relu(_in(y))
-    y = F.conv2d(F.pad(y, (1, 1, 1, 1), mode="reflect"), sd[prefix + "conv_block.5.weight"], sd[prefix + "conv_block.5.bias"])
+    y = _conv(F.pad(y, (1, 1, 1, 1), mode="reflect"), sd[prefix + "conv_block.5.weight"], sd[prefix + "conv_block.5.bias"])
     return x + _in(y)
 
 
@@ -92,11 +121,11 @@ def encoder(x: torch.Tensor, sd: Dict[str, torch.Tensor], net: str, cfg: TSNetCo
     if cfg.addcoords:
         x = coord_conv(x)
     p = net + ".model."
-    x = F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), sd[p + "1.weight"], sd[p + "1.bias"])
+    x = _conv(F.pad(x, (3, 3, 3, 3), mode="reflect"), sd[p + "1.weight"], sd[p + "1.bias"])
     x = F.relu(_in(x))
     idx = 4
     for _ in range(cfg.n_downsampling):
-        x = F.conv2d(x, sd[p + f"{idx}.weight"], sd[p + f"{idx}.bias"], stride=2, padding=1)
+        x = _conv(x, sd[p + f"{idx}.weight"], sd[p + f"{idx}.bias"], stride=2, padding=1)
         x = F.relu(_in(x))
         idx += 3
     for _ in range(n_blocks):
@@ -105,11 +134,13 @@ def encoder(x: torch.Tensor, sd: Dict[str, torch.Tensor], net: str, cfg: TSNetCo
     return x
 
 
-def fuse_net(src_fea: torch.Tensor, tar_fea: torch.Tensor, sd: Dict[str, torch.Tensor], cfg: TSNetConfig) -> torch.Tensor:
-    """FuseNet.forward (TSNet.py:195-200): cat -> ResnetBlock(s) -> 1x1 conv."""
+def fuse_net(src_fea: torch.Tensor, tar_fea: torch.Tensor, sd: Dict[str, torch.Tensor], cfg: TSNetConfig, head: bool = True) -> torch.Tensor:
+    """FuseNet.forward (TSNet.py:195-200): cat -> ResnetBlock(s) -> 1x1 conv (head=False: stop before the 1x1 conv)."""
     x = torch.cat((src_fea, tar_fea), dim=1)
     for i in range(cfg.fuse_blocks):
         x = resnet_block(x, sd, f"fuse_net.model.{i}.")
+    if not head:
+        return x
     return F.conv2d(x, sd["fuse_net.conv.weight"], sd["fuse_net.conv.bias"])
 
 
@@ -117,7 +148,7 @@ def decoder(prop: torch.Tensor, syn: torch.Tensor, sd: Dict[str, torch.Tensor], 
     """Decoder.forward with return_fea=True (TSNet.py:162-171; ctor :136-155):
     map_conv(cat) -> model0..model{n_blocks-1} ResnetBlocks -> 3x [up x2 bilinear,
     reflpad1, conv3, IN, ReLU] -> [reflpad3, conv7, tanh]."""
-    x = F.conv2d(torch.cat([prop, syn], dim=1), sd["dec.map_conv.weight"], sd["dec.map_conv.bias"])
+    x = _conv(torch.cat([prop, syn], dim=1), sd["dec.map_conv.weight"], sd["dec.map_conv.bias"])
     if stages is not None:
         stages["dec_map"] = x
     n = 0
@@ -126,7 +157,7 @@ def decoder(prop: torch.Tensor, syn: torch.Tensor, sd: Dict[str, torch.Tensor], 
         n += 1
     for i in range(cfg.n_downsampling):
         x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
-        x = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[f"dec.model{n}.2.weight"], sd[f"dec.model{n}.2.bias"])
+        x = _conv(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[f"dec.model{n}.2.weight"], sd[f"dec.model{n}.2.bias"])
         x = F.relu(_in(x))
         if stages is not None:
             stages[f"dec_up{i}"] = x
@@ -207,12 +238,28 @@ def train_extras(src_img: List[torch.Tensor], tar_img: torch.Tensor, flows: List
 def tsnet_forward(sd: Dict[str, torch.Tensor], cfg: TSNetConfig,
                   src_img_list: List[torch.Tensor], src_lbl_list: List[torch.Tensor], src_bbox_list: List[torch.Tensor],
                   tar_lbl: torch.Tensor, tar_bbox: torch.Tensor, want_stages: bool = False,
-                  tar_img: torch.Tensor = None) -> dict:
+                  tar_img: torch.Tensor = None, round_operands: Optional[str] = None) -> dict:
     """set_test_input + forward of the reference (TSNet.py:283-294, 309-407).
 
     Inputs exactly as the reference's callers pass them: images (B,3,H,W) *before* the
     /255 of set_test_input (:286), labels (B,L,H,W), bboxes (B,H,W).
-    Returns {'rec_tar_img': (B,3,H,W), 'flows': K x (B,h,w,2), [stage tensors]}."""
+    Returns {'rec_tar_img': (B,3,H,W), 'flows': K x (B,h,w,2), [stage tensors]}.
+
+    round_operands="bf16" is NOT the reference: it is the checker of the engine's bf16-operand mode (BASELINE.json configs[2] / [4]).
+    Every convolution input and weight is rounded to bfloat16 where the engine rounds it -- all convolutions except the RGB head, and
+    `fuse_net.conv` (1x1, linear) applied to the mean over sources like the engine does -- while products, sums, InstanceNorm, the
+    transformation branch and the head stay fp32.  What remains between the two is summation order and the bf16 roundings it flips."""
+    global _ROUND_BF16
+    if round_operands not in (None, "bf16"):
+        raise ValueError("round_operands: None or 'bf16'")
+    _ROUND_BF16 = round_operands == "bf16"
+    try:
+        return _forward(sd, cfg, src_img_list, src_lbl_list, src_bbox_list, tar_lbl, tar_bbox, want_stages, tar_img)
+    finally:
+        _ROUND_BF16 = False
+
+
+def _forward(sd, cfg, src_img_list, src_lbl_list, src_bbox_list, tar_lbl, tar_bbox, want_stages, tar_img) -> dict:
     K = cfg.n_source
     src_img = [x / 255.0 for x in src_img_list[:K]]                 # :286
     src_bbox = [x.unsqueeze(1) for x in src_bbox_list[:K]]          # :288
@@ -226,7 +273,11 @@ def tsnet_forward(sd: Dict[str, torch.Tensor], cfg: TSNetConfig,
         warped.append(wpd)
         flows.append(fl)
     pg = torch.stack(warped, dim=1).mean(dim=1)                     # :392
-    sg = torch.stack([fuse_net(src_fea[i], tar_fea, sd, cfg) for i in range(K)], dim=1).mean(dim=1)  # :396-400
+    if _ROUND_BF16:     # the engine's order: the linear 1x1 convolution once, on the mean (its input is what gets rounded)
+        zbar = torch.stack([fuse_net(src_fea[i], tar_fea, sd, cfg, head=False) for i in range(K)], dim=1).mean(dim=1)
+        sg = _conv(zbar, sd["fuse_net.conv.weight"], sd["fuse_net.conv.bias"])
+    else:
+        sg = torch.stack([fuse_net(src_fea[i], tar_fea, sd, cfg) for i in range(K)], dim=1).mean(dim=1)  # :396-400
     rec, fea = decoder(pg, sg, sd, cfg, stages if want_stages else None)  # :407
     if cfg.pose and cfg.use_mask:
         rec = pose_composite(rec, cfg)                              # TSNet_pose.py:416-417

@@ -203,3 +203,32 @@ def test_packed_weight_buffer_goes_through_rccl(cfg0):
         dist.destroy_process_group()
     rec1, _ = Hh.run_engine(eng, inputs, DEV, return_flow=False)
     assert torch.equal(rec0, rec1)
+
+
+# ---- bf16-operand mode (tsnet_cfg.operand_mode = 1): BASELINE.json configs[2] and configs[4]
+def _bf16_case(cfg, B, H, W, wseed, iseed, mask="box"):
+    sd = O.synth_state_dict(cfg, seed=wseed, bias_std=0.02)
+    inp = O.synth_inputs(cfg, B, H, W, seed=iseed, mask_mode=mask)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    eng = Hh.make_engine(cfg, sd, H, W, B, DEV, operands="bf16")
+    rec, _ = Hh.run_engine(eng, inp, DEV)
+    r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, B, DEV)
+    eng.close()
+    return r
+
+
+def test_cfg2_bf16_face_checkpoint_shape_b8():
+    """configs[2]: face-checkpoint shape (n_blocks=4), bs=8, bf16 operands on one MI355X.  Gates: the smooth stages within bf16
+    rounding-flip noise of the oracle that rounds the same operands; end-to-end distances reported (helpers.bf16_mode_report)."""
+    r = _bf16_case(O.TSNetConfig(label_nc=2, n_blocks=4, n_source=3), 8, 256, 256, 21, 22)
+    print("[cfg2 bf16] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
+    assert r["src_fea"] < 0.15 and r["tar_fea"] < 0.05 and r["sg"] < 0.15
+    assert r["decoder_on_engine_features"] < 0.05
+
+
+def test_cfg4_bf16_512_k5():
+    """configs[4] per-GPU shard: 512 x 512, n_source=5, bf16 operands (P = 4096 positions)."""
+    r = _bf16_case(O.TSNetConfig(label_nc=2, n_blocks=0, n_source=5), 1, 512, 512, 25, 26, mask="bernoulli")
+    print("[cfg4 bf16] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
+    assert r["src_fea"] < 0.15 and r["tar_fea"] < 0.05 and r["sg"] < 0.15
+    assert r["decoder_on_engine_features"] < 0.05

@@ -37,7 +37,7 @@ class TsnetCfg(C.Structure):
     _fields_ = [
         ("label_nc", C.c_int), ("n_blocks", C.c_int), ("n_downsampling", C.c_int), ("n_source", C.c_int),
         ("ngf", C.c_int), ("enc_blocks", C.c_int), ("addcoords", C.c_int), ("pose_composite", C.c_int),
-        ("pose_mean", C.c_float * 3), ("height", C.c_int), ("width", C.c_int), ("max_batch", C.c_int),
+        ("pose_mean", C.c_float * 3), ("height", C.c_int), ("width", C.c_int), ("max_batch", C.c_int), ("operand_mode", C.c_int),
     ]
 
 
@@ -119,6 +119,6 @@ def load() -> C.CDLL:
         _cached = bind(C.CDLL(LIB_PATH))
     except OSError as e:  # pragma: no cover - depends on the machine
         raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
-    if _cached.tsnet_abi_version() != 1:
+    if _cached.tsnet_abi_version() != 2:
         raise RuntimeError("libtsnet_hip.so ABI version mismatch; rebuild")
     return _cached

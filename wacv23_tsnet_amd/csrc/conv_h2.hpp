@@ -72,7 +72,21 @@ __device__ __forceinline__ void split_h2_octet(const F4& x0, const F4& x1, F4& H
     for (int e = 0; e < 4; ++e) { H.v[e] = __builtin_bit_cast(float, hw[e]); L.v[e] = __builtin_bit_cast(float, lw[e]); }
 }
 
-// NPROD = 3: lo*hi, hi*lo, hi*hi;  NPROD = 4: lo*lo first (kept for the accuracy comparison in the op tests)
+// eight consecutive channels -> one octet of bf16 (round to nearest even): the bf16-operand mode's single plane
+__device__ __forceinline__ void bf16_octet(const F4& x0, const F4& x1, F4& H) {
+    unsigned hw[4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        hw[e] = (unsigned)bf16_rne(x0.v[2 * e]) | ((unsigned)bf16_rne(x0.v[2 * e + 1]) << 16);
+        hw[2 + e] = (unsigned)bf16_rne(x1.v[2 * e]) | ((unsigned)bf16_rne(x1.v[2 * e + 1]) << 16);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) H.v[e] = __builtin_bit_cast(float, hw[e]);
+}
+
+// NPROD = 3: lo*hi, hi*lo, hi*hi;  NPROD = 4: lo*lo first (kept for the accuracy comparison in the op tests);
+// NPROD = 1: bf16-operand mode (BASELINE.json configs[2] / [4]): the transformed input is rounded to ONE bf16 plane while it is
+// staged, the weights are the bf16 hi plane of the bf16x3 packing (conv_x3.hpp), one v_mfma_f32_32x32x16_bf16 per k-group; no scales.
 // HABL (tools build only, tools/x3_ablate.py h2; non-zero computes garbage): bit0 no patch staging in the loop, bit1 weight fragments
 // loaded once, bit2 A fragments read once, bit3 no fold, bit4 no slab barrier
 template <int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int HABL = 0>
@@ -80,14 +94,15 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
     constexpr int BM = kPatchRows * kPatchCols;
     constexpr int NW = WARPS_M * WARPS_N;
     static_assert(NW == 4, "four waves: patch blocks are dealt w, w+4");
-    static_assert(NPROD == 3 || NPROD == 4, "three or four products");
+    static_assert(NPROD == 1 || NPROD == 3 || NPROD == 4, "one (bf16 operands), three or four products");
+    constexpr int NPL = NPROD == 1 ? 1 : 2;                          // operand planes
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 32, NTL = WN / 32;
     constexpr int PC = kPatchCols + 2, PP = (kPatchRows + 2) * PC;   // 34, 204 patch pixels
     constexpr int PBLK = (PP + 31) / 32;                             // 7 blocks of 32 pixel slots
     constexpr int REGION = PBLK * 512;                               // one octet region: 224 slots x 16 B
-    constexpr int PLANE_P = 2 * REGION, PATCH_BYTES = 2 * PLANE_P;   // two planes x 7 KiB per stage
-    constexpr int OFF_SCRATCH = 2 * PATCH_BYTES;                     // 2 KiB sink for the wave whose second block does not exist
+    constexpr int PLANE_P = 2 * REGION, PATCH_BYTES = NPL * PLANE_P; // planes x 7 KiB per stage
+    constexpr int OFF_SCRATCH = 2 * 2 * PLANE_P;                     // 2 KiB sink for the wave whose second block does not exist (fixed offsets in both modes)
     constexpr int OFF_TAB = OFF_SCRATCH + 2048;                      // (alpha*s, beta*s) table of the image: 2 x Cin floats
 
     const int tid = threadIdx.x;
@@ -104,9 +119,9 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
 
     const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
     const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
-    tsnet_brsrc_t rsw[2];
+    tsnet_brsrc_t rsw[NPL];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
+    for (int p = 0; p < NPL; ++p) rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
 
     // ---- LDS image of a patch stage: per plane two octet REGIONS (channels 0..7 / 8..15 of the slab), each one 16-byte entry per
     //      pixel slot.  A fragment read of lane (li, lh) is region lh, slot p0 + tap shift: 16 consecutive lanes read 256
@@ -175,21 +190,26 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
                     t[q].v[e] = v > relu_floor ? v : relu_floor;
                 }
         }
-        F4 Hh, Ll;
-        split_h2_octet(t[0], t[1], Hh, Ll);
         // block 7 does not exist: its wave writes into the sink (wave-uniform select, no branch)
         unsigned char* dst = smem_raw + (b < PBLK ? (cn & 1) * PATCH_BYTES + oct * REGION + b * 512 : OFF_SCRATCH + oct * 512) + (lane & 31) * 16;
-        *reinterpret_cast<F4*>(dst) = Hh;
-        *reinterpret_cast<F4*>(dst + (b < PBLK ? PLANE_P : 1024)) = Ll;
+        F4 Hh, Ll;
+        if (NPROD == 1) {
+            bf16_octet(t[0], t[1], Hh);
+            *reinterpret_cast<F4*>(dst) = Hh;
+        } else {
+            split_h2_octet(t[0], t[1], Hh, Ll);
+            *reinterpret_cast<F4*>(dst) = Hh;
+            *reinterpret_cast<F4*>(dst + (b < PBLK ? PLANE_P : 1024)) = Ll;
+        }
     };
 
     // ---- fragments.  Weights: lane (li, lh) takes the 16 bytes of column wn0 + j*32 + li, logical octet lh
     const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
-    F4 af[2][2][MT], bf[3][2][NTL];                                  // [register set][plane][tile]
+    F4 af[2][NPL][MT], bf[3][NPL][NTL];                              // [register set][plane][tile]
     auto load_b = [&](int set, int cc, int t) __attribute__((always_inline)) {     // past the end of K the descriptor returns zeros
         const int kc = t * ncc + cc;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < NPL; ++p)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0 + j * 32) * 32));
     };
@@ -200,7 +220,7 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) af[set][p][i] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + ((i + ky) * PC + kx) * 16);
+            for (int p = 0; p < NPL; ++p) af[set][p][i] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + ((i + ky) * PC + kx) * 16);
     };
 
     f32x16 acc[MT][NTL], tot[MT][NTL];
@@ -221,7 +241,8 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c[r] = 0.f;
                 }
-                acc[i][j] = TSNET_MFMA_F16(af[sa][pa][i], bf[sb][pb][j], c);
+                if (NPROD == 1) acc[i][j] = TSNET_MFMA_BF16(af[sa][pa][i], bf[sb][pb][j], c);
+                else acc[i][j] = TSNET_MFMA_F16(af[sa][pa][i], bf[sb][pb][j], c);
             }
     };
     // step (cc, t): A(cc,t) in set SA, B(cc,t) in set t%3; issues A(cc,t+1) and B of two steps ahead first
@@ -235,10 +256,14 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
         if (t == 0 && !(HABL & 1)) stage_load_x(cc + 1, 0);
         if (t == 3 && !(HABL & 1)) stage_load_x(cc + 1, 1);
         const int SB = t % 3;
-        if (NPROD == 4) product(SA, SB, 1, 1, fresh);                // lo * lo
-        product(SA, SB, 1, 0, fresh && NPROD == 3);                  // lo * hi
-        product(SA, SB, 0, 1, false);                                // hi * lo
-        product(SA, SB, 0, 0, false);                                // hi * hi
+        if (NPROD == 1) {
+            product(SA, SB, 0, 0, fresh);                            // bf16 * bf16
+        } else {
+            if (NPROD == 4) product(SA, SB, NPL - 1, NPL - 1, fresh);        // lo * lo
+            product(SA, SB, NPL - 1, 0, fresh && NPROD == 3);        // lo * hi
+            product(SA, SB, 0, NPL - 1, false);                      // hi * lo
+            product(SA, SB, 0, 0, false);                            // hi * hi
+        }
         if (t == 2 && !(HABL & 1)) stage_store(cc + 1, 0);
         if (t == 5 && !(HABL & 1)) stage_store(cc + 1, 1);
         if ((t == 3 || t == 8) && !(HABL & 8)) {
@@ -267,7 +292,7 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
     for (; cc + 2 <= ncc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
     if (cc < ncc) slab(cc, 0);
 
-    const float unscale = a.in_unscale * a.w_unscale[0];
+    const float unscale = a.w_unscale ? a.in_unscale * a.w_unscale[0] : a.in_unscale;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -310,6 +335,222 @@ __global__ void pack_weights_h2_kernel(const float* __restrict__ w, unsigned sho
         split_h2(v * scale, hi, lo);
         out[idx] = (unsigned short)hi; out[plane + idx] = (unsigned short)lo;
     }
+}
+
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// h2r: the same arithmetic (fp32 input, producer InstanceNorm + ReLU applied on load, fp16 x 2 operands, three products, or one bf16
+// product) as an implicit GEMM for the layers the patch tile does not take: the 3 x 3 / stride-2 / zero-pad downsampling convolutions
+// of the encoders (TSNet.py:70).  Structure of conv_x3r.hpp: a thread stages one (row, 8-channel octet) slot of the im2col A tile per
+// 16-deep step -- two 16-byte fp32 loads two steps ahead, transformed and split in registers, two ds_writes -- weight fragments go
+// straight into registers one step ahead (two register sets: the loop is unrolled by four, so parities are static), one barrier per
+// step, chains of four k-groups folded into the running total.  K order is tap-major (k = tap * Cin + c), like conv_x3r.
+// What it removes next to conv_x3r on these layers: the norm_act pass that materialised relu(IN(x)) as three bf16 planes (10 bytes per
+// element of the largest activations of the network), half of the MFMA products and a third of the gathered bytes.
+struct H2rArgs : H2Args {
+    int stride, pad, taps, cin_log2;
+};
+
+template <int KS, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE>
+__global__ __launch_bounds__(256, 2)
+void conv_h2r_kernel(H2rArgs a) {
+    constexpr int BM = 128;
+    constexpr int NW = WARPS_M * WARPS_N;
+    static_assert(NW == 4, "256 threads: one 16-byte slot of the A tile per thread and plane");
+    static_assert(NPROD == 1 || NPROD == 3, "one (bf16 operands) or three products");
+    constexpr int NPL = NPROD == 1 ? 1 : 2;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 32, NTL = WN / 32;
+    constexpr int PLANE_A = BM * 32, STAGE = 2 * PLANE_A;           // 8 KiB per stage (two planes)
+    constexpr int OFF_TAB = 2 * STAGE;                               // (alpha*s, beta*s) of the tile's image: 2 x Cin floats
+
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = TSNET_UNIFORM(tid >> 6);
+    const int wm0 = (wave / WARPS_N) * WM, wn0 = (wave % WARPS_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
+    const int tile_m = bid / a.tiles_n, tile_n = bid - tile_m * a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int hw = a.Ho * a.Wo;
+    const int img = m0 / hw;                                         // a tile lies inside one image (hw % 128 == 0, checked on the host)
+
+    const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
+    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
+    tsnet_brsrc_t rsw[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
+
+    float* tab = reinterpret_cast<float*>(smem_raw + OFF_TAB);
+    if (AFFINE) {
+        for (int c = tid; c < a.Cin; c += 256) {
+            tab[c] = a.in_alpha[(size_t)img * a.Cin + c] * a.in_scale;
+            tab[a.Cin + c] = a.in_beta[(size_t)img * a.Cin + c] * a.in_scale;
+        }
+        __syncthreads();
+    }
+    const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();
+
+    // ---- A staging: thread t owns row t/2, physical octet t&1 (LDS slot t*16 inside a plane), logical octet swizzled by bit 3 of the row
+    const int srow = tid >> 1;
+    const int oct_log = (tid & 1) ^ ((srow >> 3) & 1);
+    int s_pix, s_oy, s_ox;
+    {
+        const int rem = (m0 + srow) - img * hw;
+        const int oy = rem / a.Wo;
+        s_pix = img * a.H * a.W;
+        s_oy = oy * a.stride - a.pad;
+        s_ox = (rem - oy * a.Wo) * a.stride - a.pad;
+    }
+    const int cpt_log2 = a.cin_log2 - 4;
+    F4 ar[2][2];                                                     // register stage: [set][half of the octet]
+    float am[2];                                                     // 1, or 0 where the tap lies in the zero padding / past the last tap
+    int ac0[2];                                                      // first channel of the staged octet (for the transform table)
+    auto load_a = [&](int kc, int set) __attribute__((always_inline)) {
+        const int tap = kc >> cpt_log2;                              // wave-uniform
+        const int c0 = ((kc << 4) & (a.Cin - 1)) + oct_log * 8;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        int iy = s_oy + ky, ix = s_ox + kx;
+        bool ok = tap < a.taps;
+        if (a.reflect) {
+            iy = iy < 0 ? -iy : iy;
+            iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+            ix = ix < 0 ? -ix : ix;
+            ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+        } else {
+            ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        }
+        const unsigned v = ok ? (unsigned)(((s_pix + iy * a.W + ix) * a.Cin + c0) * 4) : kOOB;
+        ar[set][0] = TSNET_BUF_LOAD16(rsx, v, 0u);
+        ar[set][1] = TSNET_BUF_LOAD16(rsx, v, 16u);
+        am[set] = ok ? 1.f : 0.f;
+        ac0[set] = ok ? c0 : 0;
+    };
+    auto store_a = [&](int set, int stage) __attribute__((always_inline)) {
+        F4 t[2];
+        if (AFFINE) {
+            const float* ta = tab + ac0[set];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const F4 al = *reinterpret_cast<const F4*>(ta + q * 4), be = *reinterpret_cast<const F4*>(ta + a.Cin + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = __builtin_fmaf(ar[set][q].v[e], al.v[e], be.v[e]);
+                    v = v > relu_floor ? v : relu_floor;
+                    t[q].v[e] = v * am[set];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = ar[set][q].v[e] * a.in_scale;
+                    t[q].v[e] = v > relu_floor ? v : relu_floor;
+                }
+        }
+        unsigned char* dst = smem_raw + stage * STAGE + tid * 16;
+        F4 Hh, Ll;
+        if (NPROD == 1) {
+            bf16_octet(t[0], t[1], Hh);
+            *reinterpret_cast<F4*>(dst) = Hh;
+        } else {
+            split_h2_octet(t[0], t[1], Hh, Ll);
+            *reinterpret_cast<F4*>(dst) = Hh;
+            *reinterpret_cast<F4*>(dst + PLANE_A) = Ll;
+        }
+    };
+
+    // ---- fragments
+    const int a_off = (wm0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16;
+    const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
+    F4 af[NPL][MT], bf[2][NPL][NTL];
+    auto frag_a = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[p][i] = *reinterpret_cast<const F4*>(smem_raw + stage * STAGE + p * PLANE_A + i * 1024 + a_off);
+    };
+    auto load_b = [&](int set, int kc) __attribute__((always_inline)) {       // past the end of K the descriptor returns zeros
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0 + j * 32) * 32));
+    };
+
+    f32x16 acc[MT][NTL], tot[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    auto product = [&](int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                f32x16 c = acc[i][j];
+                if (fresh) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                }
+                if (NPROD == 1) acc[i][j] = TSNET_MFMA_BF16(af[pa][i], bf[sb][pb][j], c);
+                else acc[i][j] = TSNET_MFMA_F16(af[pa][i], bf[sb][pb][j], c);
+            }
+    };
+
+    // step kc (u = kc mod 4, static): A(kc) in LDS stage u&1, A(kc+1) in register set (u+1)&1, B(kc) in bf[u&1]
+    auto step = [&](int kc, int u) __attribute__((always_inline)) {
+        __syncthreads();                                             // stage u&1 complete; stage (u+1)&1 no longer read
+        frag_a(u & 1);
+        load_b((u + 1) & 1, kc + 1);
+        store_a((u + 1) & 1, (u + 1) & 1);                           // A(kc+1): loaded during step kc-1
+        load_a(kc + 2, u & 1);                                       // register set u&1 held A(kc), already in LDS
+        if (NPROD == 1) {
+            product(u & 1, 0, 0, u == 0);
+        } else {
+            product(u & 1, 1, 0, u == 0);                            // lo * hi; chains of 4 k-groups counted from k = 0
+            product(u & 1, 0, 1, false);                             // hi * lo
+            product(u & 1, 0, 0, false);                             // hi * hi
+        }
+        if (u == 3) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];
+        }
+    };
+
+    load_a(0, 0);
+    load_a(1, 1);
+    store_a(0, 0);
+    load_b(0, 0);
+    const int nst = a.nchunks;
+    int kc = 0;
+    for (; kc + 4 <= nst; kc += 4) { step(kc, 0); step(kc + 1, 1); step(kc + 2, 2); step(kc + 3, 3); }
+    if (kc < nst) {                                                  // 1..3 trailing k-groups: a last, partial chain
+        step(kc, 0);
+        if (kc + 1 < nst) step(kc + 1, 1);
+        if (kc + 2 < nst) step(kc + 2, 2);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];
+    }
+
+    const float unscale = a.w_unscale ? a.in_unscale * a.w_unscale[0] : a.in_unscale;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[i][j][r] *= unscale;
+    x3_epilogue<BN, WARPS_M, WARPS_N, MT, NTL>(a, tot, smem_raw, tid, wave, n0, (size_t)img * (hw / BM) + (m0 - img * hw) / BM,
+                                               [&](int l) { const int m = m0 + l; return m < a.M ? m : -1; });
 }
 
 }  // namespace tsnet

@@ -228,7 +228,9 @@ __device__ __forceinline__ tsnet_brsrc_t tsnet_make_brsrc(const void* p, unsigne
 
 // QABL (tools/x3_ablate.py q only; non-zero computes garbage): bit0 no patch staging, bit1 no slab barrier, bit2 no fold,
 // bit3 weight fragments loaded once, bit4 A fragments read once, bit5 plane 1 unused (two planes, three products)
-template <int BN, int WARPS_M, int WARPS_N, int QABL = 0>
+// NP = 1: bf16-operand mode (BASELINE.json configs[2] / [4]): only the hi plane -- x rounded to bf16 -- is read and multiplied (one
+// product per k-group); accumulation, epilogue and statistics are unchanged (fp32 / fp64).
+template <int BN, int WARPS_M, int WARPS_N, int QABL = 0, int NP = 3>
 __device__ __forceinline__ void x3q_tile(const X3Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
     constexpr int BM = kPatchRows * kPatchCols;
     constexpr int NW = WARPS_M * WARPS_N;
@@ -347,20 +349,21 @@ __device__ __forceinline__ void x3q_tile(const X3Args& a, unsigned char* smem_ra
         const int nc = last ? cc + 1 : cc, nt = last ? 0 : t + 1;
         F4 stage;
         constexpr bool TWO = (QABL & 32) != 0;               // timing proxy of a two-plane / three-product scheme: plane 1 unused
-        const bool stage_on = t < 6 && !(QABL & 1) && !(TWO && (t % 3) == 1);
+        constexpr bool ONE = NP == 1;
+        const bool stage_on = t < 6 && !(QABL & 1) && !(TWO && (t % 3) == 1) && !(ONE && (t % 3) != 0);
         if (stage_on) stage = patch_load(cc + 1, t);
-        product(2, 0, fresh && !(QABL & 4));                 // lo  * hi
-        if (!last && !(QABL & 16)) load_a(2, nc, nt);
-        if (!TWO) product(1, 0, false);                      // mid * hi
-        product(0, 0, false);                                // hi  * hi
+        if (!ONE) product(2, 0, fresh && !(QABL & 4));       // lo  * hi
+        if (!last && !(QABL & 16) && !ONE) load_a(2, nc, nt);
+        if (!TWO && !ONE) product(1, 0, false);              // mid * hi
+        product(0, 0, ONE && fresh);                         // hi  * hi
         if (!(QABL & 8)) load_b(0, nc, nt);
-        if (!TWO) product(1, 1, false);                      // mid * mid
-        if (!last && !(QABL & 16) && !TWO) load_a(1, nc, nt);
-        if (!TWO) product(0, 1, false);                      // hi  * mid
-        if (!(QABL & 8) && !TWO) load_b(1, nc, nt);
-        product(0, 2, false);                                // hi  * lo
+        if (!TWO && !ONE) product(1, 1, false);              // mid * mid
+        if (!last && !(QABL & 16) && !TWO && !ONE) load_a(1, nc, nt);
+        if (!TWO && !ONE) product(0, 1, false);              // hi  * mid
+        if (!(QABL & 8) && !TWO && !ONE) load_b(1, nc, nt);
+        if (!ONE) product(0, 2, false);                      // hi  * lo
         if (!last && !(QABL & 16)) load_a(0, nc, nt);
-        if (!(QABL & 8)) load_b(2, nc, nt);
+        if (!(QABL & 8) && !ONE) load_b(2, nc, nt);
         if (stage_on) patch_store(cc + 1, t, stage);
         if ((t == 3 || t == 8) && !(QABL & 4)) {
 #pragma unroll
@@ -372,14 +375,14 @@ __device__ __forceinline__ void x3q_tile(const X3Args& a, unsigned char* smem_ra
 
     // prologue: patch of slab 0, then the fragments of step (0, 0)
 #pragma unroll
-    for (int q = 0; q < 6; ++q) patch_store(0, q, patch_load(0, q));
+    for (int q = 0; q < 6; ++q) if (NP == 3 || (q % 3) == 0) patch_store(0, q, patch_load(0, q));
 #pragma unroll
-    for (int p = 0; p < 3; ++p) load_b(p, 0, 0);
+    for (int p = 0; p < NP; ++p) load_b(p, 0, 0);
     for (int cc = 0; cc < ncc; ++cc) {
         if (!(QABL & 2)) __syncthreads();                    // patch(cc) complete and visible; slab cc-1 fully read
         if (!(QABL & 16) || cc == 0) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) load_a(p, cc, 0);
+            for (int p = 0; p < NP; ++p) load_a(p, cc, 0);
         }
         step(cc, 0); step(cc, 1); step(cc, 2);
         step(cc, 3); step(cc, 4); step(cc, 5);
@@ -397,13 +400,13 @@ __device__ __forceinline__ int x3p_item(int bid, int nitems) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <int BN, int WARPS_M, int WARPS_N, int QABL = 0>
+template <int BN, int WARPS_M, int WARPS_N, int QABL = 0, int NP = 3>
 __global__ __launch_bounds__(256)
 void conv_x3q_kernel(X3Args a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
     const int tile_m = bid / a.tiles_n;
-    x3q_tile<BN, WARPS_M, WARPS_N, QABL>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+    x3q_tile<BN, WARPS_M, WARPS_N, QABL, NP>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
 }
 
 template <int BN, int WARPS_M, int WARPS_N, bool FOLD = true, int ABL = 0>

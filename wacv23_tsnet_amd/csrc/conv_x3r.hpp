@@ -16,7 +16,8 @@
 
 namespace tsnet {
 
-template <int KS, int BN, int WARPS_M, int WARPS_N, bool SMALL_CIN>
+// NP = 1: bf16-operand mode -- only the hi plane is staged and multiplied (see conv_x3p.hpp)
+template <int KS, int BN, int WARPS_M, int WARPS_N, bool SMALL_CIN, int NP = 3>
 __global__ __launch_bounds__(256)
 void conv_x3r_kernel(X3Args a) {
     constexpr int BM = 128;
@@ -98,14 +99,14 @@ void conv_x3r_kernel(X3Args a) {
         const unsigned v1 = ok ? (unsigned)(((s_pix1 + pix) * a.Csplit + c_lane) * 2) : kOOB;
         const unsigned v2 = ok ? (unsigned)(((s_pix2 + pix) * C2 + c_lane) * 2) : kOOB;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const tsnet_brsrc_t rs = second ? rs2[p] : rs1[p];
             ar[set][p] = TSNET_BUF_LOAD16(rs, second ? v2 : v1, so);
         }
     };
     auto store_a = [&](int set, int stage) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<F4*>(smem_raw + stage * STAGE + p * PLANE_A + tid * 16) = ar[set][p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<F4*>(smem_raw + stage * STAGE + p * PLANE_A + tid * 16) = ar[set][p];
     };
 
     // ---- fragments
@@ -114,7 +115,7 @@ void conv_x3r_kernel(X3Args a) {
     F4 af[3][MT], bf[3][NTL];
     auto frag_a = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[p][i] = *reinterpret_cast<const F4*>(smem_raw + stage * STAGE + p * PLANE_A + i * 1024 + a_off);
     };
@@ -150,15 +151,19 @@ void conv_x3r_kernel(X3Args a) {
         frag_a(u & 1);
         store_a((u + 1) & 1, (u + 1) & 1);                   // A(kc+1): loaded during step kc-1
         load_a(kc + 2, u & 1);                               // register set u&1 held A(kc), already in LDS
-        product(2, 0, u == 0);                               // chains of 4 k-groups counted from k = 0 (conv_x3.hpp)
-        product(1, 0, false);
-        product(0, 0, false);
+        if (NP == 3) {
+            product(2, 0, u == 0);                           // chains of 4 k-groups counted from k = 0 (conv_x3.hpp)
+            product(1, 0, false);
+        }
+        product(0, 0, NP == 1 && u == 0);
         load_b(0, kc + 1);
-        product(1, 1, false);
-        product(0, 1, false);
-        load_b(1, kc + 1);
-        product(0, 2, false);
-        load_b(2, kc + 1);
+        if (NP == 3) {
+            product(1, 1, false);
+            product(0, 1, false);
+            load_b(1, kc + 1);
+            product(0, 2, false);
+            load_b(2, kc + 1);
+        }
         if (u == 3) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -171,7 +176,7 @@ void conv_x3r_kernel(X3Args a) {
     load_a(1, 1);
     store_a(0, 0);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) load_b(p, 0);
+    for (int p = 0; p < NP; ++p) load_b(p, 0);
     const int nst = a.nchunks;
     int kc = 0;
     for (; kc + 4 <= nst; kc += 4) { step(kc, 0); step(kc + 1, 1); step(kc + 2, 2); step(kc + 3, 3); }

@@ -314,9 +314,10 @@ void launch_x3p(const X3Args& a, hipStream_t s) {
 #endif
 
 template <int BN, int WM_, int WN_>
-void launch_x3q(const X3Args& a, hipStream_t s) {
+void launch_x3q(const X3Args& a, hipStream_t s, int np) {      // np = 1: bf16-operand mode (hi plane only)
     const size_t lds = 2 * 3 * 7 * 1024 + 1024;
-    hipLaunchKernelGGL((conv_x3q_kernel<BN, WM_, WN_>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    if (np == 1) hipLaunchKernelGGL((conv_x3q_kernel<BN, WM_, WN_, 0, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_x3q_kernel<BN, WM_, WN_>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
 #ifdef TSNET_TOOLS
@@ -331,8 +332,13 @@ void launch_x3p_mixed(const X3Args& a, int nsplit, hipStream_t s) {
 #endif
 
 template <int KS, int BN, int WM_, int WN_>
-void launch_x3r(const X3Args& a, hipStream_t s) {
+void launch_x3r(const X3Args& a, hipStream_t s, int np) {
     const size_t lds = 2 * 3 * 128 * 32;
+    if (np == 1) {
+        if (a.Cin < 16) hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, true, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, false, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+        return;
+    }
     if (a.Cin < 16) hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
@@ -365,7 +371,7 @@ void launch_x3_abl(X3Args a, hipStream_t s) {     // diagnostic: 3x3, tile 0 (12
 #endif
 
 template <int KS>
-int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stats partials per image (0 = none)
+int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s, int np = 3) {     // returns stats partials per image (0 = none)
     int best = forced_tile;
     if (best < 0) {
         static const char* const e_tile = getenv("TSNET_X3_TILE");     // in-situ A/B switch, read once
@@ -416,11 +422,11 @@ int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s) {     // returns stat
         case 12: launch_x3p<64, 2, 2>(a, s); break;
         case 13: launch_x3p_mixed(a, mixed_split, s); break;
 #endif
-        case 14: launch_x3q<128, 2, 2>(a, s); break;
-        case 15: launch_x3q<64, 2, 2>(a, s); break;
-        case 16: launch_x3r<KS, 128, 2, 2>(a, s); break;
-        case 17: launch_x3r<KS, 64, 2, 2>(a, s); break;
-        case 18: launch_x3r<KS, 32, 4, 1>(a, s); break;
+        case 14: launch_x3q<128, 2, 2>(a, s, np); break;
+        case 15: launch_x3q<64, 2, 2>(a, s, np); break;
+        case 16: launch_x3r<KS, 128, 2, 2>(a, s, np); break;
+        case 17: launch_x3r<KS, 64, 2, 2>(a, s, np); break;
+        case 18: launch_x3r<KS, 32, 4, 1>(a, s, np); break;
         default: throw ArgError("conv(x3): this tile is only built into the tools library (superseded kernel generation)");
     }
     if (a.stat_part && a.fin_counter) return -1;     // statistics complete: alpha / beta written by the kernel
@@ -436,6 +442,7 @@ struct X3Call {
     float* fin_alpha = nullptr; float* fin_beta = nullptr; int* fin_counter = nullptr;   // optional in-kernel finalize
     int variant = -1;
     int tclass = TSNET_T_CONV;
+    int np = 3;            // 1 = bf16-operand mode: only the hi plane is read (one MFMA product per k-group)
 };
 
 void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
@@ -513,9 +520,9 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
     if (abl) throw ArgError("ablation variants are only built into the tools library");
 #endif
     switch (L.ks) {
-        case 1: c.stat_S = launch_x3_ks<1>(g, forced, ctx.stream); break;
-        case 3: c.stat_S = launch_x3_ks<3>(g, forced, ctx.stream); break;
-        case 7: c.stat_S = launch_x3_ks<7>(g, forced, ctx.stream); break;
+        case 1: c.stat_S = launch_x3_ks<1>(g, forced, ctx.stream, c.np); break;
+        case 3: c.stat_S = launch_x3_ks<3>(g, forced, ctx.stream, c.np); break;
+        case 7: c.stat_S = launch_x3_ks<7>(g, forced, ctx.stream, c.np); break;
         default: throw ArgError("conv: kernel size must be 1, 3 or 7");
     }
     check_launch("conv_x3");
@@ -553,18 +560,19 @@ inline int h2_scale_log2(float bound) {
 
 template <int BN, int NPROD>
 void launch_h2(const H2Args& a, hipStream_t s) {
-    const size_t lds = 2 * 2 * 7168 + 2048 + (size_t)2 * a.Cin * 4;
+    const size_t lds = 2 * 2 * 7168 + 2048 + (size_t)2 * a.Cin * 4;      // two-plane layout offsets in every mode
     if (a.in_alpha) hipLaunchKernelGGL((conv_h2_kernel<BN, 2, 2, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_h2_kernel<BN, 2, 2, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
 void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
-    if (!h2_layer_ok(L) || !L.wh) throw ArgError("conv(h2): layer is not a 3x3 / stride-1 / pad-1 layer with fp16x2 weights");
+    const bool bf16 = c.nprod == 1;                // bf16-operand mode: the hi plane of the bf16x3 packing, no scales
+    if (!h2_layer_ok(L) || !(bf16 ? (const void*)L.w3 : (const void*)L.wh)) throw ArgError("conv(h2): layer is not a 3x3 / stride-1 / pad-1 layer with packed 16-bit weights");
     H2Args g{};
     g.x = c.x; g.in_alpha = c.alpha; g.in_beta = c.alpha ? c.beta : nullptr; g.in_relu = c.relu;
-    const int sa = h2_scale_log2(c.bound);
+    const int sa = bf16 ? 0 : h2_scale_log2(c.bound);
     g.in_scale = std::ldexp(1.0f, sa); g.in_unscale = std::ldexp(1.0f, -sa);
-    g.w = L.wh; g.w_unscale = L.wh_unscale; g.bias = L.bias; g.y = c.y; g.y3 = nullptr;
+    g.w = bf16 ? L.w3 : L.wh; g.w_unscale = bf16 ? nullptr : L.wh_unscale; g.bias = L.bias; g.y = c.y; g.y3 = nullptr;
     g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
     g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.Ho = c.H; g.Wo = c.W; g.Cout = L.cout; g.Npad = L.npad;
     g.reflect = L.reflect; g.nchunks = (9 * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
@@ -610,8 +618,59 @@ void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
     }
     if (c.nprod == 3) { if (bn == 64) launch_h2<64, 3>(g, ctx.stream); else launch_h2<128, 3>(g, ctx.stream); }
     else if (c.nprod == 4) { if (bn == 64) launch_h2<64, 4>(g, ctx.stream); else launch_h2<128, 4>(g, ctx.stream); }
-    else throw ArgError("conv(h2): 3 or 4 products");
+    else if (c.nprod == 1) { if (bn == 64) launch_h2<64, 1>(g, ctx.stream); else launch_h2<128, 1>(g, ctx.stream); }
+    else throw ArgError("conv(h2): 1 (bf16 operands), 3 or 4 products");
     check_launch("conv_h2");
+    c.stat_S = !c.stat_part ? 0 : (g.fin_counter ? -1 : hw / 128);
+    ++g_launch_counters[0];
+}
+
+// ---- h2r: the stride-2 downsampling convolutions on the same arithmetic (conv_h2.hpp, implicit GEMM)
+inline bool h2r_layer_ok(const ConvLayer& L) {
+    return L.ks == 3 && L.stride == 2 && L.pad == 1 && !L.reflect && L.cin_pad >= 16 && (L.cin_pad & (L.cin_pad - 1)) == 0 && L.npad % 64 == 0;
+}
+
+template <int BN, int NPROD>
+void launch_h2r(const H2rArgs& a, hipStream_t s) {
+    const size_t lds = 2 * 2 * 128 * 32 + (size_t)2 * a.Cin * 4;
+    if (a.in_alpha) hipLaunchKernelGGL((conv_h2r_kernel<3, BN, 2, 2, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_h2r_kernel<3, BN, 2, 2, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+}
+
+void run_conv_h2r(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
+    const bool bf16 = c.nprod == 1;
+    if (!h2r_layer_ok(L) || !(bf16 ? (const void*)L.w3 : (const void*)L.wh)) throw ArgError("conv(h2r): layer is not a 3x3 / stride-2 / zero-pad layer with packed 16-bit weights");
+    H2rArgs g{};
+    g.x = c.x; g.in_alpha = c.alpha; g.in_beta = c.alpha ? c.beta : nullptr; g.in_relu = c.relu;
+    const int sa = bf16 ? 0 : h2_scale_log2(c.bound);
+    g.in_scale = std::ldexp(1.0f, sa); g.in_unscale = std::ldexp(1.0f, -sa);
+    g.w = bf16 ? L.w3 : L.wh; g.w_unscale = bf16 ? nullptr : L.wh_unscale; g.bias = L.bias; g.y = c.y; g.y3 = nullptr;
+    g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
+    g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
+    g.stride = 2; g.pad = 1; g.taps = 9; g.reflect = 0;
+    g.Ho = (c.H + 2 - 3) / 2 + 1; g.Wo = (c.W + 2 - 3) / 2 + 1;
+    g.Cout = L.cout; g.Npad = L.npad; g.nchunks = (9 * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
+    const int hw = g.Ho * g.Wo;
+    if (hw % 128) throw ArgError("conv(h2r): an output image must be a whole number of 128-row tiles");
+    if (c.alpha && !c.beta) throw ArgError("conv(h2r): alpha without beta");
+    if ((double)c.N * c.H * c.W * L.cin_pad * 4 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
+        throw ArgError("conv(h2r): tensor too large for 32-bit buffer offsets");
+    int bn = c.bn;
+    if (bn == 0) {       // ceil(tiles / 256) x tile area, as for the patch kernel
+        const long tm = g.M / 128;
+        const double c64 = (double)((tm * ((g.Cout + 63) / 64) + 255) / 256) * 64.0;
+        const double c128 = (double)((tm * ((g.Cout + 127) / 128) + 255) / 256) * 128.0 / 1.15;
+        bn = (g.Npad % 128 == 0 && g.Cout > 64 && c128 < c64) ? 128 : 64;
+    }
+    if ((bn != 64 && bn != 128) || g.Npad % bn) throw ArgError("conv(h2r): tile width must be 64 or 128 and divide the padded width");
+    g.tiles_m = g.M / 128; g.tiles_n = (g.Cout + bn - 1) / bn;
+    g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f; g.fin_S = hw / 128;
+    g.fin_counter = (c.stat_part && c.fin_counter && hw / 128 <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= kFinCounterInts) ? c.fin_counter : nullptr;
+    TimeScope ts(ctx, c.tclass);
+    if (c.nprod == 3) { if (bn == 64) launch_h2r<64, 3>(g, ctx.stream); else launch_h2r<128, 3>(g, ctx.stream); }
+    else if (c.nprod == 1) { if (bn == 64) launch_h2r<64, 1>(g, ctx.stream); else launch_h2r<128, 1>(g, ctx.stream); }
+    else throw ArgError("conv(h2r): 1 (bf16 operands) or 3 products");
+    check_launch("conv_h2r");
     c.stat_S = !c.stat_part ? 0 : (g.fin_counter ? -1 : hw / 128);
     ++g_launch_counters[0];
 }
@@ -833,6 +892,7 @@ struct tsnet_engine {
     float* FT = nullptr;                  // (B,P,2C) target half of fuse_c1, computed once per forward
     // ---- bf16x3 mode (conv_x3.hpp): every conv input exists as three bf16 planes
     bool x3 = true;
+    int np = 3;                           // 1 = bf16-operand mode (cfg.operand_mode): one plane / one product everywhere
     bool h2 = true;                       // fp16x2 patch convolution (conv_h2.hpp) for the 3x3 / stride-1 layers whose input is bounded; TSNET_H2=0: round-1 schedule
     float* U_f32[8] = {nullptr};          // fp32 upsampled decoder inputs (h2 schedule; the bf16x3 schedule writes planes only)
     unsigned short* wpack3 = nullptr; size_t wpack3_elems = 0;
@@ -901,11 +961,14 @@ struct tsnet_engine {
                    std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks);
     void resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float* y1, float* y2, int N, int hh, int ww);
     void forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
+    // every convolution of the forward goes through these two: they apply the engine's operand mode
+    void rx3(Ctx& ctx, const ConvLayer& L, X3Call& c) { c.np = np; run_conv_x3(ctx, L, c); }
+    void rh2(Ctx& ctx, const ConvLayer& L, H2Call& c) { c.nprod = np == 1 ? 1 : 3; run_conv_h2(ctx, L, c); }
     void conv_stats_x3(Ctx& ctx, const ConvLayer& L, X3Call& c, int N, int HW, float* alpha, float* beta) {
         double* pt = ctx.lane ? part_side : part;
         c.stat_part = pt;
         c.fin_alpha = alpha; c.fin_beta = beta; c.fin_counter = ctx.lane ? fin_counter_side : fin_counter;
-        run_conv_x3(ctx, L, c);
+        rx3(ctx, L, c);
         if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
         if (c.stat_S > 0) {
             TimeScope ts(ctx, TSNET_T_STATS);
@@ -919,7 +982,8 @@ struct tsnet_engine {
         double* pt = ctx.lane ? part_side : part;
         c.stat_part = pt;
         c.fin_alpha = alpha; c.fin_beta = beta; c.fin_counter = ctx.lane ? fin_counter_side : fin_counter;
-        run_conv_h2(ctx, L, c);
+        if (L.stride == 2) { c.nprod = np == 1 ? 1 : 3; run_conv_h2r(ctx, L, c); }
+        else rh2(ctx, L, c);
         if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
         TimeScope ts(ctx, TSNET_T_STATS);
         hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + 63) / 64, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
@@ -1030,7 +1094,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     off += round_up((int)all_layers.size(), 64);
     size_t oh = 0;
     std::vector<size_t> offs_h(all_layers.size(), 0);
-    if (x3 && h2) for (size_t i = 0; i < all_layers.size(); ++i) if (h2_layer_ok(*all_layers[i])) { offs_h[i] = oh; oh += 2 * (size_t)all_layers[i]->kpad * all_layers[i]->npad; }
+    if (x3 && h2) for (size_t i = 0; i < all_layers.size(); ++i) if (h2_layer_ok(*all_layers[i]) || h2r_layer_ok(*all_layers[i])) { offs_h[i] = oh; oh += 2 * (size_t)all_layers[i]->kpad * all_layers[i]->npad; }
     off = (off + 63) / 64 * 64;
     const size_t h2_off = off;
     off += (oh + 1) / 2;
@@ -1069,11 +1133,11 @@ void tsnet_engine::alloc_all(hipStream_t s) {
             ++li;
         }
     }
-    if (x3 && h2) {                        // fp16x2 planes: per layer a power-of-two scale from the largest |weight|
+    if (x3 && h2 && np != 1) {             // fp16x2 planes: per layer a power-of-two scale from the largest |weight| (the bf16-operand mode reads the bf16x3 hi plane)
         unsigned short* wh_base = reinterpret_cast<unsigned short*>(wpack + h2_off);
         for (size_t i = 0; i < all_layers.size(); ++i) {
             ConvLayer* L = all_layers[i];
-            if (!h2_layer_ok(*L)) continue;
+            if (!h2_layer_ok(*L) && !h2r_layer_ok(*L)) continue;
             const Param& pw = params[pindex[L->wparam]];
             float mx = 0.f;
             for (float v : pw.host) { const float av = std::fabs(v); if (av > mx) mx = av; }
@@ -1238,11 +1302,22 @@ void tsnet_engine::encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned
     auto st = next_ab(ctx);
     conv_stats_x3(ctx, L[0], a, N, hh * ww, st.first, st.second);
     for (int l = 1; l <= cfg.n_downsampling; ++l) {
-        run_norm_act(ctx, raw[l - 1], st.first, st.second, 1, nullptr, N, hh * ww, L[l].cin_pad, nullptr, raw3[l - 1]);
-        X3Call d; d.x3 = raw3[l - 1]; d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
-        hh /= 2; ww /= 2;
+        // the downsampling convolution reads relu(IN(previous)): on the h2 schedule the transform is applied while the im2col tile is
+        // staged (conv_h2r), otherwise one elementwise pass materialises it as bf16x3 planes for conv_x3r
+        const bool via_h2r = h2 && h2r_layer_ok(L[l]) && ((hh / 2) * (ww / 2)) % 128 == 0 && (np == 1 ? L[l].w3 != nullptr : L[l].wh != nullptr);
+        auto prev = st;
         st = next_ab(ctx);
-        conv_stats_x3(ctx, L[l], d, N, hh * ww, st.first, st.second);
+        if (via_h2r) {
+            H2Call d; d.x = raw[l - 1]; d.alpha = prev.first; d.beta = prev.second; d.relu = 1; d.bound = std::sqrt((float)(hh * ww));
+            d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
+            hh /= 2; ww /= 2;
+            conv_stats_h2(ctx, L[l], d, N, hh * ww, st.first, st.second);
+        } else {
+            run_norm_act(ctx, raw[l - 1], prev.first, prev.second, 1, nullptr, N, hh * ww, L[l].cin_pad, nullptr, raw3[l - 1]);
+            X3Call d; d.x3 = raw3[l - 1]; d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
+            hh /= 2; ww /= 2;
+            conv_stats_x3(ctx, L[l], d, N, hh * ww, st.first, st.second);
+        }
     }
     const bool use_h2 = h2 && (hh % kPatchRows == 0) && (ww % kPatchCols == 0);
     run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea, use_h2 ? nullptr : out_fea3);
@@ -1277,10 +1352,10 @@ void tsnet_engine::target_chain_x3(Ctx& ctx, const float* tar_lbl, int B) {
     run_l2norm(ctx, tar_fea, that, B * P, C);
     if (h2_feat()) {                                                                   // shared target half of fuse conv1
         H2Call t; t.x = tar_fea; t.bound = std::sqrt((float)P); t.N = B; t.H = h; t.W = w; t.y = FT;
-        run_conv_h2(ctx, fuse_c1_tar, t);
+        rh2(ctx, fuse_c1_tar, t);
     } else {
         X3Call t; t.x3 = tar3; t.N = B; t.H = h; t.W = w; t.y = FT;
-        run_conv_x3(ctx, fuse_c1_tar, t);
+        rx3(ctx, fuse_c1_tar, t);
     }
 }
 
@@ -1332,7 +1407,7 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
             check_launch("fuse_resid_mean");
         }
         X3Call c; c.x3 = zbar3; c.N = B; c.H = h; c.W = w; c.y = sg; c.y3 = sg3;
-        run_conv_x3(ctx, fuse_out, c);
+        rx3(ctx, fuse_out, c);
     }
 
     // ---- decoder
@@ -1341,7 +1416,7 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
     {
         X3Call a; a.x3 = pg3; a.x23 = sg3; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
         a.y3 = cfg.n_blocks > 0 ? D3 : nullptr;
-        run_conv_x3(ctx, dec_map, a);
+        rx3(ctx, dec_map, a);
     }
     for (int i = 0; i < cfg.n_blocks; ++i) {
         // the decoder's stream starts at dec_map's raw output (no bound): its first convolutions stay on the bf16x3 planes
@@ -1581,6 +1656,11 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
           // bf16x3 convs (conv_x3.hpp): needs 16-channel granularity everywhere except the stems, and the vector head
           e->x3 = !(x && !atoi(x)) && (cfg->ngf % 16 == 0) && e->vector_head && !e->fuse_norm_in_loader; }
         { const char* hh2 = getenv("TSNET_H2"); e->h2 = e->x3 && !(hh2 && !atoi(hh2)); }
+        if (cfg->operand_mode != 0 && cfg->operand_mode != 1) return bad("operand_mode must be 0 (fp32-class) or 1 (bf16 operands)");
+        if (cfg->operand_mode == 1) {
+            if (!e->x3) return bad("bf16 operands need the split-plane schedule (ngf % 16 == 0)");
+            e->np = 1;
+        }
         { const char* sf = getenv("TSNET_SPLIT_FUSE"); e->split_fuse = !e->fuse_norm_in_loader && !(sf && !atoi(sf)); }
         *out = e;
     } catch (const std::exception& ex) { g_create_error = ex.what(); return TSNET_ERR_NOMEM; }

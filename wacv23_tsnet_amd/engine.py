@@ -44,7 +44,7 @@ class TSNetEngine:
     def __init__(self, *, label_nc: int, n_blocks: int, n_downsampling: int = 3, n_source: int = 3, ngf: int = 64,
                  enc_blocks: int = 9, addcoords: bool = True, pose_composite: bool = False,
                  pose_mean: Sequence[float] = POSE_MEAN, height: int = 256, width: int = 256, max_batch: int = 4,
-                 lib=None):
+                 operands: str = "fp32", lib=None):
         self.lib = lib if lib is not None else _lib.load()
         cfg = _lib.TsnetCfg()
         cfg.label_nc, cfg.n_blocks, cfg.n_downsampling, cfg.n_source = label_nc, n_blocks, n_downsampling, n_source
@@ -52,6 +52,9 @@ class TSNetEngine:
         for i in range(3):
             cfg.pose_mean[i] = float(pose_mean[i])
         cfg.height, cfg.width, cfg.max_batch = height, width, max_batch
+        if operands not in ("fp32", "bf16"):
+            raise ValueError("operands must be 'fp32' (fp32-class arithmetic) or 'bf16' (bf16 conv operands, fp32 accumulate)")
+        cfg.operand_mode = 1 if operands == "bf16" else 0
         self.cfg = cfg
         self.K = n_source
         self.h = height >> n_downsampling
