@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): host CPU topology and oracle throughput vs torch thread count."""
 import os, sys, time, json, subprocess
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
 import torch
 from oracle import tsnet_oracle as O
 print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))

@@ -1,7 +1,7 @@
 """GPU box: demo post-processing -- device kernels vs the reference's host path (oracle) per frame."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/ (helpers)
 import torch
 from oracle import demo_oracle as DO
 from wacv23_tsnet_amd import demo

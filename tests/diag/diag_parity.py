@@ -1,8 +1,8 @@
 """Diagnostic (GPU box): where does the HIP path's deviation from the fp32 oracle sit relative to the
 oracle's own fp32 rounding noise?  Compares GPU fp32, oracle fp32 and oracle fp64 ("truth") at cfg0."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/ (helpers)
 import torch
 import helpers as Hh
 from oracle import tsnet_oracle as O

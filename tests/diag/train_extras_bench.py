@@ -1,6 +1,6 @@
 """GPU box: cost of the training-mode extras at the cfg1 shapes, device vs the oracle's host path."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
 import torch
 from oracle import tsnet_oracle as O
 from wacv23_tsnet_amd.engine import TSNetEngine

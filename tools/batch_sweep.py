@@ -2,16 +2,16 @@
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import tsnet_oracle as O
+from wacv23_tsnet_amd import synth
 from wacv23_tsnet_amd.engine import TSNetEngine
 H = W = 256
-cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_downsampling=3, n_source=3)
-sd = O.synth_state_dict(cfg, seed=0)
+sd = None
 out = {}
 for B in (1, 2, 4, 8, 16, 32):
     eng = TSNetEngine(label_nc=2, n_blocks=0, n_downsampling=3, n_source=3, height=H, width=W, max_batch=B)
+    sd = sd or synth.state_dict(eng.param_shapes(), seed=0)
     eng.load_state_dict(sd); eng.finalize("cuda")
-    inp = O.synth_inputs(cfg, B, H, W, seed=1)
+    inp = synth.inputs(3, 2, B, H, W, seed=1)
     si, sl, sb, tl, tb = [[t.cuda() for t in x] if isinstance(x, list) else x.cuda() for x in inp]
     for _ in range(3): eng.forward(si, sl, sb, tl, tb)
     torch.cuda.synchronize(); t0 = time.perf_counter()

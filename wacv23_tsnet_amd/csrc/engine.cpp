@@ -783,6 +783,24 @@ void finish_stats(Ctx& ctx, const ConvCall& c, const float* y, int N, int HW, in
     check_launch("in_finalize2");
 }
 
+// y = x + add[n % add_nmod] with the InstanceNorm statistics of y -> (alpha, beta); `part` must hold N*64*C*2 doubles
+void run_add_stats(Ctx& ctx, const float* x, const float* add, int add_nmod, float* y, int N, int HW, int C, double* part, float* alpha, float* beta) {
+    if (C & 3) throw ArgError("add_stats: C must be a multiple of 4");
+    TimeScope ts(ctx, TSNET_T_STATS);
+    const int cq = C / 4, cols = cq < 256 ? cq : 256, R = 256 / cols;
+    int S = (HW + R * 8 - 1) / (R * 8);
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    const int rps = (HW + S - 1) / S;
+    S = (HW + rps - 1) / rps;
+    AddStatsArgs sa{x, add, y, part, HW, C, S, rps, add_nmod > 0 ? add_nmod : 1};
+    hipLaunchKernelGGL(add_stats_partial_kernel, dim3(S, N, (cq + 255) / 256), dim3(256), 0, ctx.stream, sa);
+    check_launch("add_stats_partial");
+    const int NC = N * C;
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, ctx.stream, part, alpha, beta, NC, C, S, HW, 1e-5f);
+    check_launch("in_finalize");
+}
+
 void run_norm_act(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, const float* resid,
                   int N, int HW, int C, float* y, unsigned short* y3 = nullptr) {
     if (C & 3) throw ArgError("norm_act: C must be a multiple of 4");
@@ -916,6 +934,7 @@ struct tsnet_engine {
     float *X = nullptr, *Y1 = nullptr, *Y2 = nullptr;
     float *tar_fea = nullptr, *that = nullptr, *shat = nullptr, *flow = nullptr, *pg = nullptr;
     float *F1 = nullptr, *F2 = nullptr, *zbar = nullptr, *sg = nullptr;
+    float* F1s = nullptr;                 // per-source half of FuseNet's first convolution (+ bias): computed by set_sources, cached in clip mode
     float *D = nullptr, *DY1 = nullptr, *DY2 = nullptr;
     std::vector<float*> U, R;
     float* ab[4][2] = {{nullptr}};
@@ -1198,7 +1217,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     const size_t fe = (size_t)P * C;
     want(&X, NB * fe); want(&Y1, NB * fe); want(&Y2, NB * fe);
     want(&tar_fea, B * fe); want(&that, B * fe); want(&shat, NB * fe); want(&flow, NB * P * 2); want(&pg, B * fe);
-    want(&F1, NB * fe * 2); want(&F2, NB * fe * 2); want(&zbar, B * fe * 2); want(&sg, B * fe); want(&FT, B * fe * 2);
+    want(&F1, NB * fe * 2); want(&F2, NB * fe * 2); if (x3) want(&F1s, NB * fe * 2); want(&zbar, B * fe * 2); want(&sg, B * fe); want(&FT, B * fe * 2);
     want(&D, B * fe); want(&DY1, B * fe); want(&DY2, B * fe);
     U.assign(cfg.n_downsampling, nullptr); R.assign(cfg.n_downsampling, nullptr);
     for (int i = 0; i < cfg.n_downsampling; ++i) {
@@ -1387,15 +1406,13 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
     {
         auto s1 = next_ab();
         auto s2 = next_ab();
+        // F1 = conv_src(src) [from set_sources] + conv_tar(tar) [target chain], and its InstanceNorm statistics
+        run_add_stats(ctx, F1s, FT, B, F1, NB, P, 2 * C, part, s1.first, s1.second);
         if (h2_feat()) {
-            H2Call a; a.x = X; a.bound = enc_bound(); a.N = NB; a.H = h; a.W = w; a.y = F1; a.addend = FT; a.add_nmod = B;
-            conv_stats_h2(ctx, fuse_c1_src, a, NB, P, s1.first, s1.second);
             H2Call b; b.x = F1; b.alpha = s1.first; b.beta = s1.second; b.relu = 1; b.bound = std::sqrt((float)P);
             b.N = NB; b.H = h; b.W = w; b.y = F2;
             conv_stats_h2(ctx, fuse_c2, b, NB, P, s2.first, s2.second);
         } else {
-            X3Call a; a.x3 = X3; a.N = NB; a.H = h; a.W = w; a.y = F1; a.addend = FT; a.add_nmod = B;
-            conv_stats_x3(ctx, fuse_c1_src, a, NB, P, s1.first, s1.second);
             run_norm_act(ctx, F1, s1.first, s1.second, 1, nullptr, NB, P, 2 * C, nullptr, T3);
             X3Call b; b.x3 = T3; b.N = NB; b.H = h; b.W = w; b.y = F2;
             conv_stats_x3(ctx, fuse_c2, b, NB, P, s2.first, s2.second);
@@ -1511,6 +1528,17 @@ void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const floa
     if (x3) encode_x3(ctx, img_enc, x_img3, K * B, raw_img, raw3_img, X, X3, cfg.enc_blocks);
     else encode(ctx, img_enc, x_img, K * B, cp_img, raw_img, X, cfg.enc_blocks);
     run_l2norm(ctx, X, shat, K * B * P, C);
+    if (x3) {
+        // the per-source half of FuseNet's first convolution (conv(cat(src, tar)) = conv_src(src) + conv_tar(tar), TSNet.py:195-197)
+        // depends on the sources only: computed here, so a driving frame of a clip does not pay for it
+        if (h2_feat()) {
+            H2Call a; a.x = X; a.bound = enc_bound(); a.N = K * B; a.H = h; a.W = w; a.y = F1s;
+            rh2(ctx, fuse_c1_src, a);
+        } else {
+            X3Call a; a.x3 = X3; a.N = K * B; a.H = h; a.W = w; a.y = F1s;
+            rx3(ctx, fuse_c1_src, a);
+        }
+    }
     cached_B = B;
 }
 

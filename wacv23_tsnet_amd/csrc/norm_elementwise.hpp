@@ -71,6 +71,64 @@ __global__ __launch_bounds__(256) void in_stats_partial_kernel(StatsArgs a) {
     }
 }
 
+// The same reduction fused with an addition: y[n] = x[n] + add[n % add_nmod], statistics of y.  FuseNet's first convolution is split at
+// the channel concat (TSNet.py:195-197: cat(src_fea, tar_fea) -> conv): the per-source half is computed once per source set
+// (tsnet_set_sources, cached in clip mode), the shared target half once per driving frame; this kernel joins them and produces the
+// InstanceNorm statistics of the sum.  One-shot forward and clip mode run the SAME kernels in the same order: bit-identical results.
+struct AddStatsArgs {
+    const float* x;      // (N, HW, C)
+    const float* add;    // (add_nmod, HW, C)
+    float* y;            // (N, HW, C)
+    double* part;        // (N, S, C, 2)
+    int HW, C, S, rows_per_split, add_nmod;
+};
+
+__global__ __launch_bounds__(256) void add_stats_partial_kernel(AddStatsArgs a) {
+    __shared__ double red[256 * 8];
+    const int cq_total = a.C >> 2;
+    const int cols = cq_total < 256 ? cq_total : 256;
+    const int R = 256 / cols;
+    const int tid = threadIdx.x;
+    const int cq = tid % cols + blockIdx.z * 256;
+    const int rg = tid / cols;
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int r0 = s * a.rows_per_split;
+    int r1 = r0 + a.rows_per_split;
+    if (r1 > a.HW) r1 = a.HW;
+    double sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    if (rg < R && cq < cq_total) {
+        const size_t cb = (size_t)cq * 4;
+        const float* bx = a.x + ((size_t)n * a.HW) * a.C + cb;
+        const float* ba = a.add + ((size_t)(n % a.add_nmod) * a.HW) * a.C + cb;
+        float* by = a.y + ((size_t)n * a.HW) * a.C + cb;
+        for (int r = r0 + rg; r < r1; r += R) {
+            const float4 u = *reinterpret_cast<const float4*>(bx + (size_t)r * a.C);
+            const float4 w = *reinterpret_cast<const float4*>(ba + (size_t)r * a.C);
+            float4 v;
+            v.x = u.x + w.x; v.y = u.y + w.y; v.z = u.z + w.z; v.w = u.w + w.w;
+            *reinterpret_cast<float4*>(by + (size_t)r * a.C) = v;
+            sm[0] += v.x; sq[0] += (double)v.x * v.x;
+            sm[1] += v.y; sq[1] += (double)v.y * v.y;
+            sm[2] += v.z; sq[2] += (double)v.z * v.z;
+            sm[3] += v.w; sq[3] += (double)v.w * v.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = sm[e]; red[tid * 8 + 4 + e] = sq[e]; }
+    __syncthreads();
+    if (rg == 0 && cq < cq_total) {
+        double tsm[4] = {0, 0, 0, 0}, tsq[4] = {0, 0, 0, 0};
+        for (int g = 0; g < R; ++g) {
+            const int t = g * cols + tid;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { tsm[e] += red[t * 8 + e]; tsq[e] += red[t * 8 + 4 + e]; }
+        }
+        double* o = a.part + (((size_t)n * a.S + s) * a.C + (size_t)cq * 4) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e * 2] = tsm[e]; o[e * 2 + 1] = tsq[e]; }
+    }
+}
+
 // stage 2: alpha = 1/sqrt(var+eps), beta = -mean*alpha  (the x*alpha+beta form ATen's CPU
 // batch-norm transform uses), one thread per (n, c).
 __global__ void in_finalize_kernel(const double* __restrict__ part, float* __restrict__ alpha, float* __restrict__ beta,
