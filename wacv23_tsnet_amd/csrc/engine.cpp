@@ -824,6 +824,21 @@ void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* bet
     check_launch("upsample2x");
 }
 
+// RGB head: head_conv2_kernel (weights in LDS, two pixels per thread); TSNET_HEAD=1 selects the first-generation kernel (A/B switch)
+void launch_head(const HeadArgs& ha, int hh, int ww, int B, hipStream_t s) {
+    static const bool old_head = [] { const char* e = getenv("TSNET_HEAD"); return e && atoi(e) == 1; }();
+    if (old_head) {
+        const int tiles = ((ww + kHeadT - 1) / kHeadT) * ((hh + kHeadT - 1) / kHeadT);
+        hipLaunchKernelGGL(head_conv_kernel, dim3(tiles, B), dim3(256), 0, s, ha);
+    } else {
+        const int tiles = ((ww + kHead2W - 1) / kHead2W) * ((hh + kHead2H - 1) / kHead2H);
+        const size_t lds = (size_t)((kHeadCh / 4) * kHead2Rows * kHead2Pitch + 49 * kHeadCh) * sizeof(float4);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_conv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(head_conv2_kernel, dim3(tiles, B), dim3(256), lds, s, ha);
+    }
+    check_launch("head_conv");
+}
+
 void run_l2norm(Ctx& ctx, const float* x, float* y, int rows, int C) {
     TimeScope ts(ctx, TSNET_T_ELEMWISE);
     hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, ctx.stream, x, y, rows, C);
@@ -1468,9 +1483,7 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
         ha.N = B; ha.H = hh; ha.W = ww; ha.C = cc;
         ha.composite = cfg.pose_composite; ha.fore_x0 = 64; ha.fore_x1 = 192;
         for (int c = 0; c < 3; ++c) ha.bg[c] = (-cfg.pose_mean[c]) / 255.0f;
-        const int tiles = ((ww + kHeadT - 1) / kHeadT) * ((hh + kHeadT - 1) / kHeadT);
-        hipLaunchKernelGGL(head_conv_kernel, dim3(tiles, B), dim3(256), 0, ctx.stream, ha);
-        check_launch("head_conv");
+        launch_head(ha, hh, ww, B, ctx.stream);
     }
     last_B = B;
 }
@@ -1622,9 +1635,7 @@ void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* t
         ha.N = B; ha.H = hh; ha.W = ww; ha.C = cc;
         ha.composite = cfg.pose_composite; ha.fore_x0 = 64; ha.fore_x1 = 192;          // TSNet_pose.py:279
         for (int c = 0; c < 3; ++c) ha.bg[c] = (-cfg.pose_mean[c]) / 255.0f;             // TSNet_pose.py:276
-        const int tiles = ((ww + kHeadT - 1) / kHeadT) * ((hh + kHeadT - 1) / kHeadT);
-        hipLaunchKernelGGL(head_conv_kernel, dim3(tiles, B), dim3(256), 0, ctx.stream, ha);
-        check_launch("head_conv");
+        launch_head(ha, hh, ww, B, ctx.stream);
         last_B = B;
         return;
     }
