@@ -170,6 +170,11 @@ int tsnet_op_conv2d_x3(const float* x, int N, int H, int W, int Cin, const float
 int tsnet_op_conv2d_h2(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int pad_mode,
                        const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, int tile_n,
                        float* y, void* stream);
+/* The encoder's other convolutions on the same arithmetic, as an implicit GEMM (conv_h2r): ksize = 3 -> 3x3 / stride 2 / zero pad 1
+ * (downsampling, TSNet.py:70), ksize = 7 -> 7x7 / stride 1 / reflection pad 3 (stem, TSNet.py:66; Cin = 8 or a power of two >= 16).
+ * The output image must be a whole number of 128-position tiles.  nprod = 3, or 1 for bf16 operands. */
+int tsnet_op_conv2d_h2r(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int ksize,
+                        const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, float* y, void* stream);
 int tsnet_op_instnorm_stats(const float* x, int N, int HW, int C, float* alpha, float* beta, void* stream);
 int tsnet_op_norm_act(const float* x, const float* alpha, const float* beta, int relu, const float* resid,
                       int N, int HW, int C, float* y, void* stream);

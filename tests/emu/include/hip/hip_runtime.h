@@ -99,6 +99,8 @@ template <class T> static inline T emu_buf_load16(const tsnet_rsrc_t& r, unsigne
 #define __hip_atomic_load(p, order, scope) (*(p))
 template <class T> static inline T emu_fetch_add(T* p, T v) { T o = *p; *p = o + v; return o; }
 #define __hip_atomic_fetch_add(p, v, order, scope) emu_fetch_add((p), (v))
+template <class T> static inline T emu_fetch_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+#define __hip_atomic_fetch_max(p, v, order, scope) emu_fetch_max((p), (v))
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 

@@ -90,6 +90,35 @@ def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, n
         return y.cpu()
     return ((nchw(y.cpu()).double() - ref).abs().max() / ref.abs().max()).item()
 
+
+def conv_h2r_case(lib, dev, N, H, W, Cin, Cout, ksize, norm=False, bias=True, seed=0):
+    """the encoder's stem (7x7, reflection pad 3) and downsampling (3x3, stride 2, zero pad 1) convolutions, optionally on
+    relu(x*alpha+beta), vs tsnet_op_conv2d_h2r (fp16 x 2 implicit GEMM with the transform fused).  Returns max|d| / max|ref|."""
+    x = _rand(seed, "x", (N, Cin, H, W))
+    w = _rand(seed, "w", (Cout, Cin, ksize, ksize)) * (2.0 / (Cin * ksize * ksize) ** 0.5)
+    b = _rand(seed, "b", (Cout,)) if bias else None
+    xin, al, be = x, None, None
+    if norm:
+        al = _rand(seed, "al", (N, Cin), 0.5, 1.5)
+        be = _rand(seed, "be", (N, Cin), -0.3, 0.3)
+        xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
+    bd64 = None if b is None else b.double()
+    if ksize == 7:
+        ref = F.conv2d(F.pad(xin.double(), (3,) * 4, mode="reflect"), w.double(), bd64)
+    else:
+        ref = F.conv2d(xin.double(), w.double(), bd64, stride=2, padding=1)
+    bound = float(xin.abs().max()) * 1.0001 + 1e-30
+    xd = nhwc(x).to(dev)
+    y = torch.full((N, ref.shape[2], ref.shape[3], Cout), float("nan"), device=dev)
+    ald = al.contiguous().to(dev) if norm else None
+    bed = be.contiguous().to(dev) if norm else None
+    wd, bd = w.to(dev), (b.to(dev) if bias else None)
+    rc = lib.tsnet_op_conv2d_h2r(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), _p(bd), Cout, ksize, _p(ald), _p(bed), 1 if norm else 0, bound, 3,
+                                 y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    return ((nchw(y.cpu()).double() - ref).abs().max() / ref.abs().max()).item()
+
 def instnorm_case(lib, dev, N, H, W, C, relu, resid, seed=0, offset=0.0):
     """InstanceNorm2d(eps=1e-5, biased var) [+ReLU] [+residual] vs stats + norm_act kernels."""
     x = _rand(seed, "x", (N, C, H, W), -2, 2) + offset

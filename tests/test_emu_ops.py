@@ -49,6 +49,14 @@ def test_conv_h2_wide_tile_and_scales(emu_lib):
     assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=1e-4) < 2e-6
 
 
+def test_conv_h2r(emu_lib):
+    """conv_h2r: 3x3 / stride-2 (with and without the fused IN + ReLU) and the 7x7 stems (8 channels: two taps per k-group; 32 channels)"""
+    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 32, 16, 16, 64, 3, norm=True) < 2e-6
+    assert oc.conv_h2r_case(emu_lib, "cpu", 2, 16, 32, 32, 128, 3, norm=False, bias=False) < 2e-6
+    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 16, 8, 64, 7) < 2e-6
+    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 16, 8, 32, 64, 7) < 2e-6
+
+
 @pytest.mark.parametrize("C,H,W", [(8, 6, 5), (64, 16, 16), (24, 9, 3), (1024, 2, 2)])
 @pytest.mark.parametrize("relu,resid", [(True, False), (False, True)])
 def test_instnorm(emu_lib, C, H, W, relu, resid):

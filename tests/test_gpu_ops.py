@@ -144,3 +144,11 @@ def test_conv_h2_tile_widths_bitwise(lib):
     for bn in (64, 128):
         ys.append(oc.conv_h2_case(lib, DEV, 4, 32, 32, 256, 256, True, norm=True, tile_n=bn, return_output=True))
     assert torch.equal(ys[0], ys[1])
+
+
+def test_conv_h2r_layers(lib):
+    """the encoder's downsampling convolutions and stems at their real shapes"""
+    assert oc.conv_h2r_case(lib, DEV, 2, 256, 256, 64, 128, 3, norm=True) < 1e-6
+    assert oc.conv_h2r_case(lib, DEV, 4, 64, 64, 256, 512, 3, norm=True) < 1e-6
+    assert oc.conv_h2r_case(lib, DEV, 2, 256, 256, 8, 64, 7) < 1e-6
+    assert oc.conv_h2r_case(lib, DEV, 1, 256, 256, 32, 64, 7, bias=False) < 1e-6

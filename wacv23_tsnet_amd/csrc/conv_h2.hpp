@@ -45,7 +45,23 @@ struct H2Args {
     int N, H, W, Cin, Ho, Wo, Cout, Npad, reflect, nchunks, M;
     int tiles_m, tiles_n;
     float* fin_alpha; float* fin_beta; int* fin_counter; int fin_S; float fin_eps;
+    unsigned* amax_out;        // see X3Args
+    // operand scale from the data instead of an a-priori bound: in_amax = bit pattern of max |x| published by x's producer
+    // (X3Args::amax_out), bound = that + in_bound_add (what later stages may add, e.g. InstanceNorm outputs of a residual stream);
+    // null = the host's in_scale / in_unscale
+    const unsigned* in_amax; float in_bound_add;
 };
+
+// power-of-two operand scale for |x| <= bound: |x * 2^sa| <= 2^15 (the host's h2_scale_log2, engine.cpp)
+__device__ __forceinline__ void h2_device_scale(const unsigned* amax, float add, float& scale, float& unscale) {
+    const float bound = __builtin_bit_cast(float, __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + add;
+    int e = 0;
+    (void)frexpf(bound, &e);
+    int sa = 15 - e;
+    sa = sa > 24 ? 24 : (sa < -24 ? -24 : sa);
+    scale = ldexpf(1.0f, sa);
+    unscale = ldexpf(1.0f, -sa);
+}
 
 #ifndef TSNET_MFMA_F16
 typedef _Float16 tsnet_f16x8 __attribute__((ext_vector_type(8)));
@@ -116,6 +132,8 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
     const int img = tile_m / tper, tin = tile_m - img * tper;
     const int oy0 = (tin / tcols) * kPatchRows, ox0 = (tin % tcols) * kPatchCols;
     const int ncc = a.Cin >> 4;
+    float in_scale = a.in_scale, in_unscale = a.in_unscale;
+    if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax, a.in_bound_add, in_scale, in_unscale);
 
     const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
     const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
@@ -155,8 +173,8 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
     float* tab = reinterpret_cast<float*>(smem_raw + OFF_TAB);       // [Cin] alpha*s, then [Cin] beta*s
     if (AFFINE) {
         for (int c = tid; c < a.Cin; c += 256) {
-            tab[c] = a.in_alpha[(size_t)img * a.Cin + c] * a.in_scale;
-            tab[a.Cin + c] = a.in_beta[(size_t)img * a.Cin + c] * a.in_scale;
+            tab[c] = a.in_alpha[(size_t)img * a.Cin + c] * in_scale;
+            tab[a.Cin + c] = a.in_beta[(size_t)img * a.Cin + c] * in_scale;
         }
         __syncthreads();
     }
@@ -186,7 +204,7 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = sx[q].v[e] * a.in_scale;                  // a padded slot loaded zeros
+                    float v = sx[q].v[e] * in_scale;                    // a padded slot loaded zeros
                     t[q].v[e] = v > relu_floor ? v : relu_floor;
                 }
         }
@@ -292,7 +310,7 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
     for (; cc + 2 <= ncc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
     if (cc < ncc) slab(cc, 0);
 
-    const float unscale = a.w_unscale ? a.in_unscale * a.w_unscale[0] : a.in_unscale;
+    const float unscale = a.w_unscale ? in_unscale * a.w_unscale[0] : in_unscale;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -352,7 +370,9 @@ struct H2rArgs : H2Args {
     int stride, pad, taps, cin_log2;
 };
 
-template <int KS, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE>
+// SMALL_CIN: Cin = 8 (the 7 x 7 stems at label_nc = 2: 3 + 2 + 3 coordinate channels = 8, or 2 + 3 padded to 8): the two octets of a
+// 16-deep k-group are two different taps of the same pixel row, as in conv_x3r.hpp
+template <int KS, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, bool SMALL_CIN = false>
 __global__ __launch_bounds__(256, 2)
 void conv_h2r_kernel(H2rArgs a) {
     constexpr int BM = 128;
@@ -377,6 +397,8 @@ void conv_h2r_kernel(H2rArgs a) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int hw = a.Ho * a.Wo;
     const int img = m0 / hw;                                         // a tile lies inside one image (hw % 128 == 0, checked on the host)
+    float in_scale = a.in_scale, in_unscale = a.in_unscale;
+    if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax, a.in_bound_add, in_scale, in_unscale);
 
     const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
     const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
@@ -387,8 +409,8 @@ void conv_h2r_kernel(H2rArgs a) {
     float* tab = reinterpret_cast<float*>(smem_raw + OFF_TAB);
     if (AFFINE) {
         for (int c = tid; c < a.Cin; c += 256) {
-            tab[c] = a.in_alpha[(size_t)img * a.Cin + c] * a.in_scale;
-            tab[a.Cin + c] = a.in_beta[(size_t)img * a.Cin + c] * a.in_scale;
+            tab[c] = a.in_alpha[(size_t)img * a.Cin + c] * in_scale;
+            tab[a.Cin + c] = a.in_beta[(size_t)img * a.Cin + c] * in_scale;
         }
         __syncthreads();
     }
@@ -405,13 +427,14 @@ void conv_h2r_kernel(H2rArgs a) {
         s_oy = oy * a.stride - a.pad;
         s_ox = (rem - oy * a.Wo) * a.stride - a.pad;
     }
-    const int cpt_log2 = a.cin_log2 - 4;
+    const int cpt_log2 = SMALL_CIN ? 0 : a.cin_log2 - 4;
     F4 ar[2][2];                                                     // register stage: [set][half of the octet]
     float am[2];                                                     // 1, or 0 where the tap lies in the zero padding / past the last tap
     int ac0[2];                                                      // first channel of the staged octet (for the transform table)
     auto load_a = [&](int kc, int set) __attribute__((always_inline)) {
-        const int tap = kc >> cpt_log2;                              // wave-uniform
-        const int c0 = ((kc << 4) & (a.Cin - 1)) + oct_log * 8;
+        int tap, c0;
+        if (SMALL_CIN) { tap = kc * 2 + oct_log; c0 = 0; }
+        else { tap = kc >> cpt_log2; c0 = ((kc << 4) & (a.Cin - 1)) + oct_log * 8; }      // tap: wave-uniform
         const int ky = tap / KS, kx = tap - ky * KS;
         int iy = s_oy + ky, ix = s_ox + kx;
         bool ok = tap < a.taps;
@@ -448,7 +471,7 @@ void conv_h2r_kernel(H2rArgs a) {
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = ar[set][q].v[e] * a.in_scale;
+                    const float v = ar[set][q].v[e] * in_scale;
                     t[q].v[e] = v > relu_floor ? v : relu_floor;
                 }
         }
@@ -542,7 +565,7 @@ void conv_h2r_kernel(H2rArgs a) {
             for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];
     }
 
-    const float unscale = a.w_unscale ? a.in_unscale * a.w_unscale[0] : a.in_unscale;
+    const float unscale = a.w_unscale ? in_unscale * a.w_unscale[0] : in_unscale;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll

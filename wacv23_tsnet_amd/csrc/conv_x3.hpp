@@ -37,6 +37,9 @@ struct X3Args {
     // optional: the last workgroup to deliver the statistics of an (image, channel tile) finalises them itself
     // (alpha = rstd, beta = -mean*rstd), replacing the in_finalize2 launch; null = off
     float* fin_alpha; float* fin_beta; int* fin_counter; int fin_S; float fin_eps;
+    // optional: max |y| of the launch, as the bit pattern of a non-negative float (order-independent atomic max: deterministic).  The
+    // fp16 x 2 kernels (conv_h2.hpp) derive the operand scale of a tensor without an a-priori bound from it; null = off
+    unsigned* amax_out;
 };
 
 #ifndef TSNET_DRAIN_VMEM
@@ -60,6 +63,7 @@ __device__ __forceinline__ void x3_epilogue(const Args& a, f32x16 (&tot)[MT][NTL
     double csum[NTL], csq[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) { csum[j] = 0.0; csq[j] = 0.0; }
+    float vmax = 0.f;
     const size_t yplane = (size_t)a.M * a.Cout;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -79,6 +83,7 @@ __device__ __forceinline__ void x3_epilogue(const Args& a, f32x16 (&tot)[MT][NTL
                 }
                 if (a.stat_part && mok) { csum[j] += (double)v; csq[j] += (double)v * (double)v; }
                 if (!nok || !mok) continue;
+                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
                 if (a.y) a.y[(size_t)m * a.Cout + n] = v;
                 if (a.y3) {
                     unsigned short sh, sm, sl;
@@ -89,6 +94,7 @@ __device__ __forceinline__ void x3_epilogue(const Args& a, f32x16 (&tot)[MT][NTL
             }
         }
     }
+    if (a.amax_out) tsnet_publish_amax(a.amax_out, vmax);
     if (a.stat_part) {
         __syncthreads();
         double* red = reinterpret_cast<double*>(smem_raw);

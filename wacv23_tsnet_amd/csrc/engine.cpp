@@ -443,6 +443,7 @@ struct X3Call {
     int variant = -1;
     int tclass = TSNET_T_CONV;
     int np = 3;            // 1 = bf16-operand mode: only the hi plane is read (one MFMA product per k-group)
+    unsigned* amax_out = nullptr;   // publish max |y| (operand scale of a consumer without an a-priori bound)
 };
 
 void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
@@ -450,6 +451,7 @@ void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
     g.x = c.x3; g.x2 = c.x23; g.w = L.w3; g.bias = L.bias; g.y = c.y; g.y3 = c.y3;
     g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
     g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_counter = c.stat_part ? c.fin_counter : nullptr; g.fin_eps = 1e-5f;
+    g.amax_out = c.amax_out;
     g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
     g.Csplit = c.x23 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
     g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
@@ -534,6 +536,7 @@ struct H2Call {
     const float* x = nullptr;
     const float* alpha = nullptr; const float* beta = nullptr; int relu = 0;   // x*alpha+beta (+ReLU) on load, or the raw tensor
     float bound = 0.f;          // max |operand| after the transform (InstanceNorm output: sqrt(HW); residual stream: (blocks+1) sqrt(HW))
+    const unsigned* in_amax = nullptr; float bound_add = 0.f;   // or: bound = max |x| published on the device by x's producer + bound_add
     int N = 0, H = 0, W = 0;
     float* y = nullptr;
     const float* addend = nullptr; int add_nmod = 1;
@@ -570,8 +573,9 @@ void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
     if (!h2_layer_ok(L) || !(bf16 ? (const void*)L.w3 : (const void*)L.wh)) throw ArgError("conv(h2): layer is not a 3x3 / stride-1 / pad-1 layer with packed 16-bit weights");
     H2Args g{};
     g.x = c.x; g.in_alpha = c.alpha; g.in_beta = c.alpha ? c.beta : nullptr; g.in_relu = c.relu;
-    const int sa = bf16 ? 0 : h2_scale_log2(c.bound);
+    const int sa = (bf16 || c.in_amax) ? 0 : h2_scale_log2(c.bound);
     g.in_scale = std::ldexp(1.0f, sa); g.in_unscale = std::ldexp(1.0f, -sa);
+    g.in_amax = bf16 ? nullptr : c.in_amax; g.in_bound_add = c.bound_add; g.amax_out = nullptr;
     g.w = bf16 ? L.w3 : L.wh; g.w_unscale = bf16 ? nullptr : L.wh_unscale; g.bias = L.bias; g.y = c.y; g.y3 = nullptr;
     g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
     g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.Ho = c.H; g.Wo = c.W; g.Cout = L.cout; g.Npad = L.npad;
@@ -627,29 +631,39 @@ void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
 
 // ---- h2r: the stride-2 downsampling convolutions on the same arithmetic (conv_h2.hpp, implicit GEMM)
 inline bool h2r_layer_ok(const ConvLayer& L) {
-    return L.ks == 3 && L.stride == 2 && L.pad == 1 && !L.reflect && L.cin_pad >= 16 && (L.cin_pad & (L.cin_pad - 1)) == 0 && L.npad % 64 == 0;
+    const bool down = L.ks == 3 && L.stride == 2 && L.pad == 1 && !L.reflect && L.cin_pad >= 16;       // encoder downsampling (TSNet.py:70)
+    const bool stem = L.ks == 7 && L.stride == 1 && L.pad == 3 && L.reflect && L.cin_pad >= 8;         // encoder stem (TSNet.py:66)
+    return (down || stem) && (L.cin_pad & (L.cin_pad - 1)) == 0 && L.npad % 64 == 0;
 }
 
-template <int BN, int NPROD>
+template <int KS, int BN, int NPROD>
 void launch_h2r(const H2rArgs& a, hipStream_t s) {
     const size_t lds = 2 * 2 * 128 * 32 + (size_t)2 * a.Cin * 4;
-    if (a.in_alpha) hipLaunchKernelGGL((conv_h2r_kernel<3, BN, 2, 2, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_h2r_kernel<3, BN, 2, 2, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    if (a.Cin < 16) {
+        if (a.in_alpha) throw ArgError("conv(h2r): 8-channel layers take no input transform");
+        hipLaunchKernelGGL((conv_h2r_kernel<KS, BN, 2, 2, NPROD, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    } else if (a.in_alpha) {
+        hipLaunchKernelGGL((conv_h2r_kernel<KS, BN, 2, 2, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((conv_h2r_kernel<KS, BN, 2, 2, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    }
 }
 
 void run_conv_h2r(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
     const bool bf16 = c.nprod == 1;
-    if (!h2r_layer_ok(L) || !(bf16 ? (const void*)L.w3 : (const void*)L.wh)) throw ArgError("conv(h2r): layer is not a 3x3 / stride-2 / zero-pad layer with packed 16-bit weights");
+    if (!h2r_layer_ok(L) || !(bf16 ? (const void*)L.w3 : (const void*)L.wh)) throw ArgError("conv(h2r): layer is not a downsampling / stem layer with packed 16-bit weights");
     H2rArgs g{};
     g.x = c.x; g.in_alpha = c.alpha; g.in_beta = c.alpha ? c.beta : nullptr; g.in_relu = c.relu;
-    const int sa = bf16 ? 0 : h2_scale_log2(c.bound);
+    const int sa = (bf16 || c.in_amax) ? 0 : h2_scale_log2(c.bound);
     g.in_scale = std::ldexp(1.0f, sa); g.in_unscale = std::ldexp(1.0f, -sa);
+    g.in_amax = bf16 ? nullptr : c.in_amax; g.in_bound_add = c.bound_add; g.amax_out = nullptr;
     g.w = bf16 ? L.w3 : L.wh; g.w_unscale = bf16 ? nullptr : L.wh_unscale; g.bias = L.bias; g.y = c.y; g.y3 = nullptr;
     g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
     g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
-    g.stride = 2; g.pad = 1; g.taps = 9; g.reflect = 0;
-    g.Ho = (c.H + 2 - 3) / 2 + 1; g.Wo = (c.W + 2 - 3) / 2 + 1;
-    g.Cout = L.cout; g.Npad = L.npad; g.nchunks = (9 * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
+    g.stride = L.stride; g.pad = L.pad; g.taps = L.ks * L.ks; g.reflect = L.reflect;
+    g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1; g.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
+    g.Cout = L.cout; g.Npad = L.npad; g.nchunks = (g.taps * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
+    if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
     const int hw = g.Ho * g.Wo;
     if (hw % 128) throw ArgError("conv(h2r): an output image must be a whole number of 128-row tiles");
     if (c.alpha && !c.beta) throw ArgError("conv(h2r): alpha without beta");
@@ -660,16 +674,19 @@ void run_conv_h2r(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
         const long tm = g.M / 128;
         const double c64 = (double)((tm * ((g.Cout + 63) / 64) + 255) / 256) * 64.0;
         const double c128 = (double)((tm * ((g.Cout + 127) / 128) + 255) / 256) * 128.0 / 1.15;
-        bn = (g.Npad % 128 == 0 && g.Cout > 64 && c128 < c64) ? 128 : 64;
+        bn = (L.ks == 3 && g.Npad % 128 == 0 && g.Cout > 64 && c128 < c64) ? 128 : 64;
     }
     if ((bn != 64 && bn != 128) || g.Npad % bn) throw ArgError("conv(h2r): tile width must be 64 or 128 and divide the padded width");
     g.tiles_m = g.M / 128; g.tiles_n = (g.Cout + bn - 1) / bn;
     g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f; g.fin_S = hw / 128;
     g.fin_counter = (c.stat_part && c.fin_counter && hw / 128 <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= kFinCounterInts) ? c.fin_counter : nullptr;
     TimeScope ts(ctx, c.tclass);
-    if (c.nprod == 3) { if (bn == 64) launch_h2r<64, 3>(g, ctx.stream); else launch_h2r<128, 3>(g, ctx.stream); }
-    else if (c.nprod == 1) { if (bn == 64) launch_h2r<64, 1>(g, ctx.stream); else launch_h2r<128, 1>(g, ctx.stream); }
-    else throw ArgError("conv(h2r): 1 (bf16 operands) or 3 products");
+    if (c.nprod != 1 && c.nprod != 3) throw ArgError("conv(h2r): 1 (bf16 operands) or 3 products");
+    if (L.ks == 7) {
+        if (bn != 64) throw ArgError("conv(h2r): the 7x7 stems run on 64-wide tiles");
+        if (c.nprod == 3) launch_h2r<7, 64, 3>(g, ctx.stream); else launch_h2r<7, 64, 1>(g, ctx.stream);
+    } else if (c.nprod == 3) { if (bn == 64) launch_h2r<3, 64, 3>(g, ctx.stream); else launch_h2r<3, 128, 3>(g, ctx.stream); }
+    else { if (bn == 64) launch_h2r<3, 64, 1>(g, ctx.stream); else launch_h2r<3, 128, 1>(g, ctx.stream); }
     check_launch("conv_h2r");
     c.stat_S = !c.stat_part ? 0 : (g.fin_counter ? -1 : hw / 128);
     ++g_launch_counters[0];
@@ -927,6 +944,8 @@ struct tsnet_engine {
     bool x3 = true;
     int np = 3;                           // 1 = bf16-operand mode (cfg.operand_mode): one plane / one product everywhere
     bool h2 = true;                       // fp16x2 patch convolution (conv_h2.hpp) for the 3x3 / stride-1 layers whose input is bounded; TSNET_H2=0: round-1 schedule
+    unsigned* amax = nullptr;             // device: max |x| of tensors without an a-priori bound, as float bits ([0] packed source input,
+                                          // [1] packed label input, [2] decoder stream = dec_map output); reset before each producer
     float* U_f32[8] = {nullptr};          // fp32 upsampled decoder inputs (h2 schedule; the bf16x3 schedule writes planes only)
     unsigned short* wpack3 = nullptr; size_t wpack3_elems = 0;
     unsigned short* arena3 = nullptr;
@@ -992,7 +1011,12 @@ struct tsnet_engine {
     void alloc_all(hipStream_t s);
     void encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin, int N, int cp, std::vector<float*>& raw, float* out_fea, int nblocks);
     void encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned short* xin3, int N, std::vector<float*>& raw,
-                   std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks);
+                   std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks,
+                   const float* xin_f32 = nullptr, const unsigned* xin_amax = nullptr);
+    // the 7x7 stem runs on conv_h2r (fp32 packed input, operand scale from its published maximum) when the h2 schedule is on
+    bool stem_h2r(const std::vector<ConvLayer>& L) const {
+        return h2 && h2r_layer_ok(L[0]) && (cfg.height * cfg.width) % 128 == 0 && (np == 1 ? L[0].w3 != nullptr : L[0].wh != nullptr);
+    }
     void resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float* y1, float* y2, int N, int hh, int ww);
     void forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
     // every convolution of the forward goes through these two: they apply the engine's operand mode
@@ -1016,16 +1040,18 @@ struct tsnet_engine {
         double* pt = ctx.lane ? part_side : part;
         c.stat_part = pt;
         c.fin_alpha = alpha; c.fin_beta = beta; c.fin_counter = ctx.lane ? fin_counter_side : fin_counter;
-        if (L.stride == 2) { c.nprod = np == 1 ? 1 : 3; run_conv_h2r(ctx, L, c); }
+        if (L.stride == 2 || L.ks == 7) { c.nprod = np == 1 ? 1 : 3; run_conv_h2r(ctx, L, c); }
         else rh2(ctx, L, c);
         if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
         TimeScope ts(ctx, TSNET_T_STATS);
         hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + 63) / 64, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
         check_launch("in_finalize2");
     }
-    // ResnetBlock on the h2 schedule.  stream_bound > 0: the residual stream Xs is bounded (encoder: (blocks+1) sqrt(HW)) and the first
-    // convolution reads it as fp32; otherwise (decoder: the stream starts at a raw convolution output) it reads the bf16x3 planes Xs3.
-    void resblock_h2(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float stream_bound, float* y1, float* y2, int N, int hh, int ww);
+    // ResnetBlock on the h2 schedule.  stream_bound > 0: the residual stream Xs has an a-priori bound (encoder: (blocks+1) sqrt(HW));
+    // stream_amax: its bound is measured -- max |first value| published by the producer + amax_add (decoder: the stream starts at a raw
+    // convolution output); neither: the first convolution reads the bf16x3 planes Xs3.
+    void resblock_h2(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float stream_bound, float* y1, float* y2, int N, int hh, int ww,
+                     const unsigned* stream_amax = nullptr, float amax_add = 0.f);
     void resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww);
     void set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B);
     void forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
@@ -1240,7 +1266,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
         want(&U[i], B * sp * (C >> i));
         want(&R[i], B * sp * (C >> (i + 1)));
     }
-    if (x3 && h2) for (int i = 1; i < cfg.n_downsampling && i < 8; ++i) want(&U_f32[i], B * (size_t)(h << (i + 1)) * (w << (i + 1)) * (C >> i));
+    if (x3 && h2) for (int i = 0; i < cfg.n_downsampling && i < 8; ++i) want(&U_f32[i], B * (size_t)(h << (i + 1)) * (w << (i + 1)) * (C >> i));
     for (int i = 0; i < 4; ++i) { want(&ab[i][0], NB * 2 * C); want(&ab[i][1], NB * 2 * C); }
     want(&bbox_copy, NB * H * W);
     float* part_f = nullptr;
@@ -1255,6 +1281,8 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     part = reinterpret_cast<double*>(part_f);
     // arrival counters: one per (image, 32-channel group) of a launch; launches with more (image, group) pairs than kFinCounterInts
     // fall back to the in_finalize2 kernel (launch_x3_ks / run_conv_h2 check the index range against this size)
+    HIP_TRY(hipMalloc((void**)&amax, 8 * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(amax, 0, 8 * sizeof(unsigned), s));
     HIP_TRY(hipMalloc((void**)&fin_counter, kFinCounterInts * sizeof(int)));
     HIP_TRY(hipMemsetAsync(fin_counter, 0, kFinCounterInts * sizeof(int), s));
     if (x3) {      // side lane (tsnet_forward): own statistics scratch, counters, (alpha, beta) pairs, stream and events
@@ -1299,11 +1327,13 @@ void tsnet_engine::alloc_all(hipStream_t s) {
 
 // ---- h2 schedule: the 3x3 / stride-1 convolutions read fp32 and apply the producer's InstanceNorm + ReLU while staging (conv_h2.hpp)
 void tsnet_engine::resblock_h2(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float stream_bound,
-                               float* y1, float* y2, int N, int hh, int ww) {
+                               float* y1, float* y2, int N, int hh, int ww, const unsigned* stream_amax, float amax_add) {
     const int Cc = c1.cout, HW = hh * ww;
     auto s1 = next_ab();
-    if (stream_bound > 0.f) {
-        H2Call a; a.x = Xs; a.bound = stream_bound; a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
+    const bool fp32_stream = stream_bound > 0.f || stream_amax != nullptr;
+    if (fp32_stream) {
+        H2Call a; a.x = Xs; a.bound = stream_bound; a.in_amax = stream_bound > 0.f ? nullptr : stream_amax; a.bound_add = amax_add;
+        a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
         conv_stats_h2(ctx, c1, a, N, HW, s1.first, s1.second);
     } else {
         X3Call a; a.x3 = Xs3; a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
@@ -1313,7 +1343,7 @@ void tsnet_engine::resblock_h2(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c
     b.N = N; b.H = hh; b.W = ww; b.y = y2; b.tclass = TSNET_T_CONV_RES;
     auto s2 = next_ab();
     conv_stats_h2(ctx, c2, b, N, HW, s2.first, s2.second);
-    run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs, stream_bound > 0.f ? nullptr : Xs3);   // X += IN(y2)
+    run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs, fp32_stream ? nullptr : Xs3);   // X += IN(y2)
 }
 
 // ---- bf16x3 schedule: same graph as the fp32 one; every conv reads planes, producers write planes
@@ -1330,11 +1360,17 @@ void tsnet_engine::resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c
 }
 
 void tsnet_engine::encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned short* xin3, int N, std::vector<float*>& raw,
-                             std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks) {
+                             std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks,
+                             const float* xin_f32, const unsigned* xin_amax) {
     int hh = cfg.height, ww = cfg.width;
-    X3Call a; a.x3 = xin3; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
     auto st = next_ab(ctx);
-    conv_stats_x3(ctx, L[0], a, N, hh * ww, st.first, st.second);
+    if (xin_f32 && stem_h2r(L)) {
+        H2Call a; a.x = xin_f32; a.in_amax = xin_amax; a.bound = 1.f; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
+        conv_stats_h2(ctx, L[0], a, N, hh * ww, st.first, st.second);
+    } else {
+        X3Call a; a.x3 = xin3; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
+        conv_stats_x3(ctx, L[0], a, N, hh * ww, st.first, st.second);
+    }
     for (int l = 1; l <= cfg.n_downsampling; ++l) {
         // the downsampling convolution reads relu(IN(previous)): on the h2 schedule the transform is applied while the im2col tile is
         // staged (conv_h2r), otherwise one elementwise pass materialises it as bf16x3 planes for conv_x3r
@@ -1378,11 +1414,13 @@ void tsnet_engine::target_chain_x3(Ctx& ctx, const float* tar_lbl, int B) {
         PackArgs p{};
         p.img[0] = nullptr; p.lbl[0] = tar_lbl;
         p.coords = cfg.addcoords ? d_coords : nullptr;
-        p.out = nullptr; p.out3 = x_lbl3; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
+        const bool f32 = stem_h2r(lbl_enc);
+        p.out = f32 ? x_lbl : nullptr; p.out3 = f32 ? nullptr : x_lbl3; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
+        if (f32) { HIP_TRY(hipMemsetAsync(amax + 1, 0, sizeof(unsigned), ctx.stream)); p.amax_out = amax + 1; }
         hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ctx.stream, p);
         check_launch("pack_input(lbl)");
     }
-    encode_x3(ctx, lbl_enc, x_lbl3, B, raw_lbl, raw3_lbl, tar_fea, tar3, 0);
+    encode_x3(ctx, lbl_enc, x_lbl3, B, raw_lbl, raw3_lbl, tar_fea, tar3, 0, x_lbl, amax + 1);
     run_l2norm(ctx, tar_fea, that, B * P, C);
     if (h2_feat()) {                                                                   // shared target half of fuse conv1
         H2Call t; t.x = tar_fea; t.bound = std::sqrt((float)P); t.N = B; t.H = h; t.W = w; t.y = FT;
@@ -1445,14 +1483,19 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
     // ---- decoder
     if (fork) HIP_TRY(hipStreamWaitEvent(ctx.stream, ev_join2, 0));
     join2.done = true;
+    // The decoder's stream starts at dec_map's raw output: no a-priori bound.  On the h2 schedule dec_map publishes max |D| (one atomic
+    // max per wave, order-independent) and the convolutions reading the stream derive their fp16 operand scale from it on the device:
+    // D_i = D_0 + (i InstanceNorm outputs), |D_i| <= max |D_0| + i sqrt(P).  (bf16-operand mode: no scales, nothing to publish.)
+    const bool dyn = h2_feat() && np != 1;
+    const float sqP = std::sqrt((float)P);
     {
         X3Call a; a.x3 = pg3; a.x23 = sg3; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
-        a.y3 = cfg.n_blocks > 0 ? D3 : nullptr;
+        a.y3 = (cfg.n_blocks > 0 && !h2_feat()) ? D3 : nullptr;
+        if (dyn) { HIP_TRY(hipMemsetAsync(amax + 2, 0, sizeof(unsigned), ctx.stream)); a.amax_out = amax + 2; }
         rx3(ctx, dec_map, a);
     }
     for (int i = 0; i < cfg.n_blocks; ++i) {
-        // the decoder's stream starts at dec_map's raw output (no bound): its first convolutions stay on the bf16x3 planes
-        if (h2_feat()) resblock_h2(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, 0.f, DY1, DY2, B, h, w);
+        if (h2_feat()) resblock_h2(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, np == 1 ? 1.f : 0.f, DY1, DY2, B, h, w, dyn ? amax + 2 : nullptr, (float)i * sqP);
         else resblock_x3(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, DY1, DY2, B, h, w);
     }
     const float* cur = D; const float* cal = nullptr; const float* cbe = nullptr;
@@ -1460,7 +1503,9 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
     for (int i = 0; i < cfg.n_downsampling; ++i) {
         // input of up-convolution i = bilinear x2 of relu(IN(previous)) -- a convex combination of InstanceNorm outputs, bounded by
         // sqrt(HW) of the low-resolution map; the first one upsamples the unnormalised decoder stream and keeps the bf16x3 path
-        const bool via_h2 = h2 && cal && i < 8 && U_f32[i] && (2 * hh) % kPatchRows == 0 && (2 * ww) % kPatchCols == 0 && h2_layer_ok(dec_up[i]);
+        // (the first one upsamples the decoder stream itself: bound = the published max |D_0| + n_blocks sqrt(P), or none needed in bf16 mode)
+        const bool via_h2 = h2 && (cal || dyn || np == 1) && i < 8 && U_f32[i] && (2 * hh) % kPatchRows == 0 && (2 * ww) % kPatchCols == 0 && h2_layer_ok(dec_up[i]) &&
+                            (np == 1 ? dec_up[i].w3 != nullptr : dec_up[i].wh != nullptr) && h2_feat();
         const float in_bound = std::sqrt((float)(hh * ww));
         run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, via_h2 ? U_f32[i] : nullptr, via_h2 ? nullptr : U3[i]);
         hh *= 2; ww *= 2;
@@ -1468,6 +1513,7 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
         auto st = next_ab();
         if (via_h2) {
             H2Call a; a.x = U_f32[i]; a.bound = in_bound; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
+            if (!cal && np != 1) { a.in_amax = amax + 2; a.bound_add = (float)cfg.n_blocks * sqP; }
             conv_stats_h2(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
         } else {
             X3Call a; a.x3 = U3[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
@@ -1531,14 +1577,16 @@ void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const floa
         PackArgs p{};
         for (int s = 0; s < K; ++s) { p.img[s] = src_img[s]; p.lbl[s] = src_lbl[s]; p.img_div[s] = src_div[s]; }
         p.coords = cfg.addcoords ? d_coords : nullptr;
-        p.out = x3 ? nullptr : x_img; p.out3 = x3 ? x_img3 : nullptr;
+        const bool f32 = !x3 || stem_h2r(img_enc);
+        p.out = f32 ? x_img : nullptr; p.out3 = f32 ? nullptr : x_img3;
         p.S = K; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 3; p.Cp = cp_img;
+        if (x3 && f32) { HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), ctx.stream)); p.amax_out = amax; }
         hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)K * B * H * W)), dim3(256), 0, ctx.stream, p);
         check_launch("pack_input(img)");
         for (int s = 0; s < K; ++s)
             HIP_TRY(hipMemcpyAsync(bbox_copy + (size_t)s * Bmax * H * W, src_bbox[s], (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
     }
-    if (x3) encode_x3(ctx, img_enc, x_img3, K * B, raw_img, raw3_img, X, X3, cfg.enc_blocks);
+    if (x3) encode_x3(ctx, img_enc, x_img3, K * B, raw_img, raw3_img, X, X3, cfg.enc_blocks, x_img, amax);
     else encode(ctx, img_enc, x_img, K * B, cp_img, raw_img, X, cfg.enc_blocks);
     run_l2norm(ctx, X, shat, K * B * P, C);
     if (x3) {
@@ -1756,7 +1804,7 @@ int tsnet_finalize(tsnet_handle h, void* stream) {
 
 void tsnet_destroy(tsnet_handle h) {
     if (!h) return;
-    (void)hipFree(h->arena3); (void)hipFree(h->fin_counter); (void)hipFree(h->train_ws);
+    (void)hipFree(h->arena3); (void)hipFree(h->fin_counter); (void)hipFree(h->train_ws); (void)hipFree(h->amax);
     (void)hipFree(h->part_side); (void)hipFree(h->fin_counter_side);
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) (void)hipFree(h->ab_side[i][j]);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
@@ -2052,6 +2100,44 @@ int tsnet_op_conv2d_h2(const float* x, int N, int H, int W, int Cin, const float
     H2Call c; c.x = x; c.alpha = in_alpha; c.beta = in_beta; c.relu = in_relu; c.bound = bound; c.N = N; c.H = H; c.W = W; c.y = y;
     c.nprod = nprod; c.bn = tile_n;
     run_conv_h2(ctx, L, c);
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(wd); (void)hipFree(wh); (void)hipFree(un); (void)hipFree(bd);
+    OP_END
+}
+
+int tsnet_op_conv2d_h2r(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int ksize,
+                        const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, float* y, void* stream) {
+    OP_BEGIN
+    if (!x || !w_oihw || !y) throw ArgError("null tensor");
+    if (ksize != 3 && ksize != 7) throw ArgError("conv2d_h2r op: 3 (stride 2, zero pad 1) or 7 (stride 1, reflection pad 3)");
+    hipStream_t s = (hipStream_t)stream;
+    Ctx ctx; ctx.stream = s;
+    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = ksize;
+    L.stride = ksize == 3 ? 2 : 1; L.pad = ksize == 3 ? 1 : 3; L.reflect = ksize == 7;
+    L.kpad = conv_kpad(ksize, Cin); L.npad = std::max(conv_npad(Cout), round_up(Cout, 64));
+    const size_t wn = (size_t)Cout * Cin * ksize * ksize;
+    std::vector<float> hw(wn);
+    HIP_TRY(hipMemcpy(hw.data(), w_oihw, wn * sizeof(float), hipMemcpyDefault));
+    float mx = 0.f;
+    for (float v : hw) mx = std::max(mx, std::fabs(v));
+    const int sw = mx > 0.f ? h2_scale_log2(mx) : 0;
+    float *wd = nullptr, *bd = nullptr, *un = nullptr; unsigned short* wh = nullptr;
+    HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&wh, (size_t)L.kpad * L.npad * 4));
+    HIP_TRY(hipMalloc((void**)&un, sizeof(float)));
+    HIP_TRY(hipMemcpy(wd, hw.data(), wn * sizeof(float), hipMemcpyHostToDevice));
+    const float unscale = std::ldexp(1.0f, -sw);
+    HIP_TRY(hipMemcpy(un, &unscale, sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pack_weights_h2_kernel, dim3(ew_grid((size_t)L.kpad * L.npad)), dim3(256), 0, s, wd, wh, std::ldexp(1.0f, sw),
+                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, Cin, 0);
+    check_launch("pack_weights_h2");
+    if (bias) {
+        HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
+        HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
+    }
+    L.wh = wh; L.wh_unscale = un; L.bias = bd;
+    H2Call c; c.x = x; c.alpha = in_alpha; c.beta = in_beta; c.relu = in_relu; c.bound = bound; c.N = N; c.H = H; c.W = W; c.y = y; c.nprod = nprod;
+    run_conv_h2r(ctx, L, c);
     HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(wd); (void)hipFree(wh); (void)hipFree(un); (void)hipFree(bd);
     OP_END

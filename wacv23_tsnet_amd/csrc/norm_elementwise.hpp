@@ -354,12 +354,14 @@ struct PackArgs {
     int S, B, H, W, L, nimg, Cp;
     unsigned short* out3;  // null, or bf16x3 planes of the packed input
     float img_div[8];      // per source: 255 (set_test_input's /255, TSNet.py:286) or 1 (use_prev: a frame already in [0,1], TSNet.py:269-276)
+    unsigned* amax_out;    // null, or where to publish max |packed value| (float bits; operand scale of the fp16 x 2 stem convolution)
 };
 
 __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
     const size_t HW = (size_t)a.H * a.W;
     const size_t total = (size_t)a.S * a.B * HW;
     const int creal = a.nimg + a.L + (a.coords ? 3 : 0);
+    float vmax = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
         const int n = (int)(i / HW);
@@ -375,12 +377,14 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
                 else if (c < a.nimg + a.L) t = a.lbl[s][((size_t)b * a.L + (c - a.nimg)) * HW + pix];
                 else if (c < creal) t = a.coords[pix * 3 + (c - a.nimg - a.L)];
                 v[e] = t;
+                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(t));
             }
             const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
             if (a.out) *reinterpret_cast<float4*>(o + c0) = v4;
             if (a.out3) split3_store_at(v4, a.out3, total * a.Cp, i * a.Cp + c0);
         }
     }
+    if (a.amax_out) tsnet_publish_amax(a.amax_out, vmax);      // wave-uniform branch: every thread of the workgroup arrives
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -32,6 +32,22 @@ __device__ __forceinline__ void split3_store(float4 v, unsigned short* hi, unsig
     *reinterpret_cast<uint2*>(lo) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
 }
 
+// max |v| of the workgroup's values -> ONE atomic per workgroup (atomics on one address serialise at ~12 ns each; non-negative
+// floats order like their bit patterns).  Every thread of the workgroup must call it (two barriers).
+__device__ __forceinline__ void tsnet_publish_amax(unsigned* slot, float m) {
+    __shared__ float wave_max[16];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
+    __syncthreads();                                     // a previous use of wave_max in this workgroup is over
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (int)((blockDim.x + 63) >> 6);
+        for (int i = 1; i < nw; ++i) m = wave_max[i] > m ? wave_max[i] : m;
+        __hip_atomic_fetch_max(slot, __builtin_bit_cast(unsigned, m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // planes of a tensor with `elems` elements: store 4 consecutive elements starting at element index i
 __device__ __forceinline__ void split3_store_at(float4 v, unsigned short* planes, size_t elems, size_t i) {
     split3_store(v, planes + i, planes + elems + i, planes + 2 * elems + i);
