@@ -181,11 +181,17 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
                         "class_ms_per_forward": class_ms}
 
     # ---- CPU baseline beside it (rank 0, N=1 only): the oracle on the host cores, same workload
-    cpu_base, max_abs_delta = None, None
+    cpu_base, max_abs_delta, delta64 = None, None, None
     if world == 1 and cpu_baseline:
         torch.set_num_threads(_usable_cores())
         ref = O.tsnet_forward(sd, cfg, *inputs_cpu)            # warm-up; also the parity reference
         max_abs_delta = float((out.cpu() - ref["rec_tar_img"]).abs().max())
+        # the same forward in fp64 (one pass, not timed): how much of that delta is the fp32 CPU forward's own rounding
+        i64 = [[t.double() for t in x] if isinstance(x, list) else x.double() for x in inputs_cpu]
+        r64 = O.tsnet_forward({k: v.double() for k, v in sd.items()}, cfg, *i64)["rec_tar_img"]
+        delta64 = {"gpu_vs_oracle_fp64": float((out.cpu().double() - r64).abs().max()),
+                   "oracle_fp32_vs_fp64": float((ref["rec_tar_img"].double() - r64).abs().max())}
+        del i64, r64
         times, budget = [], 25.0
         while len(times) < 3 and sum(times) < budget:
             t1 = time.perf_counter()
@@ -234,7 +240,7 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "TSNet(label_nc=2,n_blocks=0,n_downsampling=3,n_source=3) forward, fp32, B=4 per GPU, 256x256 (BASELINE.json configs[1])",
                    "global_batch": world * batch, "parallelism": f"replicas x{world} (batch-sharded, weights broadcast once)"},
-        "max_abs_delta_vs_oracle": max_abs_delta,
+        "max_abs_delta_vs_oracle": max_abs_delta, "max_abs_delta_fp64": delta64,
         "ms_per_step_hipevent_median": round(step_ms[len(step_ms) // 2], 3) if step_ms else None,
         "ms_per_step_hipevent_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)] if step_ms else None,
         "algorithmic_gflop_per_frame": round(gflop_frame, 3),
