@@ -112,8 +112,11 @@ class TSNet(nn.Module):
                  lambda_FML=10.0, lambda_VGG=10.0, lambda_CON=10.0, lambda_GRAD=10.0,
                  is_train=True, getIntermFeat=True, label_nc=5, debug=False, lambda_dec=1.0,
                  addcoords=True, ngf=64, n_downsampling=4, return_flow=False,
-                 height=256, width=256, max_batch=None):
+                 height=256, width=256, max_batch=None, operands="fp32"):
         super().__init__()
+        if operands not in ("fp32", "bf16"):
+            raise ValueError("operands must be 'fp32' (default, 1e-3 parity with the fp32 reference) or 'bf16' (BASELINE.json configs[2]/[4])")
+        self.operands = operands
         if is_train:
             raise NotImplementedError("training (GAN/VGG losses, optimisers) is outside the MI355X forward path; "
                                       "construct with is_train=False")
@@ -233,7 +236,7 @@ class TSNet(nn.Module):
                               n_source=self.n_source, ngf=self.ngf, addcoords=self.addcoords,
                               pose_composite=self._pose and getattr(self, "use_mask", False),
                               pose_mean=getattr(self, "mean", POSE_MEAN), height=self.height, width=self.width,
-                              max_batch=max(B, self.max_batch or 0))
+                              max_batch=max(B, self.max_batch or 0), operands=self.operands)
             eng.load_state_dict(self.generator_state_dict())
             eng.finalize(dev)
             self._engine, self._engine_key = eng, key
