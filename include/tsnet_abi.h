@@ -114,7 +114,9 @@ int tsnet_forward_target(tsnet_handle h, const float* tar_lbl, const float* tar_
  * from the flows and features the LAST tsnet_forward / tsnet_forward_target left in the engine -- call it right after that
  * forward, same B, same source images.  src_img: n_source x (B,3,H,W) raw (the /255 of set_train_input is applied inside);
  * tar_img (B,3,H,W) raw.  warp_src_img (n_source,B,3,H,W): every source image warped patch-wise by its flow and
- * re-normalised to the target image's statistics (warp_src_img_list); losses: 2 device floats {loss_warp, loss_align}. */
+ * re-normalised to the target image's statistics (warp_src_img_list); losses: 2 device floats {loss_warp, loss_align}.
+ * With cfg.pose_composite (the pose model, model/TSNet_pose.py:343-346, 386-404) the warped images get the fixed-background
+ * composite before the L1 (:399-402) and losses[1] is 0: that model has no alignment loss. */
 int tsnet_train_extras(tsnet_handle h, const float* const* src_img, const float* tar_img, int B,
                        float* warp_src_img, float* losses, void* stream);
 

@@ -133,13 +133,18 @@ def run_train_case(ref_face, ref_pose, name, cfg, B, wseed, iseed):
     with torch.no_grad():
         m.forward()
     warp = [t.detach().clone() for t in m.warp_src_img_list]
-    lw, la = float(m.loss_warp), float(m.loss_align)
+    lw = float(m.loss_warp)
+    la = None if cfg.pose else float(m.loss_align)                 # TSNet_pose.py has no alignment loss
     got = O.tsnet_forward(sd, cfg, src_img, src_lbl, src_bbox, tar_lbl, tar_bbox, tar_img=tar_img)
     tr = got["train"]
     d_warp = max((a - b).abs().max().item() for a, b in zip(tr["warp_src_img_list"], warp))
-    d_lw, d_la = abs(float(tr["loss_warp"]) - lw), abs(float(tr["loss_align"]) - la)
+    d_lw = abs(float(tr["loss_warp"]) - lw)
+    d_la = 0.0 if cfg.pose else abs(float(tr["loss_align"]) - la)
+    assert not cfg.pose or tr["loss_align"] is None
     d_rec = (got["rec_tar_img"] - m.rec_tar_img).abs().max().item()
     print(f"[{name}] oracle vs reference: max|d warp|={d_warp:.3e} d loss_warp={d_lw:.3e} d loss_align={d_la:.3e} max|d rec|={d_rec:.3e}")
+    if cfg.pose:      # the composite really happened in the reference: background columns carry -mean/255
+        assert all(float((t[:, :, :, :64] - t[:, :, :1, :1]).abs().max()) == 0.0 for t in warp)
     assert d_warp <= 1e-6 and d_lw <= 1e-6 and d_la <= 1e-6 and d_rec <= 1e-6, "oracle restatement diverges from the reference"
     meta = dict(name=name, B=B, H=H, W=W, wseed=wseed, iseed=iseed, mask_mode="box", bias_std=0.0, threads=THREADS,
                 torch=torch.__version__, loss_warp=lw, loss_align=la,
@@ -211,10 +216,12 @@ def main():
     from oracle.tsnet_oracle import TSNetConfig
 
     train_case = lambda: run_train_case(ref_face, ref_pose, "g5_train_extras_256_k2", TSNetConfig(label_nc=2, n_blocks=0, n_source=2), 1, 11, 12)
+    train_case_pose = lambda: run_train_case(ref_face, ref_pose, "g5_train_extras_pose_256_k2", TSNetConfig(label_nc=25, n_blocks=0, n_source=2, pose=True), 1, 13, 14)
     if args.only_train:
         mpath = os.path.join(GOLD, "MANIFEST.json")
-        metas = [m for m in json.load(open(mpath)) if m["name"] != "g5_train_extras_256_k2"]
+        metas = [m for m in json.load(open(mpath)) if m["name"] not in ("g5_train_extras_256_k2", "g5_train_extras_pose_256_k2")]
         metas.append(train_case())
+        metas.append(train_case_pose())
         with open(mpath, "w") as f:
             json.dump(metas, f, indent=1)
         return
@@ -235,6 +242,7 @@ def main():
         # G4: cfg0 -- TSNet(label_nc=2, n_blocks=0, n_downsampling=3, n_source=3), B=4, 256x256
         metas.append(run_case(ref_face, ref_pose, "g4_cfg0_full", TSNetConfig(label_nc=2, n_blocks=0, n_source=3), 4, 256, 256, 0, 1, full=True))
     metas.append(train_case())
+    metas.append(train_case_pose())
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(metas, f, indent=1)
 

@@ -206,13 +206,15 @@ def pose_composite(rec: torch.Tensor, cfg: TSNetConfig) -> torch.Tensor:
 # --------------------------------------------------------------------------- forward
 @torch.no_grad()
 def train_extras(src_img: List[torch.Tensor], tar_img: torch.Tensor, flows: List[torch.Tensor],
-                 pg: torch.Tensor, sg: torch.Tensor) -> dict:
+                 pg: torch.Tensor, sg: torch.Tensor, cfg: "TSNetConfig" = None) -> dict:
     """The forward's training-mode extras, TSNet.py:327-331, 372-390, 402-405.
     src_img / tar_img are already divided by 255 (set_train_input, :267,279).  Per source: the image is cut into
     down x down patches (F.unfold), the patch grid is warped with the source's flow (F.grid_sample), folded back,
     re-normalised to the target image's per-channel mean / unbiased std, and compared with the target (10 * L1).
     loss_align = 1 - mean cosine similarity of the propagated and the synthesised features.
-    (The reference folds to a hard-coded 256 (:379); output_size is the image size here, identical at 256.)"""
+    (The reference folds to a hard-coded 256 (:379); output_size is the image size here, identical at 256.)
+    Pose model (cfg.pose, TSNet_pose.py:343-346, 386-404): the same warp + re-normalisation, then the fixed-background composite of
+    the warped image BEFORE the L1 (:399-400), and no loss_align (returned as None)."""
     b, _, h, w = pg.shape
     ref_mean = tar_img.view(b, 3, -1).mean(dim=2).view(b, 3, 1, 1)             # :329
     ref_std = tar_img.view(b, 3, -1).std(dim=2).view(b, 3, 1, 1)               # :330
@@ -228,10 +230,15 @@ def train_extras(src_img: List[torch.Tensor], tar_img: torch.Tensor, flows: List
         gen_std = warp_src_img.view(b, 3, -1).std(dim=2).view(b, 3, 1, 1)
         norm_warp_src_img = (warp_src_img - gen_mean) / gen_std
         warp_src_img = norm_warp_src_img * ref_std + ref_mean                  # :384
+        if cfg is not None and cfg.pose and cfg.use_mask:
+            warp_src_img = pose_composite(warp_src_img, cfg)                   # TSNet_pose.py:399-400
         warp_list.append(warp_src_img)
         loss_list.append(10 * F.l1_loss(warp_src_img, tar_img))                # :386
     loss_warp = sum(loss_list)                                                 # :390
-    loss_align = 1 - (F.cosine_similarity(pg, sg, dim=1)).mean()               # :403-405
+    if cfg is not None and cfg.pose:
+        loss_align = None                                                      # TSNet_pose.py has no alignment loss
+    else:
+        loss_align = 1 - (F.cosine_similarity(pg, sg, dim=1)).mean()           # :403-405
     return {"warp_src_img_list": warp_list, "loss_warp": loss_warp, "loss_align": loss_align}
 
 
@@ -283,7 +290,7 @@ def _forward(sd, cfg, src_img_list, src_lbl_list, src_bbox_list, tar_lbl, tar_bb
         rec = pose_composite(rec, cfg)                              # TSNet_pose.py:416-417
     out = {"rec_tar_img": rec, "flows": flows}
     if tar_img is not None:                                         # set_train_input + is_train branches of forward
-        out["train"] = train_extras(src_img, tar_img / 255.0, flows, pg, sg)
+        out["train"] = train_extras(src_img, tar_img / 255.0, flows, pg, sg, cfg)
     if want_stages:
         stages.update({"src_fea": src_fea, "tar_fea": tar_fea, "pg": pg, "sg": sg, "dec_fea": fea})
         out["stages"] = stages

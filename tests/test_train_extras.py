@@ -13,11 +13,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import helpers as Hh
 from oracle import tsnet_oracle as O
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g5_train_extras_256_k2.npz")
+GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["g5_train_extras_256_k2", "g5_train_extras_pose_256_k2"]     # face model; pose model (TSNet_pose.py:343-346, 386-404)
 
 
-def _golden_case():
-    z = np.load(GOLD)
+def _golden_case(name="g5_train_extras_256_k2"):
+    z = np.load(os.path.join(GOLD_DIR, name + ".npz"))
     meta = json.loads(str(z["meta"]))
     cfg = Hh.cfg_from_meta(meta)
     sd = O.synth_state_dict(cfg, seed=meta["wseed"])
@@ -26,15 +27,22 @@ def _golden_case():
     return z, meta, cfg, sd, inp, tar_img
 
 
-def test_oracle_train_extras_match_reference_golden():
-    z, meta, cfg, sd, inp, tar_img = _golden_case()
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_train_extras_match_reference_golden(name):
+    z, meta, cfg, sd, inp, tar_img = _golden_case(name)
     torch.set_num_threads(min(16, torch.get_num_threads()))
     tr = O.tsnet_forward(sd, cfg, *inp, tar_img=tar_img)["train"]
     for i, wimg in enumerate(tr["warp_src_img_list"]):
         assert np.abs(wimg[:, :, 96:160, 96:160].numpy() - z[f"warp{i}_crop"]).max() <= 1e-6
         assert np.abs(wimg.double().sum(dim=3).numpy() - z[f"warp{i}_rowsum64"]).max() <= 1e-4
     assert abs(float(tr["loss_warp"]) - meta["loss_warp"]) <= 1e-6
-    assert abs(float(tr["loss_align"]) - meta["loss_align"]) <= 1e-6
+    if cfg.pose:
+        assert tr["loss_align"] is None and meta["loss_align"] is None
+        bg = -np.asarray(cfg.mean, dtype=np.float32) / np.float32(255.0)       # the composite: background columns are -mean/255
+        for wimg in tr["warp_src_img_list"]:
+            assert np.array_equal(wimg[0, :, 5, 3].numpy(), bg) and np.array_equal(wimg[0, :, 200, 250].numpy(), bg)
+    else:
+        assert abs(float(tr["loss_align"]) - meta["loss_align"]) <= 1e-6
 
 
 def _engine_vs_oracle(lib, dev, cfg, sd, inp, tar_img, H, W, B, tol_img, make_kw=None):
@@ -46,7 +54,8 @@ def _engine_vs_oracle(lib, dev, cfg, sd, inp, tar_img, H, W, B, tol_img, make_kw
         torch.cuda.synchronize()
     d_img = max((a.cpu() - b).abs().max().item() for a, b in zip(warp, ref["warp_src_img_list"]))
     d_lw = abs(lw.item() - float(ref["loss_warp"]))
-    d_la = abs(la.item() - float(ref["loss_align"]))
+    assert (la is None) == (ref["loss_align"] is None)
+    d_la = 0.0 if la is None else abs(la.item() - float(ref["loss_align"]))
     print(f"[train-extras] d_warp_img={d_img:.2e} d_loss_warp={d_lw:.2e} d_loss_align={d_la:.2e}")
     # the warped image follows the flow (error <= 1e-4 of the [-1,1] grid, i.e. <= 1.6e-3 patch positions); measured:
     # 1.0e-6 on the image at the 256x256 golden case on MI355X, losses equal to 1e-7
@@ -63,10 +72,42 @@ def test_train_extras_emulated(emu_lib):
     _engine_vs_oracle(emu_lib, "cpu", cfg, sd, inp, tar_img, 32, 32, 2, 2e-4, make_kw=dict(lib=emu_lib))
 
 
+def test_pose_train_extras_emulated(emu_lib):
+    """Pose model (256 x 256 only: the composite's columns are fixed, TSNet_pose.py:277-280), narrow channels."""
+    cfg = O.TSNetConfig(label_nc=25, n_blocks=0, n_source=2, ngf=8, enc_blocks=0, fuse_ngf=128, pose=True)
+    sd = O.synth_state_dict(cfg, seed=5, bias_std=0.02)
+    sd = {k: (v * 3 if k.endswith("weight") else v) for k, v in sd.items()}
+    inp = O.synth_inputs(cfg, 1, 256, 256, seed=6, mask_mode="box")
+    tar_img = O.synth_inputs(cfg, 1, 256, 256, seed=1006, mask_mode="box")[0][0]
+    _engine_vs_oracle(emu_lib, "cpu", cfg, sd, inp, tar_img, 256, 256, 1, 2e-4, make_kw=dict(lib=emu_lib))
+
+
 @pytest.mark.gpu
-def test_train_extras_gpu_golden_case():
-    z, meta, cfg, sd, inp, tar_img = _golden_case()
+@pytest.mark.parametrize("name", CASES)
+def test_train_extras_gpu_golden_case(name):
+    z, meta, cfg, sd, inp, tar_img = _golden_case(name)
     _engine_vs_oracle(None, "cuda", cfg, sd, inp, tar_img, 256, 256, meta["B"], 2e-4)
+
+
+@pytest.mark.gpu
+def test_pose_train_extras_through_the_model_shell():
+    """TSNetPose.set_train_input + forward: warp_src_img_list with the fixed-background composite, loss_warp, no loss_align;
+    values against the golden captured from the reference's TSNet_pose in training mode."""
+    from wacv23_tsnet_amd.model import TSNetPose
+    z, meta, cfg, sd, inp, tar_img = _golden_case("g5_train_extras_pose_256_k2")
+    m = TSNetPose(is_train=False, label_nc=25, n_blocks=0, n_downsampling=3, n_source=2)
+    m.load_checkpoint({net: {k[len(net) + 1:]: v for k, v in sd.items() if k.startswith(net + ".")} for net in ("img_enc", "lbl_enc", "fuse_net", "dec")})
+    m = m.cuda()
+    m.set_train_input(inp[0], inp[1], inp[2], tar_img, inp[3], inp[4])
+    m.forward()
+    torch.cuda.synchronize()
+    assert abs(float(m.loss_warp) - meta["loss_warp"]) <= 1e-4 and m.loss_align is None
+    bg = torch.tensor([-x / 255.0 for x in cfg.mean], dtype=torch.float32)
+    for i in range(2):
+        w = m.warp_src_img_list[i].cpu()
+        assert np.abs(w[:, :, 96:160, 96:160].numpy() - z[f"warp{i}_crop"]).max() <= 2e-4
+        assert np.abs(w.double().sum(dim=3).numpy() - z[f"warp{i}_rowsum64"]).max() <= 5e-2
+        assert torch.equal(w[0, :, :, :64], bg.view(3, 1, 1).expand(3, 256, 64))          # background columns are exactly -mean/255
 
 
 @pytest.mark.gpu

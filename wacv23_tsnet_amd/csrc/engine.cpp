@@ -1923,11 +1923,17 @@ int tsnet_train_extras(tsnet_handle h, const float* const* src_img, const float*
     check_launch("frame_stats(tar)");
     hipLaunchKernelGGL(frame_stats_kernel, dim3(3, N), dim3(256), 0, st, warp_src_img, 3, HW, 1.0f, gen_mean, gen_std);   // :381-382
     check_launch("frame_stats(warp)");
-    hipLaunchKernelGGL(renorm_l1_kernel, dim3(chunks, 3, N), dim3(256), 0, st, warp_src_img, tar_img, B, HW, gen_mean, gen_std, ref_mean, ref_std, l1_part);
+    const bool pose = h->cfg.pose_composite != 0;       // TSNet_pose.py:399-400 composite before the L1; no alignment loss
+    float bg[3];
+    for (int c = 0; c < 3; ++c) bg[c] = (-h->cfg.pose_mean[c]) / 255.0f;            // TSNet_pose.py:276
+    hipLaunchKernelGGL(renorm_l1_kernel, dim3(chunks, 3, N), dim3(256), 0, st, warp_src_img, tar_img, B, HW, gen_mean, gen_std, ref_mean, ref_std, l1_part,
+                       W, pose ? 64 : 0, pose ? 192 : 0, bg[0], bg[1], bg[2]);
     check_launch("renorm_l1");
-    hipLaunchKernelGGL(cosine_partial_kernel, dim3(ncos), dim3(256), 0, st, h->pg, h->sg, B * P, C, cos_part);
-    check_launch("cosine_partial");
-    hipLaunchKernelGGL(train_losses_kernel, dim3(1), dim3(64), 0, st, l1_part, K, B * 3 * chunks, (double)B * 3 * HW, cos_part, ncos, (double)B * P, losses);
+    if (!pose) {
+        hipLaunchKernelGGL(cosine_partial_kernel, dim3(ncos), dim3(256), 0, st, h->pg, h->sg, B * P, C, cos_part);
+        check_launch("cosine_partial");
+    }
+    hipLaunchKernelGGL(train_losses_kernel, dim3(1), dim3(64), 0, st, l1_part, K, B * 3 * chunks, (double)B * 3 * HW, cos_part, pose ? 0 : ncos, (double)B * P, losses);
     check_launch("train_losses");
     API_END(h)
 }

@@ -9,6 +9,8 @@
 //               (frame_stats_kernel of postproc.hpp + the elementwise pass below)
 //   * :386,:390 loss_warp = sum_i 10 * L1(warp_src_img_i, tar_img)
 //   * :403-405  loss_align = 1 - mean_p cos(pg[:, p], sg[:, p])
+// Pose model (model/TSNet_pose.py:343-346, 386-404): same warp and re-normalisation, then the fixed-background composite of the
+// warped image (:399-400) before the L1 (:402); no alignment loss.
 // Reductions are fp64 in a fixed order (per-block partials, then one block): deterministic.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(256) void patch_warp_kernel(PatchWarpArgs a) {
 __global__ __launch_bounds__(256) void renorm_l1_kernel(float* __restrict__ x, const float* __restrict__ tar, int B, int HW,
                                                         const float* __restrict__ gen_mean, const float* __restrict__ gen_std,
                                                         const float* __restrict__ ref_mean, const float* __restrict__ ref_std,
-                                                        double* __restrict__ part) {
+                                                        double* __restrict__ part, int W, int fore_x0, int fore_x1, float bg0, float bg1,
+                                                        float bg2) {
     __shared__ double red[256];
     const int c = blockIdx.y, n = blockIdx.z, b = n % B, tid = threadIdx.x;
     const float gm = gen_mean[n * 3 + c], gs = gen_std[n * 3 + c], rm = ref_mean[b * 3 + c], rs = ref_std[b * 3 + c];
@@ -75,6 +78,10 @@ __global__ __launch_bounds__(256) void renorm_l1_kernel(float* __restrict__ x, c
     for (int i = blockIdx.x * 256 + tid; i < HW; i += gridDim.x * 256) {
         float v = px[i];
         v = v - gm; v = v / gs; v = v * rs; v = v + rm;
+        if (fore_x1 > fore_x0) {                              // pose composite: x * fore + bg * (1 - fore), fore in {0, 1}
+            const int X = i % W;
+            if (X < fore_x0 || X >= fore_x1) v = c == 0 ? bg0 : c == 1 ? bg1 : bg2;
+        }
         px[i] = v;
         const float d = v - pt[i] / 255.0f;
         acc += (double)(d < 0.f ? -d : d);
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(256) void cosine_partial_kernel(const float* __rest
 // out[0] = loss_warp = sum_n 10 * (sum of frame n's partials) / (3*HW);  out[1] = loss_align = 1 - (sum of cos partials) / rows
 __global__ void train_losses_kernel(const double* __restrict__ l1_part, int frames, int per_frame, double l1_den,
                                     const double* __restrict__ cos_part, int ncos, double rows, float* __restrict__ out) {
+    // ncos == 0: the pose model, which has no alignment loss -> out[1] = 0
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float lw = 0.f;
     for (int n = 0; n < frames; ++n) {                       // frames are grouped by source: K terms of B frames each are
@@ -125,7 +133,7 @@ __global__ void train_losses_kernel(const double* __restrict__ l1_part, int fram
     double cs = 0.0;
     for (int i = 0; i < ncos; ++i) cs += cos_part[i];
     out[0] = lw;
-    out[1] = 1.0f - (float)(cs / rows);
+    out[1] = ncos > 0 ? 1.0f - (float)(cs / rows) : 0.0f;
 }
 
 }  // namespace tsnet

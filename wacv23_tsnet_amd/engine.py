@@ -220,7 +220,8 @@ class TSNetEngine:
     def train_extras(self, src_img: List[torch.Tensor], tar_img: torch.Tensor):
         """tsnet_train_extras: the is_train branches of the reference forward (TSNet.py:327-331, 372-390, 402-405) for the
         forward that was just run.  Returns (warp_src_img_list: K x (B,3,H,W), loss_warp, loss_align) -- the losses as 0-d
-        device tensors."""
+        device tensors.  With pose_composite (the pose model, TSNet_pose.py:343-346, 386-404) the warped images carry the
+        fixed-background composite and loss_align is None (that model has none)."""
         B = tar_img.shape[0]
         H, W, K = self.cfg.height, self.cfg.width, self.K
         si = [self._prep(src_img[i], (B, 3, H, W), f"src_img[{i}]") for i in range(K)]
@@ -232,7 +233,7 @@ class TSNetEngine:
             rc = self.lib.tsnet_train_extras(self._h, self._ptr_array(si), ti.data_ptr(), B, warp.data_ptr(), losses.data_ptr(), _stream_of(ti))
         self._check(rc, "tsnet_train_extras")
         self._keep_train = (si, ti)
-        return [warp[i] for i in range(K)], losses[0], losses[1]
+        return [warp[i] for i in range(K)], losses[0], (None if self.cfg.pose_composite else losses[1])
 
     def stage(self, name: str, device, shape=None) -> torch.Tensor:
         """Copy of a stage tensor of the last forward, NHWC (see tsnet_stage_ptr); `shape` = trailing (H, W, C)

@@ -200,6 +200,8 @@ class TSNet(nn.Module):
             self.warp_grid2d_list = flows
         if self.tar_img is not None:           # set_train_input was used: the forward's training-mode outputs
             self.warp_src_img_list, self.loss_warp, self.loss_align = eng.train_extras(self.src_img_list[:K], self.tar_img)
+            if self._pose:
+                self.loss_align = None         # TSNet_pose.py has no alignment loss
 
     # ------------------------------------------------------------------ engine management
     def _device(self):
@@ -255,8 +257,5 @@ class TSNetPose(TSNet):
         self.use_mask = use_mask
         self.mean = tuple(float(x) for x in np.asarray(mean, dtype=np.float32))
 
-    def set_train_input(self, *args, **kw):
-        """The pose model's training-mode forward composites warp_src_img with the fixed foreground mask before the L1 and has no
-        loss_align (TSNet_pose.py:396-404); the engine's train extras implement the face model's (TSNet.py:372-405).  Not built:
-        fail loudly instead of returning the face model's numbers."""
-        raise NotImplementedError("TSNetPose: the training-mode forward extras are built for the face model only; use set_test_input()")
+    # set_train_input / forward are the base class's: with use_mask the engine composites warp_src_img with the fixed background
+    # before the L1 and reports no alignment loss (TSNet_pose.py:343-346, 386-404); self.loss_align stays None.
