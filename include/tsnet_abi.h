@@ -209,6 +209,24 @@ int tsnet_demo_postprocess(const float* rec, int B, int H, int W, const float* g
 int tsnet_raster_face(const double* keypoints, int F, int h, int w, int bw, unsigned char* edges, unsigned char* bbox, void* stream);
 int tsnet_vl2ch(const float* labels, int B, int HW, int num_classes, float* out, void* stream);
 
+/* Pose clips (dataset/dataset_video_pose.py PoseDatasetTestVideo.get_image / get_smooth_lbl :489-536, test mode).
+ * tsnet_raster_pose <- utils/keypoint2img_posenorm.py connect_keypoints (:265-311; draw_edge :469-487, interp_points :490-516) followed by
+ *                      crop_person_region (:538-552) and utils/misc.py im2vl (:27-47).  pts: (F,137,2) device doubles in frame coordinates =
+ *                      the four arrays connect_keypoints takes, concatenated (pose 25 | face 70 | left hand 21 | right hand 21), invalid points
+ *                      zero (extract_valid_keypoints, :242-262).  The skeleton is drawn on the h x w frame; labels (F, win_y1-win_y0,
+ *                      win_x1-win_x0) receives the CLASS INDEX (0..24) of every pixel of the window [win_x0,win_x1) x [win_y0,win_y1) -- what
+ *                      im2vl makes of the cropped colour image.  labels must be 4-byte aligned and its allocation a multiple of 4 bytes.
+ *                      flags: 1 = basic_point_only, 2 = remove_face_labels.  Stroke widths are the test-mode ones (isTrain = False).
+ * tsnet_label_bbox  <- PoseDatasetTestVideo.get_bbox_image (:590-607): box of the non-zero label pixels grown by h/16, w/16; 0 / 255 bytes.
+ * tsnet_resize_pad  <- Image.resize(size, NEAREST) + resize_square (:425-432, :471-477): out[f, pad_top+y, pad_left+x] = in[f, ytab[y], xtab[x]],
+ *                      zero elsewhere; out (F,OH,OW) floats (binarise: != 0 -> 1, the `bbox != 0` of :441, :448).  ytab / xtab: device ints, the
+ *                      source row / column of every output row / column (wacv23_tsnet_amd/raster.py computes them in PIL's order). */
+int tsnet_raster_pose(const double* pts, int F, int h, int w, int win_x0, int win_y0, int win_x1, int win_y1, int flags,
+                      unsigned char* labels, void* stream);
+int tsnet_label_bbox(const unsigned char* labels, int F, int h, int w, unsigned char* bbox, void* stream);
+int tsnet_resize_pad(const unsigned char* in, int F, int h, int w, const int* ytab, const int* xtab, int oh, int ow,
+                     int pad_top, int pad_left, int OH, int OW, int binarise, float* out, void* stream);
+
 /* Micro-benchmark of one convolution shape on synthetic (non-zero) data: average milliseconds per
  * launch over `iters` back-to-back launches, hipEvent-timed on `stream`.  variant: -1 = the engine's
  * own tile heuristic, else tile index + 8*(BK==32) (tools/conv_sweep.py).  Diagnostic only. */

@@ -1,0 +1,118 @@
+"""Capture golden pose labels from the REAL reference's input rasterisation -- authoring container only (needs /root/reference).
+
+SURVEY.md section 8-f rank 3, pose clips: OpenPose key points -> colour-coded skeleton -> crop -> bounding-box mask -> nearest-neighbour
+resize to 128 x 256 -> zero padding to 256 x 256 -> class-index label.  This script imports the reference's own code unmodified --
+    dataset/dataset_video_pose.py   PoseDatasetTestVideo: get_image('openpose' | 'pts') :489-512, crop_person_region :538-552, get_crop_coords
+                                    :554-588, get_bbox_image :590-607, resize_square :471-477; the class is instantiated and its methods run as
+                                    they are, in the order __getitem__ (:304-461) calls them for the source frames of a clip
+    utils/keypoint2img_posenorm.py  read_keypoints_posenorm :11-41, read_pts_posenorm :67-239, extract_valid_keypoints :242-262,
+                                    connect_keypoints :265-311, draw_edge :469-487, interp_points :490-516
+    utils/misc.py                   im2vl :27-47
+-- behind stubs for the modules this image lacks (cv2, torchvision.transforms.functional: imported by the dataset module, never touched
+by these functions), and runs it on every key-point file of the
+demo clips in demo/dance_example/labels (60 frames of 1920 x 1080 video).  Stored (data only), per clip:
+    pts        (F, 137, 2) float64: the four point arrays connect_keypoints received (pose 25 | face 70 | left hand 21 | right hand 21)
+    crop       the clip's crop rectangle (xs, ys, xe, ye) from its first frame (:329-333), and the frame size
+    cls_crop   (F, ch, cw) uint8: im2vl of the cropped skeleton image
+    bbox_crop  (F, ch, cw) bit-packed: get_bbox_image of it
+    cls_256, bbox_256  (F, 256, 256): after resize((128, 256), NEAREST) + resize_square, as __getitem__ hands them to the model (:425-448)
+    json0      the text of the clip's first key-point file (an input data file of the demo, for the host-side reader)
+    pts_redraw, cls_redraw  the 'pts' path of the driving frames (:397-407, same-sex pairs: ref_pts_length = ""): the skeleton re-drawn at crop
+               size from the shifted points
+
+    python oracle/capture_raster_pose_goldens.py
+"""
+from __future__ import annotations
+
+import copy
+import glob
+import json
+import os
+import sys
+import types
+
+import numpy as np
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+IMG_MEAN = np.array((101.84807705937696, 112.10832843463207, 111.65973036298041), dtype=np.float32)
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not mounted; goldens can only be captured in the authoring container")
+    for name in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional", "imageio", "json_tricks"):
+        m = types.ModuleType(name)
+        if name in ("torchvision", "torchvision.transforms"):
+            m.__path__ = []                                        # packages
+        sys.modules[name] = m
+    sys.modules["json_tricks"].load = json.load                    # the constructor reads two video-list files the captured functions never use
+    sys.modules["json_tricks"].loads = json.loads
+    sys.path.insert(0, REF)
+    import dataset.dataset_video_pose as ds
+    import utils.misc as misc
+    return ds, misc
+
+
+def stack_pts(pts):
+    out = np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in pts], axis=0)
+    assert out.shape == (137, 2)
+    return out
+
+
+def main():
+    ds, misc = import_reference()
+    os.makedirs(GOLD, exist_ok=True)
+    jp = os.path.join(REF, "dataset", "json_pose")
+    d = ds.PoseDatasetTestVideo(test_pairs=[], sub_json_path=os.path.join(jp, "clean_video_dict.json"),
+                                msk_json_path=os.path.join(jp, "clean_unseen_video_dict.json"), label_path=None, smooth_label_path=None,
+                                image_path=None, mean=IMG_MEAN, n_frame_total=30)
+    lab_root = os.path.join(REF, "demo", "dance_example", "labels")
+    img_root = os.path.join(REF, "demo", "dance_example", "images")
+    arrays, meta = {}, {"clips": {}, "source": "demo/dance_example/labels/*/*_keypoints.json", "img_size": list(d.img_size)}
+    for clip in sorted(os.listdir(lab_root)):
+        files = sorted(glob.glob(os.path.join(lab_root, clip, "*.json")))
+        size = Image.open(sorted(glob.glob(os.path.join(img_root, clip, "*")))[0]).size                     # :330
+        _, crop, _, scale = d.get_image(A_path=files[0], size=size, crop_coords=None, input_type="openpose",
+                                        ref_pts_length=None, scale=None)                                    # :331-334
+        pts_all, cls_crop, bbox_crop, cls_256, bbox_256, pts_re, cls_re = [], [], [], [], [], [], []
+        for f in files:
+            lbl, c, pts, _ = d.get_image(A_path=f, size=size, crop_coords=crop, input_type="openpose", ref_pts_length=None, scale=scale)   # :343-348
+            assert list(c) == list(crop)
+            pts_all.append(stack_pts(pts))
+            bbox = d.get_bbox_image(lbl)                                                                    # :351
+            cls_crop.append(misc.im2vl(np.asarray(lbl, dtype=np.uint8), "pose", False, False))
+            bbox_crop.append(np.asarray(bbox, dtype=np.uint8) != 0)
+            lbl_sq = d.resize_square(lbl.resize(d.img_size, resample=Image.NEAREST))                        # :426-431
+            bbox_sq = d.resize_square(bbox.resize(d.img_size, resample=Image.NEAREST))
+            cls_256.append(misc.im2vl(np.asarray(lbl_sq, dtype=np.uint8), "pose", False, False))            # :436-439
+            bbox_256.append(np.array(np.asarray(bbox_sq, dtype=np.uint8) != 0, dtype=np.uint8))             # :440-441
+            # the driving frames' second pass (:397-407): re-drawn at crop size from the points; same-sex pair -> no limb re-scaling
+            p2 = copy.deepcopy(pts)
+            re = d.get_image(A_path=None, size=lbl.size, crop_coords=crop, input_type="pts", ref_pts_length="", scale=None, pts=p2)
+            pts_re.append(stack_pts(p2))                                                                    # shifted in place by read_pts_posenorm
+            cls_re.append(misc.im2vl(np.asarray(re, dtype=np.uint8), "pose", False, False))
+        arrays[f"{clip}_pts"] = np.stack(pts_all)
+        arrays[f"{clip}_json0"] = np.array(open(files[0], encoding="utf-8").read())        # the first frame's OpenPose file: input of the file-reading host code
+        arrays[f"{clip}_cls_crop"] = np.stack(cls_crop)
+        arrays[f"{clip}_bbox_crop"] = np.packbits(np.stack(bbox_crop), axis=-1)
+        arrays[f"{clip}_cls_256"] = np.stack(cls_256)
+        arrays[f"{clip}_bbox_256"] = np.packbits(np.stack(bbox_256) > 0, axis=-1)
+        arrays[f"{clip}_pts_redraw"] = np.stack(pts_re)
+        arrays[f"{clip}_cls_redraw"] = np.stack(cls_re)
+        hist = np.bincount(arrays[f"{clip}_cls_crop"].ravel(), minlength=25)
+        meta["clips"][clip] = dict(frames=len(files), size=[int(size[0]), int(size[1])], crop=[int(x) for x in crop], scale=float(scale),
+                                   files=[os.path.basename(f) for f in files], class_pixels=[int(x) for x in hist])
+        print(f"[{clip}] {len(files)} frames of {size}, crop {crop}, classes present: {int((hist > 0).sum())}, label pixels {int(hist[1:].sum())}")
+    import PIL
+    import scipy
+    meta["versions"] = dict(numpy=np.__version__, scipy=scipy.__version__, pillow=PIL.__version__)
+    np.savez_compressed(os.path.join(GOLD, "g9_raster_pose.npz"), meta=json.dumps(meta), **arrays)
+    print("written", os.path.getsize(os.path.join(GOLD, "g9_raster_pose.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

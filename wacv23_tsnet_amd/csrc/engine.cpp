@@ -2253,6 +2253,44 @@ int tsnet_raster_face(const double* keypoints, int F, int h, int w, int bw, unsi
     OP_END
 }
 
+int tsnet_raster_pose(const double* pts, int F, int h, int w, int win_x0, int win_y0, int win_x1, int win_y1, int flags,
+                      unsigned char* labels, void* stream) {
+    OP_BEGIN
+    if (!pts || !labels) throw ArgError("raster_pose: null tensor");
+    if (F < 1 || F > 65535 || h < 1 || w < 1 || (double)h * w >= 2147483647.0) throw ArgError("raster_pose: bad shape");
+    if (win_x0 < 0 || win_y0 < 0 || win_x1 > w || win_y1 > h || win_x1 <= win_x0 || win_y1 <= win_y0) throw ArgError("raster_pose: window outside the frame");
+    if (((uintptr_t)labels & 3) != 0) throw ArgError("raster_pose: labels must be 4-byte aligned (and padded to a multiple of 4 bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)F * (win_y1 - win_y0) * (win_x1 - win_x0), n4 = (n + 3) / 4 * 4;
+    HIP_TRY(hipMemsetAsync(labels, 0, n4, s));
+    hipLaunchKernelGGL(pose_edges_kernel, dim3(kPosePrims, F), dim3(64), 0, s, pts, labels, h, w, win_x0, win_y0, win_x1, win_y1, flags);
+    check_launch("pose_edges");
+    hipLaunchKernelGGL(pose_order_to_class_kernel, dim3(ew_grid(n)), dim3(256), 0, s, labels, n);
+    check_launch("pose_order_to_class");
+    OP_END
+}
+
+int tsnet_label_bbox(const unsigned char* labels, int F, int h, int w, unsigned char* bbox, void* stream) {
+    OP_BEGIN
+    if (!labels || !bbox) throw ArgError("label_bbox: null tensor");
+    if (F < 1 || F > 65535 || h < 1 || w < 1 || (double)h * w >= 2147483647.0) throw ArgError("label_bbox: bad shape");
+    hipLaunchKernelGGL(label_bbox_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, labels, bbox, h, w);
+    check_launch("label_bbox");
+    OP_END
+}
+
+int tsnet_resize_pad(const unsigned char* in, int F, int h, int w, const int* ytab, const int* xtab, int oh, int ow,
+                     int pad_top, int pad_left, int OH, int OW, int binarise, float* out, void* stream) {
+    OP_BEGIN
+    if (!in || !ytab || !xtab || !out) throw ArgError("resize_pad: null tensor");
+    if (F < 1 || h < 1 || w < 1 || oh < 1 || ow < 1 || pad_top < 0 || pad_left < 0 || pad_top + oh > OH || pad_left + ow > OW)
+        throw ArgError("resize_pad: bad shape");
+    hipLaunchKernelGGL(gather_pad_kernel, dim3(ew_grid((size_t)F * OH * OW)), dim3(256), 0, (hipStream_t)stream, in, F, h, w, ytab, xtab, oh, ow,
+                       pad_top, pad_left, OH, OW, out, binarise);
+    check_launch("gather_pad");
+    OP_END
+}
+
 int tsnet_vl2ch(const float* labels, int B, int HW, int num_classes, float* out, void* stream) {
     OP_BEGIN
     if (!labels || !out) throw ArgError("vl2ch: null tensor");

@@ -10,6 +10,12 @@
 // fp64), evaluated in the reference's operation order a*x^2 + b*x + c.  The two differ only where a sample lands within the optimiser's
 // error of an integer (the end points of a piece, whose true ordinates are the integer key points): tests/test_raster.py reports the
 // Hamming distance to the reference's maps on every frame of the demo clips.  Bounding box and one-hot are integer work: bit-exact.
+//
+// Pose clips (OpenPose key points -> colour-coded skeleton -> class-index label; dataset/dataset_video_pose.py:489-615):
+//   * utils/keypoint2img_posenorm.py connect_keypoints (:265-311) + draw_edge (:469-487) + interp_points (:490-516, two-point pieces only:
+//     a straight line) + utils/misc.py im2vl (:27-47, colour -> class index)                  -> pose_edges_kernel + pose_order_to_class_kernel
+//   * PoseDatasetTestVideo.get_bbox_image (:590-607)                                          -> label_bbox_kernel
+//   * Image.resize(.., NEAREST) + resize_square (:425-432, :471-477)                          -> gather_pad_kernel (index tables from the host)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -95,6 +101,169 @@ __global__ __launch_bounds__(256) void onehot_kernel(const float* __restrict__ l
         const int c = (int)((i / HW) % nc);
         const int b = (int)(i / ((size_t)HW * nc));
         out[i] = lbl[(size_t)b * HW + p] == (float)c ? 1.f : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- pose clips
+constexpr int kPosePts = 137;            // pose 25 | face 70 | left hand 21 | right hand 21, the four arrays connect_keypoints takes
+constexpr int kPoseEdges = 24, kHandSegs = 20, kFacePieces = 54;
+constexpr int kPosePrims = kPoseEdges + 2 * kHandSegs + kFacePieces;
+// pose_edge_list incl. the feet (define_edge_lists, keypoint2img_posenorm.py:396-421); with basic_point_only only the first 18
+__device__ const unsigned char kPoseEdgeTable[kPoseEdges][2] = {
+    {17, 15}, {15, 0}, {0, 16}, {16, 18}, {0, 1}, {1, 8}, {1, 2}, {2, 3}, {3, 4}, {1, 5}, {5, 6}, {6, 7},
+    {8, 9}, {9, 10}, {10, 11}, {8, 12}, {12, 13}, {13, 14}, {11, 24}, {11, 22}, {22, 23}, {14, 21}, {14, 19}, {19, 20}};
+// face_list cut into consecutive pairs (edge_len = 2, :296-300)
+__device__ const unsigned char kFacePieceTable[kFacePieces][2] = {
+    {0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {9, 10}, {10, 11}, {11, 12}, {12, 13}, {13, 14}, {14, 15}, {15, 16},
+    {17, 18}, {18, 19}, {19, 20}, {20, 21}, {22, 23}, {23, 24}, {24, 25}, {25, 26},
+    {28, 31}, {31, 32}, {32, 33}, {33, 34}, {34, 35}, {35, 28},
+    {36, 37}, {37, 38}, {38, 39}, {39, 40}, {40, 41}, {41, 36}, {42, 43}, {43, 44}, {44, 45}, {45, 46}, {46, 47}, {47, 42},
+    {48, 49}, {49, 50}, {50, 51}, {51, 52}, {52, 53}, {53, 54}, {54, 55}, {55, 56}, {56, 57}, {57, 58}, {58, 59}, {59, 48}};
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// Painting order decides which colour a pixel keeps (later primitives overwrite earlier ones, set_color :461-466).  The canvas holds
+// (order + 1) per pixel, raised with a byte-wise atomic max -- order-independent, so the result does not depend on scheduling -- and
+// pose_order_to_class_kernel maps it to the class index im2vl gives the colour of that primitive.
+__device__ __forceinline__ void raise_byte(unsigned char* base, size_t idx, unsigned v) {
+    unsigned* wp = reinterpret_cast<unsigned*>(base + (idx & ~(size_t)3));
+    const unsigned sh = (unsigned)(idx & 3) * 8;
+    unsigned old = *wp;
+    while (((old >> sh) & 0xffu) < v) {
+        const unsigned nw = (old & ~(0xffu << sh)) | (v << sh);
+        const unsigned prev = atomicCAS(wp, old, nw);
+        if (prev == old) break;
+        old = prev;
+    }
+}
+
+// grid = (kPosePrims, F).  pts: (F, 137, 2) fp64 in frame coordinates, invalid points = 0 (extract_valid_keypoints).  The skeleton is drawn on
+// the h x w frame (border clamping of draw_edge against THAT size), but only pixels inside the window [x0, x1) x [y0, y1) are stored:
+// out is (F, y1 - y0, x1 - x0) -- crop_person_region (:538-552) of the drawn frame.  flags: 1 = basic_point_only, 2 = remove_face_labels.
+__global__ __launch_bounds__(64) void pose_edges_kernel(const double* __restrict__ pts, unsigned char* __restrict__ out, int h, int w,
+                                                        int x0, int y0, int x1, int y1, int flags) {
+    const int e = blockIdx.x, f = blockIdx.y;
+    const double* P = pts + (size_t)f * kPosePts * 2;
+    int ia, ib, order, bw;
+    bool ends = false;
+    {   // stroke widths from the person's height in pixels (:272-273, 283, 295); the min runs over all 25 rows, zeros included
+        double ymin = P[1], ymax = P[1];
+        for (int i = 1; i < 25; ++i) { ymin = fmin(ymin, P[2 * i + 1]); ymax = fmax(ymax, P[2 * i + 1]); }
+        const int ph = (int)(ymax - ymin);
+        const int bw_pose = imin(imax(1, ph / 150), 5), bw_small = imin(imax(1, ph / 450), 3);
+        if (e < kPoseEdges) {
+            if ((flags & 1) && e >= 18) return;
+            ia = kPoseEdgeTable[e][0]; ib = kPoseEdgeTable[e][1]; order = e; bw = bw_pose; ends = true;
+        } else if (e < kPoseEdges + 2 * kHandSegs) {
+            if (flags & 1) return;
+            const int k = e - kPoseEdges, hand = k / kHandSegs, seg = k % kHandSegs, finger = seg / 4, j = seg % 4;
+            const int base = 25 + 70 + hand * 21;
+            ia = base + (j == 0 ? 0 : finger * 4 + j); ib = base + finger * 4 + j + 1;
+            order = kPoseEdges + hand * 5 + finger; bw = bw_small;
+        } else {
+            if (flags & 3) return;
+            const int k = e - kPoseEdges - 2 * kHandSegs;
+            ia = 25 + kFacePieceTable[k][0]; ib = 25 + kFacePieceTable[k][1]; order = kPoseEdges + 10; bw = bw_small;
+        }
+    }
+    const double ax = P[2 * ia], ay = P[2 * ia + 1], bx = P[2 * ib], by = P[2 * ib + 1];
+    if (ax == 0.0 || bx == 0.0) return;                           // `0 not in x`
+    const bool swap = fabs(ax - bx) < fabs(ay - by);              // fit along the axis with the larger extent (:491-492)
+    double u0 = swap ? ay : ax, v0 = swap ? ax : ay, u1 = swap ? by : bx, v1 = swap ? bx : by;
+    const double b = (v1 - v0) / (u1 - u0), c = v0 - b * u0;      // the line curve_fit(linear, ..) converges to
+    if (u0 > u1) { const double t = u0; u0 = u1; u1 = t; }
+    const int num = (int)ceil(u1 - u0);
+    if (num < 1 || !(fabs(b) <= 1.7e308)) return;
+    const double step = num > 1 ? (u1 - u0) / (double)(num - 1) : 0.0;
+    const int cw = x1 - x0, ch = y1 - y0;
+    const unsigned val = (unsigned)order + 1u;
+    auto put = [&](int y, int x) {
+        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+        if (y >= y0 && y < y1 && x >= x0 && x < x1) raise_byte(out, (size_t)f * ch * cw + (size_t)(y - y0) * cw + (x - x0), val);
+    };
+    auto sample = [&](int i, int& x, int& y) {
+        const double cu = (i == num - 1 && num > 1) ? u1 : u0 + (double)i * step;       // np.linspace
+        const double cv = b * cu + c;
+        const int iu = (int)cu, iv = (int)cv;                     // astype(int)
+        x = swap ? iv : iu; y = swap ? iu : iv;
+    };
+    for (int i = threadIdx.x; i < num; i += blockDim.x) {
+        int x, y;
+        sample(i, x, y);
+        for (int di = -bw; di < bw; ++di)
+            for (int dj = -bw; dj < bw; ++dj) put(y + di, x + dj);
+    }
+    if (ends) {                                                   // discs of radius 2 bw at the first and the last sample (:480-487)
+        int ex[2], ey[2];
+        sample(0, ex[0], ey[0]);
+        sample(num - 1, ex[1], ey[1]);
+        const int side = 4 * bw;
+        for (int t = threadIdx.x; t < side * side * 2; t += blockDim.x) {
+            const int which = t / (side * side), r = t % (side * side), di = r / side - 2 * bw, dj = r % side - 2 * bw;
+            if (di * di + dj * dj < 4 * bw * bw) put(ey[which] + di, ex[which] + dj);
+        }
+    }
+}
+
+// (order + 1) -> class index of that primitive's colour (utils/misc.py global_pose_color_dict :10-25): pose edge i -> i + 1, the foot edges
+// reuse the colours of edges 14 and 17, finger i -> 19 + i on both hands, face -> 24
+__global__ __launch_bounds__(256) void pose_order_to_class_kernel(unsigned char* __restrict__ io, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = io[i];
+        if (v == 0) continue;
+        const int o = v - 1;
+        int cls;
+        if (o < 18) cls = o + 1;
+        else if (o < 21) cls = 15;
+        else if (o < 24) cls = 18;
+        else if (o < 34) cls = 19 + (o - 24) % 5;
+        else cls = 24;
+        io[i] = (unsigned char)cls;
+    }
+}
+
+// get_bbox_image of the pose dataset (:590-607): the box of the non-zero label pixels, grown by h/16, w/16.  grid = F, 256 threads.
+// A frame without any label pixel (the reference raises there) gives an all-zero mask.
+__global__ __launch_bounds__(256) void label_bbox_kernel(const unsigned char* __restrict__ lbl, unsigned char* __restrict__ out, int h, int w) {
+    __shared__ int sx0[256], sx1[256], sy0[256], sy1[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const unsigned char* L = lbl + (size_t)f * h * w;
+    int x0 = w, x1 = -1, y0 = h, y1 = -1;
+    for (int i = tid; i < h * w; i += 256)
+        if (L[i]) { const int y = i / w, x = i - y * w; x0 = imin(x0, x); x1 = imax(x1, x); y0 = imin(y0, y); y1 = imax(y1, y); }
+    sx0[tid] = x0; sx1[tid] = x1; sy0[tid] = y0; sy1[tid] = y1;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) { sx0[tid] = imin(sx0[tid], sx0[tid + k]); sx1[tid] = imax(sx1[tid], sx1[tid + k]);
+                       sy0[tid] = imin(sy0[tid], sy0[tid + k]); sy1[tid] = imax(sy1[tid], sy1[tid + k]); }
+        __syncthreads();
+    }
+    x0 = sx0[0]; x1 = sx1[0]; y0 = sy0[0]; y1 = sy1[0];
+    const bool any = x1 >= 0;
+    const int bx0 = imax(0, x0 - w / 16), bx1 = imin(w, x1 + w / 16), by0 = imax(0, y0 - h / 16), by1 = imin(h, y1 + h / 16);
+    for (int i = tid; i < h * w; i += 256) {
+        const int y = i / w, x = i - y * w;
+        out[(size_t)f * h * w + i] = (any && y >= by0 && y < by1 && x >= bx0 && x < bx1) ? 255 : 0;
+    }
+}
+
+// out[f, py + y, px + x] = in[f, ytab[y], xtab[x]] for y < oh, x < ow; 0 elsewhere.  Nearest-neighbour resize with the host's index tables
+// (PIL's accumulation order lives there) followed by the centred zero padding of resize_square.  out: (F, OH, OW) floats.
+__global__ __launch_bounds__(256) void gather_pad_kernel(const unsigned char* __restrict__ in, int F, int h, int w, const int* __restrict__ ytab,
+                                                         const int* __restrict__ xtab, int oh, int ow, int py, int px, int OH, int OW,
+                                                         float* __restrict__ out, int binarise) {
+    const size_t total = (size_t)F * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % OW), Y = (int)((i / OW) % OH), f = (int)(i / ((size_t)OW * OH));
+        const int y = Y - py, x = X - px;
+        float v = 0.f;
+        if (y >= 0 && y < oh && x >= 0 && x < ow) {
+            const unsigned char s = in[((size_t)f * h + ytab[y]) * w + xtab[x]];
+            v = binarise ? (s != 0 ? 1.f : 0.f) : (float)s;
+        }
+        out[i] = v;
     }
 }
 
