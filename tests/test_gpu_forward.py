@@ -169,6 +169,22 @@ def test_cfg3_shape_pose_l25():
     eng.close()
 
 
+def test_cfg3_full_batch_32_on_one_gpu():
+    """configs[3] whole: TSNet_pose, bs = 32 (the reference spreads it over 8 GPUs with DataParallel; 288 GB hold it on one).  Every sample is
+    independent, so besides the oracle gate the first four samples must equal, bit for bit, a B = 4 run of the same engine."""
+    cfg = O.TSNetConfig(label_nc=25, n_blocks=4, n_source=3, pose=True)
+    sd, inp, ref = _oracle_case(cfg, 32, 256, 256, 23, 27)
+    eng = Hh.make_engine(cfg, sd, 256, 256, 32, DEV)
+    rec, _ = Hh.run_engine(eng, inp, DEV, return_flow=False)
+    d = (rec - ref["rec_tar_img"]).abs().max().item()
+    sub = [[t[:4] for t in x] if isinstance(x, list) else x[:4] for x in inp]
+    rec4, _ = Hh.run_engine(eng, sub, DEV, return_flow=False)
+    print(f"[cfg3-bs32] d_rec={d:.2e}")
+    assert d <= TOL_REC
+    assert torch.equal(rec[:4], rec4)
+    eng.close()
+
+
 def test_cfg4_shape_512_k5():
     """configs[4] shape: 512x512, n_source=5 (P=4096 positions: the fused flow kernel never builds P x P)."""
     cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=5)
