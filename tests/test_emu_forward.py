@@ -176,6 +176,26 @@ def test_h2_schedule(emu_lib, monkeypatch):
     eng3.close()
 
 
+def test_h2_samples_do_not_see_their_batch(emu_lib):
+    """The fp16 operand scales that come from the data (packed inputs, decoder stream) are taken per image: a sample's result must be the
+    same bits whether it runs alone or next to a sample with a 40x larger input range (the basis of batch sharding across GPUs)."""
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=1, ngf=32, enc_blocks=0, fuse_ngf=512)
+    sd = O.synth_state_dict(cfg, seed=14, bias_std=0.02)
+    sd = {k: (v * 2 if k.endswith("weight") else v) for k, v in sd.items()}
+    inp = O.synth_inputs(cfg, 2, 32, 256, seed=16, mask_mode="box")
+    inp[0][0][1] *= 40.0                                     # second sample: source image far outside [0, 255]
+    eng = Hh.make_engine(cfg, sd, 32, 256, 2, "cpu", lib=emu_lib)
+    emu_lib.tsnet_debug_counters(None, 1)
+    rec2, _ = Hh.run_engine(eng, inp, "cpu", return_flow=False)
+    cnt = (C.c_int64 * 4)()
+    emu_lib.tsnet_debug_counters(cnt, 1)
+    assert cnt[0] > 0                                        # the h2 schedule ran
+    one = [[t[:1] for t in x] if isinstance(x, list) else x[:1] for x in inp]
+    rec1, _ = Hh.run_engine(eng, one, "cpu", return_flow=False)
+    assert torch.equal(rec2[:1], rec1)
+    eng.close()
+
+
 def test_bf16_operand_mode(emu_lib):
     """tsnet_cfg.operand_mode = 1 (BASELINE.json configs[2] / [4]): every convolution reads ONE bf16 plane of its input and of its weights
     (conv_h2 with one product and the transform fused, conv_x3q / conv_x3r on the hi plane), fp32 accumulate."""

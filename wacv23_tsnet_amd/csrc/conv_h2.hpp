@@ -49,7 +49,7 @@ struct H2Args {
     // operand scale from the data instead of an a-priori bound: in_amax = bit pattern of max |x| published by x's producer
     // (X3Args::amax_out), bound = that + in_bound_add (what later stages may add, e.g. InstanceNorm outputs of a residual stream);
     // null = the host's in_scale / in_unscale
-    const unsigned* in_amax; float in_bound_add;
+    const unsigned* in_amax; float in_bound_add;          // in_amax[image]: one slot per image, so a sample's result never depends on its batch
 };
 
 // power-of-two operand scale for |x| <= bound: |x * 2^sa| <= 2^15 (the host's h2_scale_log2, engine.cpp)
@@ -133,7 +133,7 @@ __device__ __forceinline__ void h2_tile(const H2Args& a, unsigned char* smem_raw
     const int oy0 = (tin / tcols) * kPatchRows, ox0 = (tin % tcols) * kPatchCols;
     const int ncc = a.Cin >> 4;
     float in_scale = a.in_scale, in_unscale = a.in_unscale;
-    if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax, a.in_bound_add, in_scale, in_unscale);
+    if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax + img, a.in_bound_add, in_scale, in_unscale);
 
     const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
     const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
@@ -398,7 +398,7 @@ void conv_h2r_kernel(H2rArgs a) {
     const int hw = a.Ho * a.Wo;
     const int img = m0 / hw;                                         // a tile lies inside one image (hw % 128 == 0, checked on the host)
     float in_scale = a.in_scale, in_unscale = a.in_unscale;
-    if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax, a.in_bound_add, in_scale, in_unscale);
+    if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax + img, a.in_bound_add, in_scale, in_unscale);
 
     const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
     const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));

@@ -39,7 +39,7 @@ struct X3Args {
     float* fin_alpha; float* fin_beta; int* fin_counter; int fin_S; float fin_eps;
     // optional: max |y| of the launch, as the bit pattern of a non-negative float (order-independent atomic max: deterministic).  The
     // fp16 x 2 kernels (conv_h2.hpp) derive the operand scale of a tensor without an a-priori bound from it; null = off
-    unsigned* amax_out;
+    unsigned* amax_out;    // null, or amax_out[image] <- max |y| of that image (float bits, atomic max); needs Ho*Wo % BM == 0
 };
 
 #ifndef TSNET_DRAIN_VMEM
@@ -94,7 +94,7 @@ __device__ __forceinline__ void x3_epilogue(const Args& a, f32x16 (&tot)[MT][NTL
             }
         }
     }
-    if (a.amax_out) tsnet_publish_amax(a.amax_out, vmax);
+    if (a.amax_out) { const int mf = m_of(0); tsnet_publish_amax(a.amax_out + (mf < 0 ? 0 : mf / hw), vmax); }   // the tile lies inside one image (host-checked)
     if (a.stat_part) {
         __syncthreads();
         double* red = reinterpret_cast<double*>(smem_raw);

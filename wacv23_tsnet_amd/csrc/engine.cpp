@@ -133,6 +133,13 @@ inline int ew_grid(size_t total, int block = 256) {
     return (int)g;
 }
 
+// pack_input_kernel: grid.x blocks per image (grid.y = images), sized so the whole grid stays near 8 blocks per CU
+inline int pack_grid(int hw) {
+    int g = (hw + 255) / 256;
+    if (g > 128) g = 128;
+    return g < 1 ? 1 : g;
+}
+
 // ------------------------------------------------------------------------------------------------
 // convolution layer description + launch
 struct ConvLayer {
@@ -944,8 +951,13 @@ struct tsnet_engine {
     bool x3 = true;
     int np = 3;                           // 1 = bf16-operand mode (cfg.operand_mode): one plane / one product everywhere
     bool h2 = true;                       // fp16x2 patch convolution (conv_h2.hpp) for the 3x3 / stride-1 layers whose input is bounded; TSNET_H2=0: round-1 schedule
-    unsigned* amax = nullptr;             // device: max |x| of tensors without an a-priori bound, as float bits ([0] packed source input,
-                                          // [1] packed label input, [2] decoder stream = dec_map output); reset before each producer
+    unsigned* amax = nullptr;             // device: max |x| PER IMAGE of tensors without an a-priori bound, as float bits; reset before each
+                                          // producer.  One slot per image: a sample's scale (hence its result, bit for bit) never depends on the
+                                          // rest of the batch.  amax_src: K*Bmax packed source inputs; amax_tar: Bmax packed label inputs;
+                                          // amax_dec: Bmax decoder streams (dec_map output)
+    unsigned* amax_src() const { return amax; }
+    unsigned* amax_tar() const { return amax + (size_t)K * Bmax; }
+    unsigned* amax_dec() const { return amax + (size_t)(K + 1) * Bmax; }
     float* U_f32[8] = {nullptr};          // fp32 upsampled decoder inputs (h2 schedule; the bf16x3 schedule writes planes only)
     unsigned short* wpack3 = nullptr; size_t wpack3_elems = 0;
     unsigned short* arena3 = nullptr;
@@ -1281,8 +1293,8 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     part = reinterpret_cast<double*>(part_f);
     // arrival counters: one per (image, 32-channel group) of a launch; launches with more (image, group) pairs than kFinCounterInts
     // fall back to the in_finalize2 kernel (launch_x3_ks / run_conv_h2 check the index range against this size)
-    HIP_TRY(hipMalloc((void**)&amax, 8 * sizeof(unsigned)));
-    HIP_TRY(hipMemsetAsync(amax, 0, 8 * sizeof(unsigned), s));
+    HIP_TRY(hipMalloc((void**)&amax, (size_t)(K + 2) * Bmax * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(amax, 0, (size_t)(K + 2) * Bmax * sizeof(unsigned), s));
     HIP_TRY(hipMalloc((void**)&fin_counter, kFinCounterInts * sizeof(int)));
     HIP_TRY(hipMemsetAsync(fin_counter, 0, kFinCounterInts * sizeof(int), s));
     if (x3) {      // side lane (tsnet_forward): own statistics scratch, counters, (alpha, beta) pairs, stream and events
@@ -1416,11 +1428,11 @@ void tsnet_engine::target_chain_x3(Ctx& ctx, const float* tar_lbl, int B) {
         p.coords = cfg.addcoords ? d_coords : nullptr;
         const bool f32 = stem_h2r(lbl_enc);
         p.out = f32 ? x_lbl : nullptr; p.out3 = f32 ? nullptr : x_lbl3; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
-        if (f32) { HIP_TRY(hipMemsetAsync(amax + 1, 0, sizeof(unsigned), ctx.stream)); p.amax_out = amax + 1; }
-        hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ctx.stream, p);
+        if (f32) { HIP_TRY(hipMemsetAsync(amax_tar(), 0, (size_t)B * sizeof(unsigned), ctx.stream)); p.amax_out = amax_tar(); }
+        hipLaunchKernelGGL(pack_input_kernel, dim3(pack_grid(H * W), B), dim3(256), 0, ctx.stream, p);
         check_launch("pack_input(lbl)");
     }
-    encode_x3(ctx, lbl_enc, x_lbl3, B, raw_lbl, raw3_lbl, tar_fea, tar3, 0, x_lbl, amax + 1);
+    encode_x3(ctx, lbl_enc, x_lbl3, B, raw_lbl, raw3_lbl, tar_fea, tar3, 0, x_lbl, amax_tar());
     run_l2norm(ctx, tar_fea, that, B * P, C);
     if (h2_feat()) {                                                                   // shared target half of fuse conv1
         H2Call t; t.x = tar_fea; t.bound = std::sqrt((float)P); t.N = B; t.H = h; t.W = w; t.y = FT;
@@ -1486,16 +1498,16 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
     // The decoder's stream starts at dec_map's raw output: no a-priori bound.  On the h2 schedule dec_map publishes max |D| (one atomic
     // max per wave, order-independent) and the convolutions reading the stream derive their fp16 operand scale from it on the device:
     // D_i = D_0 + (i InstanceNorm outputs), |D_i| <= max |D_0| + i sqrt(P).  (bf16-operand mode: no scales, nothing to publish.)
-    const bool dyn = h2_feat() && np != 1;
+    const bool dyn = h2_feat() && np != 1 && P % 128 == 0;      // x3 tiles of dec_map (128 positions) must lie inside one image
     const float sqP = std::sqrt((float)P);
     {
         X3Call a; a.x3 = pg3; a.x23 = sg3; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
         a.y3 = (cfg.n_blocks > 0 && !h2_feat()) ? D3 : nullptr;
-        if (dyn) { HIP_TRY(hipMemsetAsync(amax + 2, 0, sizeof(unsigned), ctx.stream)); a.amax_out = amax + 2; }
+        if (dyn) { HIP_TRY(hipMemsetAsync(amax_dec(), 0, (size_t)B * sizeof(unsigned), ctx.stream)); a.amax_out = amax_dec(); }
         rx3(ctx, dec_map, a);
     }
     for (int i = 0; i < cfg.n_blocks; ++i) {
-        if (h2_feat()) resblock_h2(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, np == 1 ? 1.f : 0.f, DY1, DY2, B, h, w, dyn ? amax + 2 : nullptr, (float)i * sqP);
+        if (h2_feat()) resblock_h2(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, np == 1 ? 1.f : 0.f, DY1, DY2, B, h, w, dyn ? amax_dec() : nullptr, (float)i * sqP);
         else resblock_x3(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, DY1, DY2, B, h, w);
     }
     const float* cur = D; const float* cal = nullptr; const float* cbe = nullptr;
@@ -1513,7 +1525,7 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
         auto st = next_ab();
         if (via_h2) {
             H2Call a; a.x = U_f32[i]; a.bound = in_bound; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
-            if (!cal && np != 1) { a.in_amax = amax + 2; a.bound_add = (float)cfg.n_blocks * sqP; }
+            if (!cal && np != 1) { a.in_amax = amax_dec(); a.bound_add = (float)cfg.n_blocks * sqP; }
             conv_stats_h2(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
         } else {
             X3Call a; a.x3 = U3[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
@@ -1580,13 +1592,13 @@ void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const floa
         const bool f32 = !x3 || stem_h2r(img_enc);
         p.out = f32 ? x_img : nullptr; p.out3 = f32 ? nullptr : x_img3;
         p.S = K; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 3; p.Cp = cp_img;
-        if (x3 && f32) { HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), ctx.stream)); p.amax_out = amax; }
-        hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)K * B * H * W)), dim3(256), 0, ctx.stream, p);
+        if (x3 && f32) { HIP_TRY(hipMemsetAsync(amax_src(), 0, (size_t)K * B * sizeof(unsigned), ctx.stream)); p.amax_out = amax_src(); }
+        hipLaunchKernelGGL(pack_input_kernel, dim3(pack_grid(H * W), K * B), dim3(256), 0, ctx.stream, p);
         check_launch("pack_input(img)");
         for (int s = 0; s < K; ++s)
             HIP_TRY(hipMemcpyAsync(bbox_copy + (size_t)s * Bmax * H * W, src_bbox[s], (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
     }
-    if (x3) encode_x3(ctx, img_enc, x_img3, K * B, raw_img, raw3_img, X, X3, cfg.enc_blocks, x_img, amax);
+    if (x3) encode_x3(ctx, img_enc, x_img3, K * B, raw_img, raw3_img, X, X3, cfg.enc_blocks, x_img, amax_src());
     else encode(ctx, img_enc, x_img, K * B, cp_img, raw_img, X, cfg.enc_blocks);
     run_l2norm(ctx, X, shat, K * B * P, C);
     if (x3) {
@@ -1612,7 +1624,7 @@ void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* t
         p.img[0] = nullptr; p.lbl[0] = tar_lbl;
         p.coords = cfg.addcoords ? d_coords : nullptr;
         p.out = x_lbl; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
-        hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ctx.stream, p);
+        hipLaunchKernelGGL(pack_input_kernel, dim3(pack_grid(H * W), B), dim3(256), 0, ctx.stream, p);
         check_launch("pack_input(lbl)");
     }
     encode(ctx, lbl_enc, x_lbl, B, cp_lbl, raw_lbl, tar_fea, 0);

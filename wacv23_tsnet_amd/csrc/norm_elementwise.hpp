@@ -354,18 +354,19 @@ struct PackArgs {
     int S, B, H, W, L, nimg, Cp;
     unsigned short* out3;  // null, or bf16x3 planes of the packed input
     float img_div[8];      // per source: 255 (set_test_input's /255, TSNet.py:286) or 1 (use_prev: a frame already in [0,1], TSNet.py:269-276)
-    unsigned* amax_out;    // null, or where to publish max |packed value| (float bits; operand scale of the fp16 x 2 stem convolution)
+    unsigned* amax_out;    // null, or amax_out[image] <- max |packed value| of that image (float bits; operand scale of the fp16 x 2 stem)
 };
 
+// grid = (blocks per image, S * B images)
 __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
     const size_t HW = (size_t)a.H * a.W;
     const size_t total = (size_t)a.S * a.B * HW;
     const int creal = a.nimg + a.L + (a.coords ? 3 : 0);
+    const int n = blockIdx.y;
+    const int s = n / a.B, b = n - s * a.B;
     float vmax = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t pix = i % HW;
-        const int n = (int)(i / HW);
-        const int s = n / a.B, b = n - s * a.B;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < HW; pix += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = (size_t)n * HW + pix;
         float* o = a.out + i * a.Cp;
         for (int c0 = 0; c0 < a.Cp; c0 += 4) {
             float v[4];
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
             if (a.out3) split3_store_at(v4, a.out3, total * a.Cp, i * a.Cp + c0);
         }
     }
-    if (a.amax_out) tsnet_publish_amax(a.amax_out, vmax);      // wave-uniform branch: every thread of the workgroup arrives
+    if (a.amax_out) tsnet_publish_amax(a.amax_out + n, vmax);      // per image; block-uniform branch: every thread of the workgroup arrives
 }
 
 // ---------------------------------------------------------------------------------------------
