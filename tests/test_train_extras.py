@@ -102,7 +102,7 @@ def test_pose_train_extras_through_the_model_shell():
     m.forward()
     torch.cuda.synchronize()
     assert abs(float(m.loss_warp) - meta["loss_warp"]) <= 1e-4 and m.loss_align is None
-    bg = torch.tensor([-x / 255.0 for x in cfg.mean], dtype=torch.float32)
+    bg = (-torch.tensor(cfg.mean, dtype=torch.float32)) / 255.0            # float32 division, as torch.from_numpy(-mean) / 255.0 (TSNet_pose.py:276)
     for i in range(2):
         w = m.warp_src_img_list[i].cpu()
         assert np.abs(w[:, :, 96:160, 96:160].numpy() - z[f"warp{i}_crop"]).max() <= 2e-4
