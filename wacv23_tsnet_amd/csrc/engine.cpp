@@ -850,15 +850,21 @@ void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* bet
 
 // RGB head: head_conv2_kernel (weights in LDS, two pixels per thread); TSNET_HEAD=1 selects the first-generation kernel (A/B switch)
 void launch_head(const HeadArgs& ha, int hh, int ww, int B, hipStream_t s) {
-    static const bool old_head = [] { const char* e = getenv("TSNET_HEAD"); return e && atoi(e) == 1; }();
-    if (old_head) {
+    // TSNET_HEAD: 1 = first form (one pixel per thread, scalar weights), 2 = second (two pixels, weights in LDS), default = third
+    static const int form = [] { const char* e = getenv("TSNET_HEAD"); return e ? atoi(e) : 3; }();
+    if (form == 1) {
         const int tiles = ((ww + kHeadT - 1) / kHeadT) * ((hh + kHeadT - 1) / kHeadT);
         hipLaunchKernelGGL(head_conv_kernel, dim3(tiles, B), dim3(256), 0, s, ha);
-    } else {
+    } else if (form == 2 || ha.C % (2 * kHead3Ch) != 0) {
         const int tiles = ((ww + kHead2W - 1) / kHead2W) * ((hh + kHead2H - 1) / kHead2H);
         const size_t lds = (size_t)((kHeadCh / 4) * kHead2Rows * kHead2Pitch + 49 * kHeadCh) * sizeof(float4);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_conv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(head_conv2_kernel, dim3(tiles, B), dim3(256), lds, s, ha);
+    } else {
+        const int tiles = ((ww + kHead3T - 1) / kHead3T) * ((hh + kHead3T - 1) / kHead3T);
+        const size_t lds = (size_t)(2 * (kHead3PatchF4 + kHead3WtsF4) + ha.C / 2) * sizeof(float4);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_conv3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(head_conv3_kernel, dim3(tiles, B), dim3(512), lds, s, ha);
     }
     check_launch("head_conv");
 }

@@ -179,6 +179,194 @@ __global__ __launch_bounds__(256) void head_conv2_kernel(HeadArgs a) {
 }
 
 // OIHW (3, C, 7, 7) -> [tap][cin][4]
+// Third form.  head_conv2 is bound by LDS bandwidth, not by the VALU: every (pixel, tap) re-reads its 64 channels from LDS
+// (262144 px x 4 images x 49 taps x 256 B = 13.2 GB per forward = 168 us at 128 B/clk/CU; measured 177 us).  Here
+//   * every thread owns FOUR horizontally adjacent output pixels: per (tap row, channel quad) it reads 4 + 6 pixel quads once and
+//     slides the seven horizontal taps over them in registers -- 10 LDS reads where 28 were needed -- and the (wave-uniform,
+//     broadcast) weight reads are shared by four pixels instead of two; weights are stored as (r x 4 ch, g x 4 ch, b x 4 ch): three
+//     16-byte reads per (tap, quad) instead of four;
+//   * the patch columns are de-interleaved modulo 4 ([row][column phase][slot]) so the eight threads of a row read consecutive
+//     slots, and the row pitch (40 slots = 640 B = 128 mod 256) puts the two rows of a 16-lane group on disjoint banks;
+//   * 32 x 32 output tile, 8 channels per stage and half (48.6 KB patch + 4.7 KB weights each), 1.41x halo over-fetch.
+// Two fmaf chains per output and 8-channel stage (even / odd channels, 196 products each: tap row, quad, tap column), added and folded
+// into the running total.
+#ifdef TSNET_UNIFORM
+#define HEAD_UNIFORM(x) TSNET_UNIFORM(x)
+#else
+#define HEAD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+typedef float head_f2 __attribute__((ext_vector_type(2)));
+typedef float head_f4 __attribute__((ext_vector_type(4)));
+constexpr int kHead3T = 32, kHead3P = kHead3T + 6, kHead3Slots = 10, kHead3Ch = 8;
+constexpr int kHead3PatchF4 = (kHead3Ch / 4) * kHead3P * 4 * kHead3Slots;       // float4 entries of the patch
+constexpr int kHead3WtsF4 = 49 * (kHead3Ch / 4) * 3;
+
+__global__ __launch_bounds__(512, 1) void head_conv3_kernel(HeadArgs a) {
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    // 512 threads = two halves of four waves.  Both halves own the same 32 x 32 pixels; half h takes the channel stages h, h + 2, ... through
+    // its own patch / weight region and the two partial sums are added at the end (half 0 + half 1, a fixed order).  At B = 4 the head is
+    // only 256 tiles: splitting the channels is what puts two waves on every SIMD, and it halves the number of barrier-separated stages.
+    const int half = HEAD_UNIFORM((int)(threadIdx.x >> 8));           // wave-uniform: region bases stay scalar
+    float4* tile = reinterpret_cast<float4*>(smem_raw) + half * (kHead3PatchF4 + kHead3WtsF4);      // [quad][38 rows][4 column phases][10 slots]
+    float4* wts = tile + kHead3PatchF4;                                 // [49 taps][quad][r, g, b] x 4 channels
+    float4* abt = reinterpret_cast<float4*>(smem_raw) + 2 * (kHead3PatchF4 + kHead3WtsF4);          // (alpha, beta) of the image: [C/4] alpha quads, [C/4] beta quads
+    const int tid = threadIdx.x & 255;
+    const int tx = tid & 7, ty = tid >> 3;
+    const int tiles_x = (a.W + kHead3T - 1) / kHead3T;
+    const int n = blockIdx.y;
+    const int bx = (blockIdx.x % tiles_x) * kHead3T, by = (blockIdx.x / tiles_x) * kHead3T;
+    if (a.alpha) {                                                      // once per workgroup: a global load per stage would sit on the critical path
+        for (int i = threadIdx.x; i < a.C / 2; i += 512)
+            abt[i] = *reinterpret_cast<const float4*>((i < a.C / 4 ? a.alpha : a.beta - a.C) + (size_t)n * a.C + i * 4);
+        __syncthreads();
+    }
+    float tot[4][3];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { tot[p][0] = 0.f; tot[p][1] = 0.f; tot[p][2] = 0.f; }
+    // Staging geometry, fixed over the channel stages: this thread's (up to 12) patch entries and (up to 2) weight entries.  The loads of
+    // stage s + 1 are issued before the FMAs of stage s and held in registers (one wave per SIMD: nothing else would cover their latency).
+    constexpr int NPE = ((kHead3Ch / 4) * kHead3P * kHead3P + 255) / 256;       // 12
+    constexpr int NWE = (kHead3WtsF4 + 255) / 256;                               // 2
+    unsigned src_off[NPE];
+#pragma unroll
+    for (int e = 0; e < NPE; ++e) {
+        const int i = tid + e * 256;
+        const bool ok = i < (kHead3Ch / 4) * kHead3P * kHead3P;
+        const int q = ok ? i / (kHead3P * kHead3P) : 0, p = ok ? i - q * (kHead3P * kHead3P) : 0;
+        const int py = p / kHead3P, px = p - py * kHead3P;
+        int iy = by + py - 3, ix = bx + px - 3;
+        iy = iy < 0 ? -iy : iy; iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+        ix = ix < 0 ? -ix : ix; ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+        iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);           // tiles hanging over the edge: any valid address
+        ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+        src_off[e] = (unsigned)((((size_t)n * a.H + iy) * a.W + ix) * a.C + q * 4);
+    }
+    unsigned wsrc[NWE];
+#pragma unroll
+    for (int e = 0; e < NWE; ++e) {
+        const int i = tid + e * 256;
+        const int ii = i < kHead3WtsF4 ? i : 0;
+        const int col = ii % 3, tq = ii / 3, q = tq % (kHead3Ch / 4), tap = tq / (kHead3Ch / 4);
+        wsrc[e] = (unsigned)((tap * a.C + q * 4) * 4 + col);    // [tap][cin][4]: component `col` of four channels (+ c0 * 4 per stage)
+    }
+    float4 sreg[NPE], wreg[NWE];
+    auto stage_load = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < NPE; ++e) sreg[e] = *reinterpret_cast<const float4*>(a.x + src_off[e] + c0);
+#pragma unroll
+        for (int e = 0; e < NWE; ++e) {
+            const float* src = a.w + wsrc[e] + c0 * 4;
+            wreg[e] = make_float4(src[0], src[4], src[8], src[12]);
+        }
+    };
+    auto stage_store = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < NPE; ++e) {
+            float4 v = sreg[e];
+            if (a.alpha) {
+                const int c = c0 + (e * 256 + tid >= kHead3P * kHead3P ? 4 : 0);         // entries are quad-major: quad 1 starts at 38 * 38
+                const float4 al = abt[c >> 2], be = abt[(a.C + c) >> 2];
+                v.x = __builtin_fmaf(v.x, al.x, be.x); v.y = __builtin_fmaf(v.y, al.y, be.y);
+                v.z = __builtin_fmaf(v.z, al.z, be.z); v.w = __builtin_fmaf(v.w, al.w, be.w);
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            }
+            const int i = tid + e * 256;                            // recomputed, not kept: registers are the scarce resource here
+            if (i < (kHead3Ch / 4) * kHead3P * kHead3P) {
+                const int q = i / (kHead3P * kHead3P), p = i - q * (kHead3P * kHead3P);
+                const int py = p / kHead3P, px = p - py * kHead3P;
+                tile[((q * kHead3P + py) * 4 + (px & 3)) * kHead3Slots + (px >> 2)] = v;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NWE; ++e)
+            if (tid + e * 256 < kHead3WtsF4) wts[tid + e * 256] = wreg[e];
+    };
+    static_assert(kHead3Ch / 4 == 2, "stage_store: two channel quads per stage");
+    const int nst = a.C / kHead3Ch;                                     // stages: an even number (C % 16 == 0, checked by the launcher)
+    stage_load(half * kHead3Ch);
+    for (int stg = half; stg < nst; stg += 2) {
+        const int c0 = stg * kHead3Ch;
+        stage_store(c0);
+        __syncthreads();
+        if (stg + 2 < nst) stage_load(c0 + 2 * kHead3Ch);
+        // Packed fp32 FMAs (v_pk_fma_f32: two lanes per instruction) want register PAIRS as operands.  The natural pairs here are two
+        // adjacent channels: (x.c, x.c+1) of a pixel quad and (w.c, w.c+1) of one output's weight quad are adjacent registers of their
+        // 16-byte loads, so each output keeps an (even-channel, odd-channel) pair of partial sums and no operand needs a move.
+        head_f2 acc[4][3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) acc[p][o] = head_f2{0.f, 0.f};
+        // 98 steps (tap row, quad, tap column) of 24 packed FMAs.  At B = 4 the whole head is 1024 waves -- ONE per SIMD -- so nothing but
+        // this wave's own instruction stream hides the LDS latency: the pixel quads of the next (tap row, quad) and the weights two steps
+        // ahead are requested before the current step's FMAs (register double / triple buffers, scheduling fences keep the order).
+        head_f4 pxb[2][10], wb[3][3];
+        auto load_px = [&](int buf, int it) __attribute__((always_inline)) {
+            const head_f4* row = reinterpret_cast<const head_f4*>(tile + (((it & 1) * kHead3P + ty + (it >> 1)) * 4) * kHead3Slots + tx);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) pxb[buf][j] = row[(j & 3) * kHead3Slots + (j >> 2)];      // patch column 4 tx + j
+        };
+        auto load_w = [&](int buf, int st) __attribute__((always_inline)) {
+            const int it = st / 7, kx = st - it * 7;
+            const head_f4* wt = reinterpret_cast<const head_f4*>(wts + (((it >> 1) * 7 + kx) * (kHead3Ch / 4) + (it & 1)) * 3);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) wb[buf][o] = wt[o];
+        };
+        static_assert(kHead3Ch == 8, "step index = (tap row * 2 + quad) * 7 + tap column");
+        load_px(0, 0);
+        load_w(0, 0);
+        load_w(1, 1);
+#pragma unroll
+        for (int st = 0; st < 98; ++st) {
+            const int it = st / 7, kx = st - it * 7;
+            if (st + 2 < 98) load_w((st + 2) % 3, st + 2);
+            if (kx == 0 && it + 1 < 14) load_px((it + 1) & 1, it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const head_f4 w = wb[st % 3][o];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const head_f4 v = pxb[it & 1][p + kx];
+                    acc[p][o] = __builtin_elementwise_fma(v.xy, w.xy, acc[p][o]);
+                    acc[p][o] = __builtin_elementwise_fma(v.zw, w.zw, acc[p][o]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { tot[p][0] += acc[p][0].x + acc[p][0].y; tot[p][1] += acc[p][1].x + acc[p][1].y; tot[p][2] += acc[p][2].x + acc[p][2].y; }
+        __syncthreads();
+    }
+    // half 1 hands its sums over through LDS (its own patch region is free after the last barrier)
+    float* xch = reinterpret_cast<float*>(reinterpret_cast<float4*>(smem_raw) + (kHead3PatchF4 + kHead3WtsF4));
+    if (half == 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) xch[(p * 3 + o) * 256 + tid] = tot[p][o];
+    }
+    __syncthreads();
+    if (half == 1) return;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) tot[p][o] += xch[(p * 3 + o) * 256 + tid];
+    const size_t hw = (size_t)a.H * a.W;
+    const int oy = by + ty;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int ox = bx + 4 * tx + p;
+        if (ox < a.W && oy < a.H) {
+            float o[3] = {tanhf(tot[p][0] + a.bias[0]), tanhf(tot[p][1] + a.bias[1]), tanhf(tot[p][2] + a.bias[2])};
+            if (a.composite && (ox < a.fore_x0 || ox >= a.fore_x1)) { o[0] = a.bg[0]; o[1] = a.bg[1]; o[2] = a.bg[2]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.y[((size_t)n * 3 + c) * hw + (size_t)oy * a.W + ox] = o[c];
+        }
+    }
+}
+
 __global__ void pack_head_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int C) {
     const int total = 49 * C * 4;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
