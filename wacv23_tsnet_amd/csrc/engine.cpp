@@ -133,6 +133,9 @@ inline int ew_grid(size_t total, int block = 256) {
     return (int)g;
 }
 
+void launch_finalize_impl(const double* part, float* alpha, float* beta, int N, int C, int S, int HW, hipStream_t s);
+inline void launch_finalize(const double* part, float* alpha, float* beta, int N, int C, int S, int HW, hipStream_t s) { launch_finalize_impl(part, alpha, beta, N, C, S, HW, s); }
+
 // pack_input_kernel: grid.x blocks per image (grid.y = images), sized so the whole grid stays near 8 blocks per CU
 inline int pack_grid(int hw) {
     int g = (hw + 255) / 256;
@@ -793,8 +796,18 @@ void run_stats(Ctx& ctx, const float* x, int N, int HW, int C, double* part, flo
     StatsArgs sa{x, part, HW, C, S, rps};
     hipLaunchKernelGGL(in_stats_partial_kernel, dim3(S, N, (cq + 255) / 256), dim3(256), 0, ctx.stream, sa);
     check_launch("in_stats_partial");
-    const int NC = N * C;
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, ctx.stream, part, alpha, beta, NC, C, S, HW, 1e-5f);
+    launch_finalize(part, alpha, beta, N, C, S, HW, ctx.stream);
+}
+
+// stage 2 of the statistics: with more than a handful of partials per image the 16-group kernel (one serial walk per (image, channel)
+// is latency-bound: 39 us for the 64 partials of the FuseNet join)
+void launch_finalize_impl(const double* part, float* alpha, float* beta, int N, int C, int S, int HW, hipStream_t s) {
+    if (S > 8) {
+        hipLaunchKernelGGL(in_finalize2_kernel, dim3((C + kFin2Ch - 1) / kFin2Ch, N), dim3(256), 0, s, part, alpha, beta, C, S, HW, 1e-5f);
+    } else {
+        const int NC = N * C;
+        hipLaunchKernelGGL(in_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, s, part, alpha, beta, NC, C, S, HW, 1e-5f);
+    }
     check_launch("in_finalize");
 }
 
@@ -803,7 +816,7 @@ void run_stats(Ctx& ctx, const float* x, int N, int HW, int C, double* part, flo
 void finish_stats(Ctx& ctx, const ConvCall& c, const float* y, int N, int HW, int C, double* part, float* alpha, float* beta) {
     if (c.stat_S <= 0) { run_stats(ctx, y, N, HW, C, part, alpha, beta); return; }
     TimeScope ts(ctx, TSNET_T_STATS);
-    hipLaunchKernelGGL(in_finalize2_kernel, dim3((C + 63) / 64, N), dim3(256), 0, ctx.stream, part, alpha, beta, C, c.stat_S, HW, 1e-5f);
+    hipLaunchKernelGGL(in_finalize2_kernel, dim3((C + kFin2Ch - 1) / kFin2Ch, N), dim3(256), 0, ctx.stream, part, alpha, beta, C, c.stat_S, HW, 1e-5f);
     check_launch("in_finalize2");
 }
 
@@ -820,9 +833,7 @@ void run_add_stats(Ctx& ctx, const float* x, const float* add, int add_nmod, flo
     AddStatsArgs sa{x, add, y, part, HW, C, S, rps, add_nmod > 0 ? add_nmod : 1};
     hipLaunchKernelGGL(add_stats_partial_kernel, dim3(S, N, (cq + 255) / 256), dim3(256), 0, ctx.stream, sa);
     check_launch("add_stats_partial");
-    const int NC = N * C;
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, ctx.stream, part, alpha, beta, NC, C, S, HW, 1e-5f);
-    check_launch("in_finalize");
+    launch_finalize(part, alpha, beta, N, C, S, HW, ctx.stream);
 }
 
 void run_norm_act(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, const float* resid,
@@ -1048,7 +1059,7 @@ struct tsnet_engine {
         if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
         if (c.stat_S > 0) {
             TimeScope ts(ctx, TSNET_T_STATS);
-            hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + 63) / 64, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
+            hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + kFin2Ch - 1) / kFin2Ch, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
             check_launch("in_finalize2");
         } else {
             run_stats(ctx, c.y, N, HW, L.cout, pt, alpha, beta);
@@ -1062,7 +1073,7 @@ struct tsnet_engine {
         else rh2(ctx, L, c);
         if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
         TimeScope ts(ctx, TSNET_T_STATS);
-        hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + 63) / 64, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
+        hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + kFin2Ch - 1) / kFin2Ch, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
         check_launch("in_finalize2");
     }
     // ResnetBlock on the h2 schedule.  stream_bound > 0: the residual stream Xs has an a-priori bound (encoder: (blocks+1) sqrt(HW));

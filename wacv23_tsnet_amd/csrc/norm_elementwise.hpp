@@ -151,15 +151,17 @@ __global__ void in_finalize_kernel(const double* __restrict__ part, float* __res
 }
 
 // stage 2 for many partials (conv-epilogue statistics: S = tiles per image, up to 1024):
-// block = (image n, 64 channels); 4 thread groups split the S partials, fixed-order LDS combine.
+// block = (image n, 16 channels); 16 thread groups split the S partials (group g takes s = g, g + 16, ...), fixed-order LDS combine.
+// (Four groups of 64 channels left 12 workgroups walking 128 dependent additions each on the 7 x 7 stem: 16 us of latency per launch.)
+constexpr int kFin2Ch = 16, kFin2Groups = 16;
 __global__ __launch_bounds__(256) void in_finalize2_kernel(const double* __restrict__ part, float* __restrict__ alpha,
                                                             float* __restrict__ beta, int C, int S, int HW, float eps) {
     __shared__ double red[256 * 2];
-    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int n = blockIdx.y, cl = threadIdx.x & (kFin2Ch - 1), c = blockIdx.x * kFin2Ch + cl, g = threadIdx.x / kFin2Ch;
     double sm = 0, sq = 0;
     if (c < C) {
 #pragma unroll 8
-        for (int s = g; s < S; s += 4) {      // unrolled: the loads of 8 partials are in flight together, the additions stay in order
+        for (int s = g; s < S; s += kFin2Groups) {      // unrolled: the loads of 8 partials are in flight together, the additions stay in order
             const double* p = part + (((size_t)n * S + s) * C + c) * 2;
             sm += p[0];
             sq += p[1];
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void in_finalize2_kernel(const double* __restr
     red[threadIdx.x * 2] = sm; red[threadIdx.x * 2 + 1] = sq;
     __syncthreads();
     if (g == 0 && c < C) {
-        for (int k = 1; k < 4; ++k) { sm += red[(k * 64 + threadIdx.x) * 2]; sq += red[(k * 64 + threadIdx.x) * 2 + 1]; }
+        for (int k = 1; k < kFin2Groups; ++k) { sm += red[(k * kFin2Ch + cl) * 2]; sq += red[(k * kFin2Ch + cl) * 2 + 1]; }
         const double mean = sm / HW;
         double var = sq / HW - mean * mean;
         if (var < 0) var = 0;
