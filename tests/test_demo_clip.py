@@ -44,3 +44,45 @@ def test_clip_harness_equals_one_shot_forward(tmp_path):
     model.forward()
     want = runner.post(model.rec_tar_img)[0].cpu().numpy()
     assert np.array_equal(frames[1], want)
+
+
+def test_pose_clip_harness_equals_one_shot_forward(tmp_path):
+    """The same for the pose model (demo/demo_pose.py:110-247): OpenPose-format points -> skeleton labels on the device
+    (raster.PoseRasteriser) -> TSNetPose in clip mode; the labels equal the oracle's on the synthetic frames, the frames equal the
+    one-shot forward's, and the background columns carry the fixed composite colour."""
+    import demo_pose_clip
+    from oracle import raster_pose_oracle as PO
+    from wacv23_tsnet_amd import demo, raster
+    from wacv23_tsnet_amd.model import TSNetPose
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    kw = dict(is_train=False, label_nc=25, n_blocks=1, n_downsampling=3, n_source=3)
+    model = TSNetPose(**kw)
+    ckpt = {net: getattr(model, net).state_dict() for net in ("img_enc", "lbl_enc", "dec", "fuse_net")}
+    torch.save(ckpt, tmp_path / "TSNet_pose.pth")
+    model.load_checkpoint(torch.load(tmp_path / "TSNet_pose.pth", map_location="cpu"))
+    model = model.cuda()
+    K, F = 3, 2
+    pts = demo_pose_clip.synthetic_dancer(K + F)
+    pr, fr = raster.PoseRasteriser(dev), raster.FaceRasteriser(dev)
+    cls, box, crop = pr.clip_labels(list(pts), size=(1920, 1080))
+    # the device labels against the oracle's chain (generic coordinates: equal, see tests/test_raster_pose.py)
+    want_crop = PO.crop_coords(pts[0][:25], (1920, 1080))[0]
+    assert list(crop) == want_crop
+    for f in (0, K + F - 1):
+        full = PO.skeleton_classes(pts[f], (1920, 1080))[crop[1]:crop[3], crop[0]:crop[2]]
+        assert np.array_equal(cls[f].cpu().numpy(), PO.resize_square(full).astype(np.float32))
+        assert np.array_equal(box[f].cpu().numpy(), (PO.resize_square(PO.label_bbox(full)) != 0).astype(np.float32))
+    lbl = fr.vl2ch(cls, 25)
+    assert lbl.shape == (K + F, 25, 256, 256) and torch.equal(lbl.sum(dim=1), torch.ones_like(lbl[:, 0]))
+    assert len(torch.unique(cls)) == 25                                          # every limb, finger and the face are on the label
+    g = torch.Generator().manual_seed(1)
+    src_img = [(torch.rand((1, 3, 256, 256), generator=g) * 255.0 - torch.from_numpy(demo.IMG_MEAN).view(1, 3, 1, 1)) for _ in range(K)]
+    runner = demo.ClipRunner(model, src_img, [lbl[i:i + 1] for i in range(K)], [box[i:i + 1] for i in range(K)])
+    frames = runner.run(lbl[K:], box[K:], out_dir=str(tmp_path / "out"), name="p")
+    assert frames.shape == (F, 256, 256, 3) and frames.dtype == np.uint8
+    model.set_test_input([x for x in src_img], [lbl[i:i + 1] for i in range(K)], [box[i:i + 1] for i in range(K)], lbl[K + 1:K + 2], box[K + 1:K + 2])
+    model.forward()
+    assert torch.equal(model.rec_tar_img[0, :, :, :64], model.rec_tar_img[0, :, :1, :1].expand(3, 256, 64))      # fixed background (TSNet_pose.py:416-417)
+    want = runner.post(model.rec_tar_img)[0].cpu().numpy()
+    assert np.array_equal(frames[1], want)

@@ -132,8 +132,8 @@ class ClipRunner:
             for i in range(out.shape[0]):
                 if tar_imgs is not None:
                     tar_rgb = input_to_rgb(tar_imgs[i])
-                else:                                               # no ground-truth driving frame: show the label map instead
-                    m = (tar_lbls[i, -1].detach().cpu().numpy() > 0).astype(np.uint8) * 255
+                else:                                               # no ground-truth driving frame: show the label map (every non-background class) instead
+                    m = (tar_lbls[i, 0].detach().cpu().numpy() == 0).astype(np.uint8) * 255
                     tar_rgb = np.repeat(m[:, :, None], 3, axis=2)
                 strips.append(save_strip(src_rgb, tar_rgb, out[i], os.path.join(out_dir, f"{i:06d}_{name}.png")))
             save_gif(strips, os.path.join(out_dir, f"{name}.gif"))
