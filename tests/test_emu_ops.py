@@ -57,6 +57,13 @@ def test_conv_h2r(emu_lib):
     assert oc.conv_h2r_case(emu_lib, "cpu", 1, 16, 8, 32, 64, 7) < 2e-6
 
 
+def test_conv_h2s_stem_patch_kernel(emu_lib):
+    """8-channel 7x7 stems on whole 4 x 32 rectangles run on the patch kernel (conv_h2.hpp h2s): reflection at all four borders (one tile
+    high / several tiles), two images, no bias"""
+    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 4, 32, 8, 64, 7) < 2e-6
+    assert oc.conv_h2r_case(emu_lib, "cpu", 2, 8, 64, 8, 64, 7, bias=False, seed=3) < 2e-6
+
+
 @pytest.mark.parametrize("C,H,W", [(8, 6, 5), (64, 16, 16), (24, 9, 3), (1024, 2, 2)])
 @pytest.mark.parametrize("relu,resid", [(True, False), (False, True)])
 def test_instnorm(emu_lib, C, H, W, relu, resid):

@@ -331,6 +331,158 @@ void conv_h2_kernel(H2Args a) {
     h2_tile<BN, WARPS_M, WARPS_N, NPROD, AFFINE, HABL>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// h2s: the 7 x 7 stems at 8 input channels (TSNet.py:66 with label_nc = 2: image 3 + label 2 + coordinates 3, or label 2 + coordinates 3
+// padded to 8) as a PATCH kernel.  As an implicit GEMM (conv_h2r, SMALL_CIN) the stem gathers 128 rows x 16 k of fp32 from L1 for every
+// k-step -- 49 taps re-read every input pixel 49 times, and with only 64 output channels there is little MFMA work per gathered byte
+// (217 us for 39.5 GFLOP).  Here the (4+6) x (32+6) x 8-channel patch of a 4 x 32 output rectangle is fetched ONCE (12 KB of fp32),
+// scaled, split into two fp16 planes of one 16-byte octet per pixel, and the 25 k-steps (two taps per 16-deep k-group, the 50th tap has
+// zero weights) read it through shifted views: no barrier and no global A traffic inside the loop.
+// A fragment of step s: lane (li, lh) supplies output pixel li of a row and k-half lh = tap 2s + lh, i.e. patch slot
+// (row + ky) * 38 + li + kx of THAT tap.  Tap 2s + 1 is one slot right of tap 2s, or -- when tap 2s is the last of its row -- 32 slots
+// on: one per-lane base, a wave-uniform tap offset and lh x delta per step.
+template <int NPROD>
+__device__ __forceinline__ void h2s_tile(const H2Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
+    constexpr int BN = 64, WARPS_M = 2, WARPS_N = 2, MT = 2, NTL = 1;
+    constexpr int NPL = NPROD == 1 ? 1 : 2;
+    constexpr int PC = kPatchCols + 6, PR = kPatchRows + 6, PP = PR * PC;       // 38 x 10 = 380 patch pixels
+    constexpr int PLANE_S = 384 * 16;                                             // one plane: a 16-byte octet per pixel slot
+    static_assert(NPROD == 1 || NPROD == 3, "one (bf16 operands) or three products");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = TSNET_UNIFORM(tid >> 6);
+    const int wrow = wave / WARPS_N;
+    const int wn0 = (wave % WARPS_N) * 32;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tcols = a.Wo / kPatchCols, tper = (a.Ho / kPatchRows) * tcols;
+    const int img = tile_m / tper, tin = tile_m - img * tper;
+    const int oy0 = (tin / tcols) * kPatchRows, ox0 = (tin % tcols) * kPatchCols;
+    float in_scale = a.in_scale, in_unscale = a.in_unscale;
+    if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax + img, a.in_bound_add, in_scale, in_unscale);
+
+    const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
+    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * 8 * 4));
+    tsnet_brsrc_t rsw[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
+
+    // ---- weight fragments first (their latency hides behind the patch staging), two steps ahead afterwards
+    const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
+    F4 af[2][NPL][MT], bf[3][NPL];
+    auto load_b = [&](int set, int kc) __attribute__((always_inline)) {           // past the end of K the descriptor returns zeros
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) bf[set][p] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0) * 32));
+    };
+    load_b(0, 0);
+    load_b(1, 1);
+
+    // ---- patch staging: thread t takes pixel slots t and t + 256 (380 in all); reflection padding resolved in the address
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int pp = tid + r * 256;
+        const int pr = pp / PC, pc = pp - pr * PC;
+        int iy = oy0 - 3 + pr, ix = ox0 - 3 + pc;
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+        const unsigned v = pp < PP ? (unsigned)((((img * a.H + iy) * a.W) + ix) * 32) : kOOB;
+        F4 x0 = TSNET_BUF_LOAD16(rsx, v, 0u), x1 = TSNET_BUF_LOAD16(rsx, v, 16u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x0.v[e] *= in_scale; x1.v[e] *= in_scale; }
+        if (pp < 384) {                                               // slots 380..383 hold zeros (never read, kept finite)
+            F4 Hh, Ll;
+            if (NPROD == 1) {
+                bf16_octet(x0, x1, Hh);
+                *reinterpret_cast<F4*>(smem_raw + pp * 16) = Hh;
+            } else {
+                split_h2_octet(x0, x1, Hh, Ll);
+                *reinterpret_cast<F4*>(smem_raw + pp * 16) = Hh;
+                *reinterpret_cast<F4*>(smem_raw + PLANE_S + pp * 16) = Ll;
+            }
+        }
+    }
+    __syncthreads();
+
+    // per-lane address of step st: slot of tap 2 st for lh = 0; for lh = 1 the next tap = one slot right, or the first slot of the next patch
+    // row when tap 2 st ends its row, or (last step: the 50th tap does not exist, its weights are zero) the same slot again
+    const int base = (wrow * MT * PC + li) * 16;
+    auto load_a = [&](int set, int st) __attribute__((always_inline)) {
+        const int t0 = 2 * st, ky = t0 / 7, kx = t0 - ky * 7;        // wave-uniform
+        const int delta = st >= 24 ? 0 : (kx == 6 ? (PC - 6) * 16 : 16);
+        const unsigned char* b = smem_raw + base + (ky * PC + kx) * 16 + lh * delta;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) af[set][p][i] = *reinterpret_cast<const F4*>(b + p * PLANE_S + i * PC * 16);
+    };
+
+    f32x16 acc[MT], tot[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; tot[i][0][r] = 0.f; }
+    auto product = [&](int sa, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            f32x16 c = acc[i];
+            if (fresh) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+            }
+            if (NPROD == 1) acc[i] = TSNET_MFMA_BF16(af[sa][pa][i], bf[sb][pb], c);
+            else acc[i] = TSNET_MFMA_F16(af[sa][pa][i], bf[sb][pb], c);
+        }
+    };
+    // step st = 6 c + j: A(st) in set j & 1, B(st) in set j % 3 (six steps per chain keep both rotations static); issues A(st + 1), B(st + 2) first
+    auto step = [&](int st, int j) __attribute__((always_inline)) {
+        load_b((j + 2) % 3, st + 2);
+        load_a((j + 1) & 1, st + 1 < 25 ? st + 1 : 24);
+        const int SA = j & 1, SB = j % 3;
+        if (NPROD == 1) {
+            product(SA, SB, 0, 0, j == 0);
+        } else {
+            product(SA, SB, 1, 0, j == 0);                            // lo * hi
+            product(SA, SB, 0, 1, false);                             // hi * lo
+            product(SA, SB, 0, 0, false);                             // hi * hi
+        }
+    };
+    auto fold = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) tot[i][0] += acc[i];
+    };
+    load_a(0, 0);
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {                                     // four chains of six k-groups, then the 25th
+        const int s0 = 6 * c;
+        step(s0, 0); step(s0 + 1, 1); step(s0 + 2, 2); step(s0 + 3, 3); step(s0 + 4, 4); step(s0 + 5, 5);
+        fold();
+    }
+    step(24, 0);
+    fold();
+
+    const float unscale = a.w_unscale ? in_unscale * a.w_unscale[0] : in_unscale;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][0][r] *= unscale;                     // exact: power of two
+    const int m_img = img * a.Ho * a.Wo;
+    __syncthreads();                                                  // the epilogue reuses the patch region for its reduction
+    x3_epilogue<BN, WARPS_M, WARPS_N, MT, NTL>(a, tot, smem_raw, tid, wave, n0, (size_t)img * tper + tin,
+                                               [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 3)
+void conv_h2s_kernel(H2Args a) {
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
+    const int tile_m = bid / a.tiles_n;
+    h2s_tile<NPROD>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * 64);
+}
+
 // OIHW fp32 -> two fp16 planes of w * scale in the fragment order of pack_weights_x3_kernel:
 //   out[p][((kc*Npad + n)*2 + o)*8 + e] = part_p( scale * W[k = kc*16 + (o ^ ((n>>3)&1))*8 + e][n] ),  k = tap*cin_pad + c
 __global__ void pack_weights_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, float scale,

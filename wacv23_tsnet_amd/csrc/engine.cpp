@@ -692,7 +692,14 @@ void run_conv_h2r(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
     g.fin_counter = (c.stat_part && c.fin_counter && hw / 128 <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= kFinCounterInts) ? c.fin_counter : nullptr;
     TimeScope ts(ctx, c.tclass);
     if (c.nprod != 1 && c.nprod != 3) throw ArgError("conv(h2r): 1 (bf16 operands) or 3 products");
-    if (L.ks == 7) {
+    static const bool stem_patch = [] { const char* e = getenv("TSNET_H2S"); return !e || atoi(e) != 0; }();
+    if (L.ks == 7 && g.Cin == 8 && !c.alpha && stem_patch && g.Ho % kPatchRows == 0 && g.Wo % kPatchCols == 0 && c.H >= 4 && c.W >= 4) {
+        // 8-channel stem on whole 4 x 32 rectangles: the patch kernel (conv_h2.hpp h2s) -- same packed weights, same arithmetic, no im2col gather
+        const size_t lds = 2 * 2 * 7168 + 2048;
+        const H2Args& b = g;
+        if (c.nprod == 3) hipLaunchKernelGGL((conv_h2s_kernel<3>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, ctx.stream, b);
+        else hipLaunchKernelGGL((conv_h2s_kernel<1>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, ctx.stream, b);
+    } else if (L.ks == 7) {
         if (bn != 64) throw ArgError("conv(h2r): the 7x7 stems run on 64-wide tiles");
         if (c.nprod == 3) launch_h2r<7, 64, 3>(g, ctx.stream); else launch_h2r<7, 64, 1>(g, ctx.stream);
     } else if (c.nprod == 3) { if (bn == 64) launch_h2r<3, 64, 3>(g, ctx.stream); else launch_h2r<3, 128, 3>(g, ctx.stream); }
