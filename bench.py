@@ -56,10 +56,16 @@ def _pmc_traffic_bytes(kernel_prefix: str):
     rocprofv3 on itself; None when the table is absent."""
     path = os.path.join(ROOT, "profiles", "round2_pmc_summary.txt")
     try:
+        tot, n = 0.0, 0          # launch-weighted mean over the template variants of the kernel (raw input / fused InstanceNorm + ReLU)
         for line in open(path):
             if line.startswith(kernel_prefix):
                 f = line.split()
-                return int((float(f[-2]) + float(f[-1])) * 2**20), os.path.relpath(path, ROOT)
+                tot += (float(f[-2]) + float(f[-1])) * int(f[-4])
+                n += int(f[-4])
+            elif n and not line.strip():
+                break                # the byte table ends at the first blank line
+        if n:
+            return int(tot / n * 2**20), os.path.relpath(path, ROOT)
     except Exception:
         pass
     return None, None
