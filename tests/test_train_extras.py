@@ -74,7 +74,7 @@ def test_train_extras_emulated(emu_lib):
 
 def test_pose_train_extras_emulated(emu_lib):
     """Pose model (256 x 256 only: the composite's columns are fixed, TSNet_pose.py:277-280), narrow channels."""
-    cfg = O.TSNetConfig(label_nc=25, n_blocks=0, n_source=2, ngf=8, enc_blocks=0, fuse_ngf=128, pose=True)
+    cfg = O.TSNetConfig(label_nc=25, n_blocks=0, n_source=1, ngf=8, enc_blocks=0, fuse_ngf=128, pose=True)
     sd = O.synth_state_dict(cfg, seed=5, bias_std=0.02)
     sd = {k: (v * 3 if k.endswith("weight") else v) for k, v in sd.items()}
     inp = O.synth_inputs(cfg, 1, 256, 256, seed=6, mask_mode="box")
