@@ -44,6 +44,7 @@ def test_conv_h2(emu_lib, norm, reflect):
 
 def test_conv_h2_wide_tile_and_scales(emu_lib):
     assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 64, 32, 128, True, norm=True, tile_n=128) < 2e-6
+    assert oc.conv_h2_case(emu_lib, "cpu", 1, 8, 32, 32, 96, False, norm=True, tile_n=32) < 2e-6           # small-M tiles: four waves over the four patch rows
     # operands far from 1: the power-of-two scales keep the fp16 planes in range (results relative to max|ref|)
     assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=300.0) < 2e-6
     assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=1e-4) < 2e-6

@@ -138,12 +138,12 @@ def test_conv_h2_variants(lib):
 
 
 def test_conv_h2_tile_widths_bitwise(lib):
-    """64- and 128-wide tiles of conv_h2 run the same chains per output element: the launcher's choice never changes a result"""
+    """32-, 64- and 128-wide tiles of conv_h2 run the same chains per output element: the launcher's choice never changes a result"""
     import torch
     ys = []
-    for bn in (64, 128):
+    for bn in (32, 64, 128):
         ys.append(oc.conv_h2_case(lib, DEV, 4, 32, 32, 256, 256, True, norm=True, tile_n=bn, return_output=True))
-    assert torch.equal(ys[0], ys[1])
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2])
 
 
 def test_conv_h2r_layers(lib):

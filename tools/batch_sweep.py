@@ -13,9 +13,9 @@ for B in (1, 2, 4, 8, 16, 32):
     eng.load_state_dict(sd); eng.finalize("cuda")
     inp = synth.inputs(3, 2, B, H, W, seed=1)
     si, sl, sb, tl, tb = [[t.cuda() for t in x] if isinstance(x, list) else x.cuda() for x in inp]
-    for _ in range(3): eng.forward(si, sl, sb, tl, tb)
+    for _ in range(10): eng.forward(si, sl, sb, tl, tb)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = max(3, 40 // B)
+    n = max(10, 200 // B)
     for _ in range(n): eng.forward(si, sl, sb, tl, tb)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     out[B] = {"ms": round(dt * 1e3, 3), "frames_per_s": round(B / dt, 1)}

@@ -574,8 +574,9 @@ inline int h2_scale_log2(float bound) {
 template <int BN, int NPROD>
 void launch_h2(const H2Args& a, hipStream_t s) {
     const size_t lds = 2 * 2 * 7168 + 2048 + (size_t)2 * a.Cin * 4;      // two-plane layout offsets in every mode
-    if (a.in_alpha) hipLaunchKernelGGL((conv_h2_kernel<BN, 2, 2, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_h2_kernel<BN, 2, 2, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    constexpr int WM = BN >= 64 ? 2 : 4, WN = 4 / WM;                     // 32-wide tiles: four waves stacked over the four patch rows
+    if (a.in_alpha) hipLaunchKernelGGL((conv_h2_kernel<BN, WM, WN, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_h2_kernel<BN, WM, WN, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
 }
 
 void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
@@ -606,8 +607,11 @@ void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
         const double c64 = (double)((tm * ((g.Cout + 63) / 64) + 255) / 256) * 64.0;
         const double c128 = (double)((tm * ((g.Cout + 127) / 128) + 255) / 256) * 128.0 / (c.alpha ? 1.03 : 1.10);
         bn = (g.Npad % 128 == 0 && g.Cout > 64 && c128 < c64) ? 128 : 64;
+        // small M (one driving frame: the decoder's ResnetBlocks are 64 tiles of 128 x 64 on 256 CUs): 32-wide tiles double the number of
+        // workgroups; each stages the same patch but runs half the MFMA chain, and a tile alone on its CU is latency-, not throughput-bound
+        if (bn == 64 && tm * ((g.Cout + 63) / 64) <= 192 && c.nprod != 4) bn = 32;
     }
-    if (bn != 64 && bn != 128) throw ArgError("conv(h2): tile width must be 64 or 128");
+    if (bn != 32 && bn != 64 && bn != 128) throw ArgError("conv(h2): tile width must be 32, 64 or 128");
     if (g.Npad % bn) bn = 64;
     g.tiles_m = g.M / 128; g.tiles_n = (g.Cout + bn - 1) / bn;
     const int hw = g.Ho * g.Wo;
@@ -630,9 +634,9 @@ void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
         throw ArgError("ablation variants are only built into the tools library");
 #endif
     }
-    if (c.nprod == 3) { if (bn == 64) launch_h2<64, 3>(g, ctx.stream); else launch_h2<128, 3>(g, ctx.stream); }
-    else if (c.nprod == 4) { if (bn == 64) launch_h2<64, 4>(g, ctx.stream); else launch_h2<128, 4>(g, ctx.stream); }
-    else if (c.nprod == 1) { if (bn == 64) launch_h2<64, 1>(g, ctx.stream); else launch_h2<128, 1>(g, ctx.stream); }
+    if (c.nprod == 3) { if (bn == 32) launch_h2<32, 3>(g, ctx.stream); else if (bn == 64) launch_h2<64, 3>(g, ctx.stream); else launch_h2<128, 3>(g, ctx.stream); }
+    else if (c.nprod == 4) { if (bn == 64) launch_h2<64, 4>(g, ctx.stream); else if (bn == 128) launch_h2<128, 4>(g, ctx.stream); else throw ArgError("conv(h2): four products on 64- or 128-wide tiles"); }
+    else if (c.nprod == 1) { if (bn == 32) launch_h2<32, 1>(g, ctx.stream); else if (bn == 64) launch_h2<64, 1>(g, ctx.stream); else launch_h2<128, 1>(g, ctx.stream); }
     else throw ArgError("conv(h2): 1 (bf16 operands), 3 or 4 products");
     check_launch("conv_h2");
     c.stat_S = !c.stat_part ? 0 : (g.fin_counter ? -1 : hw / 128);
