@@ -697,7 +697,7 @@ void run_conv_h2r(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
     TimeScope ts(ctx, c.tclass);
     if (c.nprod != 1 && c.nprod != 3) throw ArgError("conv(h2r): 1 (bf16 operands) or 3 products");
     static const bool stem_patch = [] { const char* e = getenv("TSNET_H2S"); return !e || atoi(e) != 0; }();
-    if (L.ks == 7 && g.Cin == 8 && !c.alpha && stem_patch && g.Ho % kPatchRows == 0 && g.Wo % kPatchCols == 0 && c.H >= 4 && c.W >= 4) {
+    if (L.ks == 7 && g.Cin == 8 && bn == 64 && !c.alpha && stem_patch && g.Ho % kPatchRows == 0 && g.Wo % kPatchCols == 0 && c.H >= 4 && c.W >= 4) {
         // 8-channel stem on whole 4 x 32 rectangles: the patch kernel (conv_h2.hpp h2s) -- same packed weights, same arithmetic, no im2col gather
         const size_t lds = 2 * 2 * 7168 + 2048;
         const H2Args& b = g;
