@@ -58,6 +58,16 @@ def test_conv_h2r(emu_lib):
     assert oc.conv_h2r_case(emu_lib, "cpu", 1, 16, 8, 32, 64, 7) < 2e-6
 
 
+def test_conv_h2d_stride2_patch_kernel(emu_lib):
+    """3x3 / stride-2 layers whose output splits into 4 x 32 rectangles run on the patch kernel (conv_h2.hpp h2d): one, two and four slabs
+    (stage parity; the entry takes power-of-two input widths; the kernel takes layers with at least 512 output channels), zero padding at
+    all borders, with and without the fused IN + ReLU, two images / two tiles"""
+    for cin in (16, 32, 64):
+        assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, cin, 512, 3, norm=True, seed=cin) < 2e-6
+    assert oc.conv_h2r_case(emu_lib, "cpu", 2, 16, 64, 32, 512, 3, norm=False, bias=False) < 2e-6
+    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 128, 16, 576, 3, norm=True) < 2e-6                 # nine N-tiles, two M-tiles
+
+
 def test_conv_h2s_stem_patch_kernel(emu_lib):
     """8-channel 7x7 stems on whole 4 x 32 rectangles run on the patch kernel (conv_h2.hpp h2s): reflection at all four borders (one tile
     high / several tiles), two images, no bias"""

@@ -483,6 +483,237 @@ void conv_h2s_kernel(H2Args a) {
     h2s_tile<NPROD>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * 64);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// h2d: the encoders' 3 x 3 / stride-2 / zero-pad-1 downsampling convolutions (TSNet.py:70) as a patch kernel -- h2_tile with the patch
+// geometry of stride 2.  A 4 x 32 output rectangle reads the (2*4+1) x (2*32+1) = 9 x 65 input patch; per 16-channel slab it is fetched once
+// (585 pixels x 64 B), transformed and split like h2_tile's, and written to LDS with its columns DE-INTERLEAVED by parity: row pitch 66
+// slots = 33 even columns, then 32 odd ones.  Output column x under tap column kx reads input column 2x + kx: kx = 0 -> even slot x,
+// kx = 1 -> odd slot x, kx = 2 -> even slot x + 1, so the 32 lanes of a fragment read 32 consecutive 16-byte slots (conflict-free) and
+// row / tap shifts are immediates, exactly as in the stride-1 kernel.  Against the implicit GEMM (conv_h2r) on these layers: half the
+// staged elements (the im2col tile holds every input element 2.25 times), no global A traffic per k-step, one barrier per slab instead of
+// one per k-step.  Five staging rounds per slab (19 blocks of 32 pixel slots over four waves), spread over the nine taps on two register
+// sets.  K order, chains and fold points are h2_tile's.
+template <int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE>
+__device__ __forceinline__ void h2d_tile(const H2Args& a, unsigned char* smem_raw, const int tile_m, const int n0) {
+    constexpr int BM = kPatchRows * kPatchCols;
+    constexpr int NW = WARPS_M * WARPS_N;
+    static_assert(NW == 4 && WARPS_M == 2, "four waves, two output rows per wave");
+    static_assert(NPROD == 1 || NPROD == 3, "one (bf16 operands) or three products");
+    constexpr int NPL = NPROD == 1 ? 1 : 2;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 32, NTL = WN / 32;
+    constexpr int PCI = 2 * kPatchCols + 1, PRI = 2 * kPatchRows + 1, PP = PRI * PCI;     // 65 x 9 = 585 patch pixels
+    constexpr int RP = 66;                                           // row pitch in slots: 33 even columns, 32 odd, 1 spare
+    constexpr int REGION = PRI * RP * 16;                            // one octet region: 594 slots x 16 B
+    constexpr int PLANE_P = 2 * REGION, PATCH_BYTES = NPL * PLANE_P;
+    constexpr int OFF_SCRATCH = 2 * 2 * PLANE_P;                     // sink of the pixel block that does not exist (fixed offsets in both modes)
+    constexpr int OFF_TAB = OFF_SCRATCH + 2048;
+    constexpr int NR = 5;                                            // staging rounds: blocks wave, wave + 4, .., wave + 16 of 32 pixels
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = TSNET_UNIFORM(tid >> 6);
+    const int wrow = wave / WARPS_N;
+    const int wn0 = (wave % WARPS_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tcols = a.Wo / kPatchCols, tper = (a.Ho / kPatchRows) * tcols;
+    const int img = tile_m / tper, tin = tile_m - img * tper;
+    const int oy0 = (tin / tcols) * kPatchRows, ox0 = (tin % tcols) * kPatchCols;
+    const int ncc = a.Cin >> 4;
+    float in_scale = a.in_scale, in_unscale = a.in_unscale;
+    if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax + img, a.in_bound_add, in_scale, in_unscale);
+
+    const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
+    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
+    tsnet_brsrc_t rsw[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
+
+    // ---- staging geometry: round r of this wave = pixel block wave + 4 r; lane -> (pixel b*32 + (lane & 31), octet lane >> 5)
+    const int oct = lane >> 5;
+    unsigned vP[NR];
+    auto slot_of = [&](int r) __attribute__((always_inline)) {       // LDS byte offset of the lane's slot inside an octet region, or -1 (sink); recomputed, not kept
+        const int pp = (wave + 4 * r) * 32 + (lane & 31);
+        const int pr = pp / PCI, pc = pp - pr * PCI;
+        return pp < PP ? (pr * RP + ((pc & 1) ? 33 + (pc >> 1) : (pc >> 1))) * 16 : -1;
+    };
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int pp = (wave + 4 * r) * 32 + (lane & 31);
+        const int pr = pp / PCI, pc = pp - pr * PCI;
+        const int iy = 2 * oy0 - 1 + pr, ix = 2 * ox0 - 1 + pc;
+        const bool inside = pp < PP;
+        const bool ok = inside && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;       // zero padding
+        vP[r] = ok ? (unsigned)(((img * a.H * a.W + iy * a.W + ix) * a.Cin + oct * 8) * 4) : kOOB;
+    }
+    float* tab = reinterpret_cast<float*>(smem_raw + OFF_TAB);       // [Cin] alpha*s, then [Cin] beta*s
+    if (AFFINE) {
+        for (int c = tid; c < a.Cin; c += 256) {
+            tab[c] = a.in_alpha[(size_t)img * a.Cin + c] * in_scale;
+            tab[a.Cin + c] = a.in_beta[(size_t)img * a.Cin + c] * in_scale;
+        }
+        __syncthreads();
+    }
+    const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();
+    F4 sx[1][2];                                                     // staging registers: one round of x in flight
+    auto stage_load_x = [&](int cn, int r, int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) sx[set][q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(cn * 64 + q * 16));
+    };
+    auto stage_store = [&](int cn, int r, int set) __attribute__((always_inline)) {
+        F4 t[2];
+        const float keep = vP[r] == kOOB ? 0.f : 1.f;               // a padded pixel is zero AFTER the transform
+        if (AFFINE) {
+            const float* ta = tab + (cn < ncc ? cn * 16 : 0) + oct * 8;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const F4 al = *reinterpret_cast<const F4*>(ta + q * 4), be = *reinterpret_cast<const F4*>(ta + a.Cin + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = __builtin_fmaf(sx[set][q].v[e], al.v[e], be.v[e]);
+                    v = v > relu_floor ? v : relu_floor;
+                    t[q].v[e] = v * keep;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = sx[set][q].v[e] * in_scale;     // a padded slot loaded zeros
+                    t[q].v[e] = v > relu_floor ? v : relu_floor;
+                }
+        }
+        const int so = slot_of(r);
+        const bool real = so >= 0;
+        unsigned char* dst = smem_raw + (real ? (cn & 1) * PATCH_BYTES + oct * REGION + so : OFF_SCRATCH + (lane & 63) * 16);
+        F4 Hh, Ll;
+        if (NPROD == 1) {
+            bf16_octet(t[0], t[1], Hh);
+            *reinterpret_cast<F4*>(dst) = Hh;
+        } else {
+            split_h2_octet(t[0], t[1], Hh, Ll);
+            *reinterpret_cast<F4*>(dst) = Hh;
+            *reinterpret_cast<F4*>(dst + (real ? PLANE_P : 1024)) = Ll;
+        }
+    };
+
+    // ---- fragments
+    const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
+    F4 af[2][NPL][MT], bf[3][NPL][NTL];
+    auto load_b = [&](int set, int cc, int t) __attribute__((always_inline)) {
+        const int kc = t * ncc + cc;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0 + j * 32) * 32));
+    };
+    const unsigned char* abase = smem_raw + lh * REGION + (2 * wrow * MT * RP + li) * 16;
+    auto load_a = [&](int set, int cc, int t) __attribute__((always_inline)) {
+        const int ky = t / 3, kx = t - ky * 3;
+        const unsigned char* pbase = abase + (cc & 1) * PATCH_BYTES;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+                af[set][p][i] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + ((2 * i + ky) * RP + (kx == 1 ? 33 : (kx >> 1))) * 16);
+    };
+
+    f32x16 acc[MT][NTL], tot[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    auto product = [&](int sa, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                f32x16 c = acc[i][j];
+                if (fresh) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                }
+                if (NPROD == 1) acc[i][j] = TSNET_MFMA_BF16(af[sa][pa][i], bf[sb][pb][j], c);
+                else acc[i][j] = TSNET_MFMA_F16(af[sa][pa][i], bf[sb][pb][j], c);
+            }
+    };
+    // staging of slab cc + 1 over the nine taps of slab cc, one round in flight at a time (registers are the scarce resource at 128-wide tiles):
+    //   round 0: load at tap 0, store at tap 1;  1: 1 -> 3;  2: 3 -> 4;  3: 4 -> 6;  4: 6 -> 8   (a store precedes the next load of its tap)
+    auto step = [&](int cc, int t, int SA) __attribute__((always_inline)) {
+        const bool fresh = t == 0 || t == 4;
+        const int t2 = (t + 2) % 9;
+        load_b(t2 % 3, cc + (t + 2 >= 9 ? 1 : 0), t2);
+        if (t < 8) load_a(SA ^ 1, cc, t + 1);
+        if (t == 1) stage_store(cc + 1, 0, 0);
+        if (t == 3) stage_store(cc + 1, 1, 0);
+        if (t == 4) stage_store(cc + 1, 2, 0);
+        if (t == 6) stage_store(cc + 1, 3, 0);
+        if (t == 0) stage_load_x(cc + 1, 0, 0);
+        if (t == 1) stage_load_x(cc + 1, 1, 0);
+        if (t == 3) stage_load_x(cc + 1, 2, 0);
+        if (t == 4) stage_load_x(cc + 1, 3, 0);
+        if (t == 6) stage_load_x(cc + 1, 4, 0);
+        const int SB = t % 3;
+        if (NPROD == 1) {
+            product(SA, SB, 0, 0, fresh);
+        } else {
+            product(SA, SB, NPL - 1, 0, fresh);                      // lo * hi
+            product(SA, SB, 0, NPL - 1, false);                      // hi * lo
+            product(SA, SB, 0, 0, false);                            // hi * hi
+        }
+        if (t == 8) stage_store(cc + 1, 4, 0);
+        if (t == 3 || t == 8) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];
+        }
+    };
+    auto slab = [&](int cc, int S0) __attribute__((always_inline)) {
+        __syncthreads();                                             // patch(cc) complete and visible; slab cc-1 fully read
+        load_a(S0, cc, 0);
+        step(cc, 0, S0); step(cc, 1, S0 ^ 1); step(cc, 2, S0);
+        step(cc, 3, S0 ^ 1); step(cc, 4, S0); step(cc, 5, S0 ^ 1);
+        step(cc, 6, S0); step(cc, 7, S0 ^ 1); step(cc, 8, S0);
+    };
+
+    // prologue: patch of slab 0, weight fragments of steps (0,0) and (0,1)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { stage_load_x(0, r, 0); stage_store(0, r, 0); }
+    load_b(0, 0, 0);
+    load_b(1, 0, 1);
+    int cc = 0;
+    for (; cc + 2 <= ncc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
+    if (cc < ncc) slab(cc, 0);
+
+    const float unscale = a.w_unscale ? in_unscale * a.w_unscale[0] : in_unscale;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[i][j][r] *= unscale;
+    const int m_img = img * a.Ho * a.Wo;
+    __syncthreads();                                                 // the epilogue reuses the patch region
+    x3_epilogue<BN, WARPS_M, WARPS_N, MT, NTL>(a, tot, smem_raw, tid, wave, n0, (size_t)img * tper + tin,
+                                               [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
+}
+
+constexpr int kH2dLds = 2 * 2 * 2 * (2 * kPatchRows + 1) * 66 * 16 + 2048;      // two stages x two planes x two octet regions + sink (+ 2 Cin floats x 2 of the table)
+
+template <int BN, int NPROD, bool AFFINE>
+__global__ __launch_bounds__(256, 2)
+void conv_h2d_kernel(H2Args a) {
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    const int bid = x3p_item(blockIdx.x, a.tiles_m * a.tiles_n);
+    const int tile_m = bid / a.tiles_n;
+    h2d_tile<BN, 2, 2, NPROD, AFFINE>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+}
+
 // OIHW fp32 -> two fp16 planes of w * scale in the fragment order of pack_weights_x3_kernel:
 //   out[p][((kc*Npad + n)*2 + o)*8 + e] = part_p( scale * W[k = kc*16 + (o ^ ((n>>3)&1))*8 + e][n] ),  k = tap*cin_pad + c
 __global__ void pack_weights_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, float scale,

@@ -663,6 +663,24 @@ void launch_h2r(const H2rArgs& a, hipStream_t s) {
     }
 }
 
+template <int BN, int NPROD>
+void launch_h2d_t(const H2Args& a, hipStream_t s) {
+    const size_t lds = kH2dLds + (size_t)2 * a.Cin * 4;
+    if (a.in_alpha) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NPROD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((conv_h2d_kernel<BN, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    } else {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NPROD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((conv_h2d_kernel<BN, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    }
+}
+
+void launch_h2d(H2Args a, int nprod, hipStream_t s) {
+    // 64-wide tiles only: at 128 the tile needs more than the 256 registers two workgroups per CU leave a wave (it spills inside the slab loop)
+    a.tiles_n = (a.Cout + 63) / 64;
+    if (nprod == 3) launch_h2d_t<64, 3>(a, s); else launch_h2d_t<64, 1>(a, s);
+}
+
 void run_conv_h2r(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
     const bool bf16 = c.nprod == 1;
     if (!h2r_layer_ok(L) || !(bf16 ? (const void*)L.w3 : (const void*)L.wh)) throw ArgError("conv(h2r): layer is not a downsampling / stem layer with packed 16-bit weights");
@@ -697,12 +715,21 @@ void run_conv_h2r(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
     TimeScope ts(ctx, c.tclass);
     if (c.nprod != 1 && c.nprod != 3) throw ArgError("conv(h2r): 1 (bf16 operands) or 3 products");
     static const bool stem_patch = [] { const char* e = getenv("TSNET_H2S"); return !e || atoi(e) != 0; }();
+    static const bool down_patch = [] { const char* e = getenv("TSNET_H2D"); return !e || atoi(e) != 0; }();
     if (L.ks == 7 && g.Cin == 8 && bn == 64 && !c.alpha && stem_patch && g.Ho % kPatchRows == 0 && g.Wo % kPatchCols == 0 && c.H >= 4 && c.W >= 4) {
         // 8-channel stem on whole 4 x 32 rectangles: the patch kernel (conv_h2.hpp h2s) -- same packed weights, same arithmetic, no im2col gather
         const size_t lds = 2 * 2 * 7168 + 2048;
         const H2Args& b = g;
         if (c.nprod == 3) hipLaunchKernelGGL((conv_h2s_kernel<3>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, ctx.stream, b);
         else hipLaunchKernelGGL((conv_h2s_kernel<1>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, ctx.stream, b);
+    } else if (L.ks == 3 && down_patch && g.Cout >= 512 && g.Ho % kPatchRows == 0 && g.Wo % kPatchCols == 0 && (g.Cin & 15) == 0 && g.Cin <= 256) {
+        // stride-2 layer on whole 4 x 32 output rectangles with at least 512 output channels (the 256 -> 512 layer, where the implicit GEMM
+        // runs 64-wide tiles at the headline batch anyway): the patch kernel (conv_h2.hpp h2d), 143 vs 167 us there.  The choice depends on
+        // the LAYER only, never on the batch: the two kernels add the K chunks in different orders, and a sample's result must not depend
+        // on how many samples run with it.  At 128-wide tiles conv_h2r stays ahead (150 / 141 us vs 170 / 150 us for the
+        // 64-wide patch kernel on the 64 -> 128 and 128 -> 256 layers) and a 128-wide patch tile does not fit the register file.  Same packed
+        // weights (chunk index kc = tap * Cin/16 + slab in both kernels; only the ORDER in which the chunks are visited differs)
+        launch_h2d(g, c.nprod, ctx.stream);
     } else if (L.ks == 7) {
         if (bn != 64) throw ArgError("conv(h2r): the 7x7 stems run on 64-wide tiles");
         if (c.nprod == 3) launch_h2r<7, 64, 3>(g, ctx.stream); else launch_h2r<7, 64, 1>(g, ctx.stream);
