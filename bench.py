@@ -75,7 +75,7 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
              width: int = W, model_kw=None, cpu_baseline: bool = True, timing_probe: bool = True, secondary: bool = False) -> dict | None:
     """Everything one rank does: replica from rank 0's weights (ONE broadcast), its own batch of independent pairs, W warm-up steps,
     K timed steps between barriers, MAX over ranks.  Returns the result line on rank 0, None elsewhere."""
-    from oracle import tsnet_oracle as O            # cpu_baseline leg + parity check only
+    from wacv23_tsnet_amd import synth
     from wacv23_tsnet_amd.dist import build_replica
     from wacv23_tsnet_amd.engine import TSNetEngine
 
@@ -83,14 +83,15 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
     cuda = dev.type == "cuda"
     kw = dict(label_nc=2, n_blocks=0, n_downsampling=3, n_source=3)
     kw.update(model_kw or {})
-    cfg = O.TSNetConfig(**{k: v for k, v in kw.items() if k in ("label_nc", "n_blocks", "n_downsampling", "n_source", "ngf", "enc_blocks", "fuse_ngf")})
     eng_kw = {k: v for k, v in kw.items() if k != "fuse_ngf"}
     eng = TSNetEngine(height=height, width=width, max_batch=batch, lib=lib, **eng_kw)
-    sd = O.synth_state_dict(cfg, seed=0) if rank == 0 else None
+    # synthetic weights (the reference's init) and inputs from the package's counter PRNG; nothing under oracle/ is touched before the
+    # cpu_baseline leg below
+    sd = synth.state_dict(eng.param_shapes(), seed=0) if rank == 0 else None
     build_replica(eng, sd, dev, src=0)
 
     # every rank gets its own batch of independent pairs (weak scaling: B fixed per GPU)
-    inputs_cpu = O.synth_inputs(cfg, batch, height, width, seed=1 + rank)
+    inputs_cpu = synth.inputs(kw["n_source"], kw["label_nc"], batch, height, width, seed=1 + rank)
     src_img, src_lbl, src_bbox, tar_lbl, tar_bbox = [[t.to(dev) for t in x] if isinstance(x, list) else x.to(dev) for x in inputs_cpu]
 
     def step():
@@ -189,6 +190,8 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
     # ---- CPU baseline beside it (rank 0, N=1 only): the oracle on the host cores, same workload
     cpu_base, max_abs_delta, delta64 = None, None, None
     if world == 1 and cpu_baseline:
+        from oracle import tsnet_oracle as O        # the checker, timed on the host cores: the only use of oracle/ in this file
+        cfg = O.TSNetConfig(**{k: v for k, v in kw.items() if k in ("label_nc", "n_blocks", "n_downsampling", "n_source", "ngf", "enc_blocks", "fuse_ngf")})
         torch.set_num_threads(_usable_cores())
         ref = O.tsnet_forward(sd, cfg, *inputs_cpu)            # warm-up; also the parity reference
         max_abs_delta = float((out.cpu() - ref["rec_tar_img"]).abs().max())
@@ -211,10 +214,9 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
     second = None
     if secondary and world == 1 and cuda:
         eng.close()
-        cfg2 = O.TSNetConfig(label_nc=2, n_blocks=4, n_downsampling=3, n_source=3)
         e2 = TSNetEngine(label_nc=2, n_blocks=4, n_downsampling=3, n_source=3, height=height, width=width, max_batch=8, operands="bf16", lib=lib)
-        build_replica(e2, O.synth_state_dict(cfg2, seed=0), dev, src=0)
-        i2 = [[t.to(dev) for t in x] if isinstance(x, list) else x.to(dev) for x in O.synth_inputs(cfg2, 8, height, width, seed=3)]
+        build_replica(e2, synth.state_dict(e2.param_shapes(), seed=0), dev, src=0)
+        i2 = [[t.to(dev) for t in x] if isinstance(x, list) else x.to(dev) for x in synth.inputs(3, 2, 8, height, width, seed=3)]
         for _ in range(5):
             e2.forward(*i2)
         sync()
