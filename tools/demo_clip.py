@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--n-blocks", type=int, default=4)
     ap.add_argument("--timing-frames", type=int, default=200)
+    ap.add_argument("--clip", default=None, help="key points of a real demo clip (demo/face_examples/labels/<clip>, stored with the raster golden "
+                    "tests/golden/g7_raster_face.npz: test114 or val024) instead of the synthetic face; the frames' pixels stay synthetic")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -70,10 +72,23 @@ def main():
 
     # ---- labels on the device: key points -> edge map / bbox at crop resolution -> 256 x 256 -> one-hot (rank 3 kernels)
     K, F = 3, args.frames
-    kp = synthetic_face_keypoints(F + K, seed=0)
+    crop_in = None
+    if args.clip:
+        import json
+        z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g7_raster_face.npz"))
+        meta = json.loads(str(z["meta"]))["clips"][args.clip]
+        kp = z[f"{args.clip}_keypoints"].copy()                   # stored relative to the clip's crop: back to frame coordinates
+        kp[:, :, 0] += meta["crop"][2]
+        kp[:, :, 1] += meta["crop"][0]
+        F = min(F, kp.shape[0] - K)
+        kp = kp[:F + K]
+    else:
+        kp = synthetic_face_keypoints(F + K, seed=0)
     rs = raster.FaceRasteriser(dev)
     t0 = time.perf_counter()
-    edges, bbox, crop, bw = rs.rasterise(list(kp))
+    edges, bbox, crop, bw = rs.rasterise(list(kp), crop_in)
+    if args.clip:
+        assert list(crop) == meta["crop"] and bw == meta["bw"]      # the crop arithmetic reproduces the reference's on the real clip
     lbl = rs.vl2ch(demo.resize_nearest(edges), 2)                  # vl2ch(label map, "face") (demo_face.py:158,164)
     box = demo.resize_nearest(bbox)
     torch.cuda.synchronize()
@@ -81,7 +96,7 @@ def main():
     g = torch.Generator().manual_seed(1)
     src_img = [(torch.rand((1, 3, 256, 256), generator=g) * 255.0 - torch.from_numpy(demo.IMG_MEAN).view(1, 3, 1, 1)) for _ in range(K)]
     runner = demo.ClipRunner(model, src_img, [lbl[i:i + 1] for i in range(K)], [box[i:i + 1] for i in range(K)])
-    frames = runner.run(lbl[K:], box[K:], out_dir=args.out, name="synthetic_face")
+    frames = runner.run(lbl[K:], box[K:], out_dir=args.out, name=args.clip or "synthetic_face")
     print(f"[demo_clip] {frames.shape[0]} frames written to {args.out} (crop {crop}, brush {bw}); rasterisation of {F + K} frames: {t_raster * 1e3:.2f} ms")
 
     # ---- the demo-shaped figure: B = 1, n_blocks = 4, K = 3, clip mode, post-processing included, frames stay on the device

@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--n-blocks", type=int, default=4)
     ap.add_argument("--timing-frames", type=int, default=200)
+    ap.add_argument("--clip", default=None, help="OpenPose points of a real demo clip (demo/dance_example/labels/<clip>, stored with the raster golden "
+                    "tests/golden/g9_raster_pose.npz: 00110 or 00164) instead of the synthetic dancer; the frames' pixels stay synthetic")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -94,10 +96,21 @@ def main():
     model = model.cuda()
 
     K, F = 3, args.frames
-    pts = synthetic_dancer(F + K)
+    size = (1920, 1080)
+    if args.clip:
+        import json
+        z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g9_raster_pose.npz"))
+        meta = json.loads(str(z["meta"]))["clips"][args.clip]
+        pts, size = z[f"{args.clip}_pts"], tuple(meta["size"])
+        F = min(F, pts.shape[0] - K)
+        pts = pts[:F + K]
+    else:
+        pts = synthetic_dancer(F + K)
     pr, fr = raster.PoseRasteriser(dev), raster.FaceRasteriser(dev)
     t0 = time.perf_counter()
-    cls, box, crop = pr.clip_labels(list(pts), size=(1920, 1080))          # (F+K,256,256) class indices / 0-1 masks on the device
+    cls, box, crop = pr.clip_labels(list(pts), size=size)                   # (F+K,256,256) class indices / 0-1 masks on the device
+    if args.clip:
+        assert list(crop) == meta["crop"]                                   # the crop arithmetic reproduces the reference's on the real clip
     lbl = fr.vl2ch(cls, 25)                                                # vl2ch(label map, "pose") (demo_pose.py:164,170)
     torch.cuda.synchronize()
     t_raster = time.perf_counter() - t0
@@ -105,7 +118,7 @@ def main():
     g = torch.Generator().manual_seed(1)
     src_img = [(torch.rand((1, 3, 256, 256), generator=g) * 255.0 - torch.from_numpy(demo.IMG_MEAN).view(1, 3, 1, 1)) for _ in range(K)]
     runner = demo.ClipRunner(model, src_img, [lbl[i:i + 1] for i in range(K)], [box[i:i + 1] for i in range(K)])
-    frames = runner.run(lbl[K:], box[K:], out_dir=args.out, name="synthetic_pose")
+    frames = runner.run(lbl[K:], box[K:], out_dir=args.out, name=args.clip or "synthetic_pose")
     print(f"[demo_pose_clip] {frames.shape[0]} frames written to {args.out} (crop {tuple(crop)}, classes present {present}); "
           f"labels of {F + K} frames from the key points: {t_raster * 1e3:.2f} ms")
 
