@@ -17,6 +17,9 @@ demo clips in demo/dance_example/labels (60 frames of 1920 x 1080 video).  Store
     bbox_crop  (F, ch, cw) bit-packed: get_bbox_image of it
     cls_256, bbox_256  (F, 256, 256): after resize((128, 256), NEAREST) + resize_square, as __getitem__ hands them to the model (:425-448)
     json0      the text of the clip's first key-point file (an input data file of the demo, for the host-side reader)
+    <mode>_pts_in / _pts_out / _cls   opposite-sex pairs (mode fm / mf): points before, points after read_pts_posenorm's limb re-scaling
+               (keypoint2img_posenorm.py:90-226), and the label drawn from them, six frames per clip
+    smooth     the clip's points after dataset/smooth_pose_keypoint.py smooth_points (five-frame moving average per point)
     pts_redraw, cls_redraw  the 'pts' path of the driving frames (:397-407, same-sex pairs: ref_pts_length = ""): the skeleton re-drawn at crop
                size from the shifted points
 
@@ -55,6 +58,12 @@ def import_reference():
     import dataset.dataset_video_pose as ds
     import utils.misc as misc
     return ds, misc
+
+
+def ds_posenorm_pts(ds, d, pts, crop, size, mode):
+    """the function get_image('pts') calls, called directly to get the re-scaled points it returns next to the image (:504-507)"""
+    from utils.keypoint2img_posenorm import read_pts_posenorm
+    return read_pts_posenorm(d.opt, pts, crop, size, d.opt.basic_point_only, d.opt.remove_face_labels, mode)
 
 
 def stack_pts(pts):
@@ -103,6 +112,32 @@ def main():
         arrays[f"{clip}_bbox_256"] = np.packbits(np.stack(bbox_256) > 0, axis=-1)
         arrays[f"{clip}_pts_redraw"] = np.stack(pts_re)
         arrays[f"{clip}_cls_redraw"] = np.stack(cls_re)
+        # opposite-sex pairs (:306-314, :397-407): read_pts_posenorm re-scales torso, shoulders, arms, legs and re-attaches the hands
+        # (keypoint2img_posenorm.py:90-226) before drawing.  Six frames per clip and direction: the points it returns and the label it draws.
+        for mode in ("fm", "mf"):
+            pin, pout, cout = [], [], []
+            for fi in range(0, len(files), 5):
+                lbl, c, pts, _ = d.get_image(A_path=files[fi], size=size, crop_coords=crop, input_type="openpose", ref_pts_length=None, scale=scale)
+                pin.append(stack_pts(pts))                                                                  # frame coordinates, before the shift into the crop
+                p2 = copy.deepcopy(pts)
+                img = d.get_image(A_path=None, size=lbl.size, crop_coords=crop, input_type="pts", ref_pts_length=mode, scale=None, pts=p2)
+                new_img, _, new_pts = ds_posenorm_pts(ds, d, copy.deepcopy(pts), crop, lbl.size, mode)
+                assert np.array_equal(np.asarray(img), new_img)
+                pout.append(stack_pts(new_pts))
+                cout.append(misc.im2vl(np.asarray(img, dtype=np.uint8), "pose", False, False))
+            arrays[f"{clip}_{mode}_pts_in"] = np.stack(pin)
+            arrays[f"{clip}_{mode}_pts_out"] = np.stack(pout)
+            arrays[f"{clip}_{mode}_cls"] = np.stack(cout)
+        # temporal smoothing (dataset/smooth_pose_keypoint.py smooth_points :85-114): the extracted points of the clip before and after
+        import dataset.smooth_pose_keypoint as sm
+        seq = np.stack(pts_all)                                                                             # (F,137,2) = what its __main__ stacks per group
+        groups = [(0, 25), (25, 95), (95, 116), (116, 137)]
+        arrays[f"{clip}_smooth"] = np.concatenate([sm.smooth_points(seq[:, a:b].copy()) for a, b in groups], axis=1)
+        shipped = os.path.join(REF, "dataset", "json_pose", "smooth_openpose", f"{clip}.json")             # the reference ships its own output for one clip
+        if os.path.exists(shipped):
+            from wacv23_tsnet_amd.raster import read_smooth_openpose
+            assert np.array_equal(read_smooth_openpose(shipped), arrays[f"{clip}_smooth"]), "smoothing / reader differ from the shipped file"
+            print(f"[{clip}] equals the shipped dataset/json_pose/smooth_openpose/{clip}.json")
         hist = np.bincount(arrays[f"{clip}_cls_crop"].ravel(), minlength=25)
         meta["clips"][clip] = dict(frames=len(files), size=[int(size[0]), int(size[1])], crop=[int(x) for x in crop], scale=float(scale),
                                    files=[os.path.basename(f) for f in files], class_pixels=[int(x) for x in hist])

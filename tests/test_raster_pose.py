@@ -65,6 +65,37 @@ def test_host_logic_matches_golden_and_pil():
         assert np.array_equal(raster.nearest_table(n_in, n_out), want), (n_in, n_out)
 
 
+def test_pose_preprocessing_host_logic_matches_reference():
+    """The driving clip's preprocessing in front of the rasteriser, per person and frame (host arithmetic on 137 points): the five-frame temporal
+    smoothing (dataset/smooth_pose_keypoint.py:85-114; the golden equals the file the reference ships for clip 00164), the shift into the crop
+    and the limb re-scaling of opposite-sex pairs (keypoint2img_posenorm.py:70-226, both directions) -- EQUAL to the reference's outputs -- and
+    the reader of the smoothing script's json_tricks files."""
+    meta, z = _golden()
+    for clip, m in meta["clips"].items():
+        crop = m["crop"]
+        assert np.array_equal(raster.smooth_clip(z[f"{clip}_pts"]), z[f"{clip}_smooth"])
+        assert np.array_equal(raster.shift_into_crop(z[f"{clip}_fm_pts_in"][0], crop), z[f"{clip}_pts_redraw"][0])
+        for mode in ("fm", "mf"):
+            pin, pout = z[f"{clip}_{mode}_pts_in"], z[f"{clip}_{mode}_pts_out"]
+            for p, q in zip(pin, pout):
+                got = raster.pose_limb_rescale(raster.shift_into_crop(p, crop), mode, crop[3] - crop[1])
+                assert np.array_equal(got, q), (clip, mode)
+            assert np.abs(pout - np.stack([raster.shift_into_crop(p, crop) for p in pin])).max() > 5      # the re-scaling really moves limbs
+    with pytest.raises(ValueError):
+        raster.pose_limb_rescale(z["00110_pts"][0], "ff", 100)
+
+
+def test_read_smooth_openpose_file(tmp_path):
+    meta, z = _golden()
+    sm = z["00164_smooth"]
+    enc = lambda a: {"__ndarray__": a.tolist(), "dtype": "float64", "shape": list(a.shape), "Corder": True}      # json_tricks' array encoding
+    doc = {"pose_keypoints_2d": enc(sm[:, :25]), "face_keypoints_2d": enc(sm[:, 25:95]), "hand_left_keypoints_2d": enc(sm[:, 95:116]),
+           "hand_right_keypoints_2d": enc(sm[:, 116:]), "name": ["frame%06d" % i for i in range(sm.shape[0])]}
+    path = tmp_path / "00164.json"
+    path.write_text(json.dumps(doc))
+    assert np.array_equal(raster.read_smooth_openpose(str(path)), sm)
+
+
 def _pieces(pts):
     """(point a, point b, brush half-width, with end discs) of every stroke of the skeleton, in frame coordinates"""
     pose, face, hands = pts[:25], pts[25:95], (pts[95:116], pts[116:137])
@@ -124,6 +155,15 @@ def _device_check(lib, dev):
         allowed2 = np.stack([_coin_flip_mask(p, (cw, ch), (0, 0, cw, ch)) for p in z[f"{clip}_pts_redraw"]])
         report[clip]["redraw_differing"] = int(d2.sum())
         assert (d2 & ~allowed2).sum() == 0 and d2.sum() <= 80, report
+        # opposite-sex pairs: the label drawn from the re-scaled points (host) at crop size
+        for mode in ("fm", "mf"):
+            pin, want_m = z[f"{clip}_{mode}_pts_in"], z[f"{clip}_{mode}_cls"]
+            moved = [raster.pose_limb_rescale(raster.shift_into_crop(p, crop), mode, ch) for p in pin]
+            got_m = r.rasterise(moved, (cw, ch)).cpu().numpy()
+            dm = got_m != want_m
+            allowed_m = np.stack([_coin_flip_mask(p, (cw, ch), (0, 0, cw, ch)) for p in moved])
+            report[clip][f"{mode}_differing"] = int(dm.sum())
+            assert (dm & ~allowed_m).sum() == 0 and dm.sum() <= 40, report
         # integer work downstream of the class map: equal, given the reference's own class map
         ref_cls = torch.from_numpy(want)
         box = r.bbox(ref_cls)
