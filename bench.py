@@ -2,7 +2,9 @@
 """Headline benchmark: retargeted frames/s of the TS-Net forward at bs=4 per GPU, 256x256, n_source=3.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    N>1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
+    --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE from the environment) or by itself: without WORLD_SIZE in the environment
+    `python bench.py --gpus N` spawns its N ranks (one per GPU, rendezvous on 127.0.0.1) and prints rank 0's line.
 
 A "step" is one forward (tsnet_forward through the C ABI) over one synthetic batch of B=4 (source-set, driving-frame) pairs
 per GPU, inputs resident in HBM, fp32-class arithmetic.  Workload = BASELINE.json configs[1]:
@@ -259,33 +261,82 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
     return line
 
 
-def main():
+def _rank_main(rank: int, world: int, local_rank: int, args, q=None):
+    """One rank of the job (its own process).  `args.device == "cpu"` + `args.lib` is the CPU-tier test hook: gloo backend and the
+    emulation build of the kernels on tiny shapes (tests/test_bench_ranks.py); the product path is device "cuda" / backend nccl (= RCCL)."""
+    cuda = args.device == "cuda"
+    if cuda:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the box shares one 16-CPU cgroup between the ranks: one host thread per rank is all a launch loop needs
+        torch.set_num_threads(1)
+        if cuda:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib, kw = None, {}
+    if args.lib:
+        import ctypes
+        from wacv23_tsnet_amd import _lib
+        lib = _lib.bind(ctypes.CDLL(args.lib))
+    if args.tiny:       # test hook: a narrow net on 32 x 32 frames (the emulator runs ~1 GFLOP/s)
+        kw = dict(batch=1, height=32, width=32, model_kw=dict(n_source=2, ngf=8, enc_blocks=1, fuse_ngf=128), timing_probe=False)
+    line = run_rank(rank=rank, world=world, device=dev, steps=args.steps, warmup=args.warmup, lib=lib,
+                    cpu_baseline=not args.no_cpu_baseline and world == 1, secondary=not args.no_secondary and world == 1, **kw)
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        if q is not None:
+            q.put(line)
+        else:
+            print(json.dumps(line), flush=True)
+
+
+def _spawned(local_rank: int, world: int, port: int, args, q):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    sys.path.insert(0, ROOT)
+    _rank_main(local_rank, world, local_rank, args, q)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs[2] bf16-operand figure")
-    args = ap.parse_args()
+    ap.add_argument("--device", default="cuda", help=argparse.SUPPRESS)      # test hooks (CPU tier): "cpu" = gloo + --lib = the emulation build
+    ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--tiny", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus N>1 must be launched through torch.distributed.run with N ranks")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the box shares one 16-CPU cgroup between the ranks: one host thread per rank is all a launch loop needs
-        torch.set_num_threads(1)
-        dist.init_process_group("nccl", device_id=dev)
-    line = run_rank(rank=rank, world=world, device=dev, steps=args.steps, warmup=args.warmup, cpu_baseline=not args.no_cpu_baseline,
-                    secondary=not args.no_secondary)
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if "WORLD_SIZE" in os.environ:
+        # started by a launcher (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...): one rank per process
+        world = int(os.environ["WORLD_SIZE"])
+        if args.gpus != world:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+        _rank_main(int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0")), args)
+        return None
+    if args.gpus <= 1:
+        _rank_main(0, 1, 0, args)
+        return None
+    # --gpus N > 1 without a launcher: this process becomes the launcher -- N ranks of this node, one per GPU, rendezvous on 127.0.0.1
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.start_processes(_spawned, args=(args.gpus, port, args, q), nprocs=args.gpus, join=True, start_method="spawn")
+    line = q.get()
+    print(json.dumps(line), flush=True)
+    return line
 
 
 if __name__ == "__main__":

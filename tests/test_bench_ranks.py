@@ -61,3 +61,18 @@ def test_two_ranks_one_broadcast_no_collective_per_step(emu_lib, tmp_path):
             assert abs(line["value"] - 2 * STEPS / (line["ms_per_step"] * STEPS / 1e3)) / line["value"] < 1e-2
         else:
             assert got["line"] is None
+
+
+def test_bench_main_launches_its_own_ranks(emu_lib, capsys):
+    """`python bench.py --gpus 2` with no launcher around it (no WORLD_SIZE in the environment): bench.main() spawns the two ranks itself
+    and prints ONE line.  Same code path as on the GPU box, with the hidden test hooks selecting gloo + the emulation build + tiny shapes."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from conftest import build_emu_lib
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        assert k not in os.environ
+    line = bench.main(["--gpus", "2", "--steps", "2", "--warmup", "1", "--device", "cpu", "--lib", build_emu_lib(), "--tiny"])
+    out = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and json.loads(out[0])["n_gpus"] == 2
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["global_batch"] == 2 and line["value"] > 0
+    assert line["cpu_baseline"] is None and line["secondary_bf16_cfg2"] is None          # N > 1: neither leg runs
