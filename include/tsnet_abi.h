@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TSNET_ABI_VERSION 2
+#define TSNET_ABI_VERSION 3
 #define TSNET_MAX_SOURCES 8
 
 enum {
@@ -43,7 +43,7 @@ typedef struct tsnet_cfg {
     int n_blocks;        /* decoder ResnetBlocks (0 quick-start, 4 demos) */
     int n_downsampling;  /* must be 3 with ngf=64 (FuseNet width is 2*ngf*2^n_down, TSNet.py:227) */
     int n_source;        /* K <= TSNET_MAX_SOURCES */
-    int ngf;             /* 64 in every reference caller */
+    int ngf;             /* 64 in every reference caller; a power of two >= 8 */
     int enc_blocks;      /* img_enc ResnetBlocks (Encoder default 9, TSNet.py:53) */
     int addcoords;       /* Encoder.coord_conv on/off (TSNet.py:89-90) */
     int pose_composite;  /* 1 = TSNet_pose use_mask epilogue (TSNet_pose.py:416-417); needs H=W=256 */
@@ -123,8 +123,7 @@ int tsnet_train_extras(tsnet_handle h, const float* const* src_img, const float*
 /* Device copies of the stage tensors of the last forward, for stage-wise parity tests
  * (NHWC fp32).  name: "src_fea" (K*B,h,w,c; n = i*B+b), "tar_fea" (B,h,w,c), "pg", "sg" (B,h,w,c),
  * "dec_map" (B,h,w,c), "dec_up<i>" (B, h<<(i+1), w<<(i+1), c>>(i+1)): RAW output of the i-th decoder
- * up-convolution, before its InstanceNorm + ReLU (the last one is normalised in place when ngf % 16 != 0, i.e. when the
- * RGB head runs on the MFMA kernel).  Returns the element count through *count. */
+ * up-convolution, before its InstanceNorm + ReLU.  Returns the element count through *count. */
 int tsnet_stage_ptr(tsnet_handle h, const char* name, const float** dev_ptr, size_t* count);
 
 /* Algorithmic work of one forward at batch B (multiply-accumulates, SURVEY.md section 8-d closed form). */
@@ -143,11 +142,22 @@ int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64
 /* ---- single operators (NHWC fp32 device tensors), exported for op-level parity tests ------
  * These run the very kernels tsnet_forward uses.
  *
- * tsnet_op_conv2d <- nn.Conv2d (+ preceding nn.ReflectionPad2d / zero padding)  (TSNet.py:27,42,66,70,147,152)
- *   x (N,H,W,Cin) ; w OIHW (Cout,Cin,k,k) host or device ; bias (Cout) or NULL ; y (N,Ho,Wo,Cout)
- *   pad_mode 0 = zero, 1 = reflect.  in_alpha/in_beta (N*Cin) or NULL: the consumer-side
- *   InstanceNorm+ReLU applied on load, x' = max(alpha*x + beta, 0) (zero padding pads x').
- *   act: 0 none, 1 tanh.
+ * tsnet_op_conv2d <- nn.Conv2d (+ preceding nn.ReflectionPad2d / zero padding)  (TSNet.py:27,42,66,70,139,147,193)
+ *   x (N,H,W,Cin) fp32, Cin = 8 or a multiple of 16 (pad channels with zeros); w OIHW (Cout,Cin,k,k) host or device; bias (Cout) or NULL;
+ *   y (N,Ho,Wo,Cout).  ksize 1, 3 or 7; pad_mode 0 = zero, 1 = reflect.  in_alpha / in_beta (N*Cin each) or NULL: the producer's
+ *   nn.InstanceNorm2d (+ nn.ReLU when in_relu) applied while the operand tile is staged, x' = max(alpha*x + beta, 0); zero padding pads x'.
+ *   bound = an upper bound of |operand| after that transform (it fixes the power-of-two operand scale of the fp16 x 2 split).
+ *   nprod = 3 (lo*hi, hi*lo, hi*hi), 4 (+ lo*lo; 3x3 / stride-1 patch kernel only) or 1 (bf16 operands, tsnet_cfg.operand_mode = 1).
+ *   kernel: 0 = the kernel the forward runs this layer on at this frame size (patch kernels of conv_h2.hpp where the output splits into
+ *   4 x 32 rectangles: 3x3 / stride 1, 3x3 / stride 2 / zero pad, 7x7 stem with 8 input channels; the general implicit GEMM of conv_h2r.hpp
+ *   elsewhere), 1 = the general kernel, 2 = the patch kernel (error if the layer has none).
+ *   tile: 0 = the launcher's choice; patch 3x3 / stride 1: 32, 64, 128 (4-row tiles) or 2128 (2 rows x 128); others: 64 or 128.
+ *   All tiles of one kernel produce identical bits (tested); patch and general kernels sum K in different orders.
+ * tsnet_op_conv2d_cat <- the same on torch.cat((x, x2), channel axis) formed on load (dec.map_conv on cat(pg, sg), TSNet.py:163):
+ *   x (N,H,W,C1), x2 (x2_nmod,H,W,C2) read at image n % x2_nmod; C1 a multiple of 16.  No input transform.
+ * tsnet_op_head <- the decoder's RGB head: ReflectionPad2d(3) + Conv2d(C -> 3, 7x7) + bias + Tanh (TSNet.py:151-152) on relu(alpha*x+beta),
+ *   with the pose model's fixed-background composite (TSNet_pose.py:416-417: columns outside [64,192) <- bg) when composite != 0.
+ *   x (N,H,W,C) NHWC, w (3,C,7,7), bias (3), bg 3 host floats or NULL; y (N,3,H,W) NCHW.
  * tsnet_op_instnorm_stats <- nn.InstanceNorm2d statistics (TSNet.py:53; eps 1e-5, biased variance):
  *   alpha = 1/sqrt(var+eps), beta = -mean*alpha, each (N*C).
  * tsnet_op_norm_act   : y = alpha*x+beta (relu optional) ; if resid != NULL y += resid  (ResnetBlock tail, TSNet.py:48)
@@ -159,24 +169,13 @@ int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64
  */
 int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin,
                     const float* w_oihw, const float* bias, int Cout, int ksize, int stride, int pad, int pad_mode,
-                    const float* in_alpha, const float* in_beta, int in_relu, int act,
+                    const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, int kernel, int tile,
                     float* y, void* stream);
-/* Same convolution on the bf16x3 kernel (conv_x3.hpp): x and w are split into three bf16 planes on the
- * device first; tile = -1 (heuristic) or an index into the kernel's tile table.  No input transform. */
-int tsnet_op_conv2d_x3(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
-                       int ksize, int stride, int pad, int pad_mode, int tile, float* y, void* stream);
-/* The 3x3 / stride-1 / pad-1 convolution on the fp16x2 patch kernel (conv_h2.hpp): x stays fp32 and, when in_alpha / in_beta
- * (N*Cin each) are given, x*alpha+beta (+ReLU) -- the producer's nn.InstanceNorm2d + nn.ReLU (TSNet.py:27-33,40-46) -- is applied
- * while the input patch is staged.  bound = an upper bound of |operand| after that transform (it fixes the power-of-two operand
- * scale); nprod = 3 (lo*hi, hi*lo, hi*hi) or 4 (+ lo*lo); tile_n = 0 (heuristic), 64 or 128. */
-int tsnet_op_conv2d_h2(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int pad_mode,
-                       const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, int tile_n,
-                       float* y, void* stream);
-/* The encoder's other convolutions on the same arithmetic, as an implicit GEMM (conv_h2r): ksize = 3 -> 3x3 / stride 2 / zero pad 1
- * (downsampling, TSNet.py:70), ksize = 7 -> 7x7 / stride 1 / reflection pad 3 (stem, TSNet.py:66; Cin = 8 or a power of two >= 16).
- * The output image must be a whole number of 128-position tiles.  nprod = 3, or 1 for bf16 operands. */
-int tsnet_op_conv2d_h2r(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int ksize,
-                        const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, float* y, void* stream);
+int tsnet_op_conv2d_cat(const float* x, const float* x2, int N, int H, int W, int C1, int C2, int x2_nmod,
+                        const float* w_oihw, const float* bias, int Cout, int ksize, int stride, int pad, int pad_mode,
+                        float bound, int nprod, float* y, void* stream);
+int tsnet_op_head(const float* x, int N, int H, int W, int C, const float* in_alpha, const float* in_beta,
+                  const float* w_oihw, const float* bias, int composite, const float* bg, float* y, void* stream);
 int tsnet_op_instnorm_stats(const float* x, int N, int HW, int C, float* alpha, float* beta, void* stream);
 int tsnet_op_norm_act(const float* x, const float* alpha, const float* beta, int relu, const float* resid,
                       int N, int HW, int C, float* y, void* stream);
@@ -227,14 +226,14 @@ int tsnet_label_bbox(const unsigned char* labels, int F, int h, int w, unsigned 
 int tsnet_resize_pad(const unsigned char* in, int F, int h, int w, const int* ytab, const int* xtab, int oh, int ow,
                      int pad_top, int pad_left, int OH, int OW, int binarise, float* out, void* stream);
 
-/* Micro-benchmark of one convolution shape on synthetic (non-zero) data: average milliseconds per
- * launch over `iters` back-to-back launches, hipEvent-timed on `stream`.  variant: -1 = the engine's
- * own tile heuristic, else tile index + 8*(BK==32) (tools/conv_sweep.py).  Diagnostic only. */
+/* Micro-benchmark of one convolution shape on synthetic (non-zero) data: average milliseconds per launch over `iters` back-to-back
+ * launches, hipEvent-timed on `stream`.  variant: -1 = the layer's own kernel and tile; else bits 0-11 tile code (tsnet_op_conv2d),
+ * bit 12 general kernel, bit 13 bf16 operands, bits 16-23 / 24-31 ablation / experiment masks (tools build).  Diagnostic only. */
 int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int pad_mode, int norm,
                      int variant, int iters, float* ms_out, void* stream);
 
-/* Conv launch counters since the last reset: out[0] = conv_glds kernels, out[1] = conv_igemm (register-staged),
- * out[2] = conv_dma (buffer-descriptor LDS-DMA, fp32 MFMA); out[3] = conv_x3 (bf16x3).  Diagnostic. */
+/* Launch counters since the last reset: out[0] = patch convolution kernels (conv_h2.hpp), out[1] = general convolution kernel
+ * (conv_h2r.hpp), out[2] = RGB head, out[3] unused.  Diagnostic. */
 void tsnet_debug_counters(int64_t out[4], int reset);
 
 /* Host-side constant tables, exported so CPU tests can pin them against torch:

@@ -51,7 +51,7 @@ const char* g_error = nullptr;
 // block barrier
 int g_bar_count = 0; unsigned g_bar_gen = 0;
 // wave rendezvous
-struct WaveState { int count = 0; unsigned gen = 0; float a[2][64], b[2][64]; const void* gp[2][64]; void* lp[2][64]; unsigned short ha[2][64][8], hb[2][64][8]; int alive = 0; };
+struct WaveState { int count = 0; unsigned gen = 0; float a[2][64], b[2][64]; const void* gp[2][64]; void* lp[2][64]; float fa[2][64][8], fb[2][64][8]; int alive = 0; };
 std::vector<WaveState> g_waves;
 
 void yield() { emu_switch(&g_fibers[g_cur].sp, g_sched_sp); }
@@ -113,43 +113,48 @@ f32x16_t mfma_32x32x2(float a, float b, f32x16_t c) {
     return d;
 }
 
-f32x16_t mfma_bf16_32x32x16(const void* a16, const void* b16, f32x16_t c) {
-    // lane l holds A[i = l&31][k = 8*(l>>5) + 0..7] and B[k = 8*(l>>5) + 0..7][j = l&31] as bf16; products are
-    // exact in fp32, accumulated in k order (the hardware's internal order may differ: same error class)
+// v_mfma_f32_32x32x16_{bf16,f16}: lane l holds A[i = l&31][k = 8*(l>>5) + 0..7] and B[k = 8*(l>>5) + 0..7][j = l&31]; products are exact in
+// fp32 (8 x 8 / 11 x 11 significand bits), accumulated in k order (the hardware's internal order may differ: same error class).  Every lane
+// widens its own fragments to fp32 BEFORE the rendezvous, so the 256 fused multiply-adds per lane run on plain floats.
+static f32x16_t mfma_16bit(const float (&fa)[8], const float (&fb)[8], f32x16_t c) {
     WaveState& w = g_waves[g_cur / 64];
     const int lane = g_cur & 63, par = w.gen & 1;
-    memcpy(w.ha[par][lane], a16, 16);
-    memcpy(w.hb[par][lane], b16, 16);
+    memcpy(w.fa[par][lane], fa, sizeof fa);
+    memcpy(w.fb[par][lane], fb, sizeof fb);
     wave_rendezvous(w);
     const int j = lane & 31, hi = lane >> 5;
-    auto bf = [](unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    const float* b0 = w.fb[par][j];
+    const float* b1 = w.fb[par][j + 32];
     f32x16_t d = c;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float* a0 = w.fa[par][i];
+        const float* a1 = w.fa[par][i + 32];
         float t = d[r];
-        for (int k = 0; k < 16; ++k) t = fmaf(bf(w.ha[par][i + 32 * (k >> 3)][k & 7]), bf(w.hb[par][j + 32 * (k >> 3)][k & 7]), t);
+        for (int k = 0; k < 8; ++k) t = fmaf(a0[k], b0[k], t);
+        for (int k = 0; k < 8; ++k) t = fmaf(a1[k], b1[k], t);
         d[r] = t;
     }
     return d;
 }
 
-f32x16_t mfma_f16_32x32x16(const void* a16, const void* b16, f32x16_t c) {
-    // same fragment layout as the bf16 form; fp16 products are exact in fp32 (11 x 11 significand bits)
-    WaveState& w = g_waves[g_cur / 64];
-    const int lane = g_cur & 63, par = w.gen & 1;
-    memcpy(w.ha[par][lane], a16, 16);
-    memcpy(w.hb[par][lane], b16, 16);
-    wave_rendezvous(w);
-    const int j = lane & 31, hi = lane >> 5;
-    auto hf = [](unsigned short h) { _Float16 f; memcpy(&f, &h, 2); return (float)f; };
-    f32x16_t d = c;
-    for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float t = d[r];
-        for (int k = 0; k < 16; ++k) t = fmaf(hf(w.ha[par][i + 32 * (k >> 3)][k & 7]), hf(w.hb[par][j + 32 * (k >> 3)][k & 7]), t);
-        d[r] = t;
+f32x16_t mfma_bf16_32x32x16(const void* a16, const void* b16, f32x16_t c) {
+    unsigned short ha[8], hb[8];
+    memcpy(ha, a16, 16); memcpy(hb, b16, 16);
+    float fa[8], fb[8];
+    for (int k = 0; k < 8; ++k) {
+        unsigned ua = (unsigned)ha[k] << 16, ub = (unsigned)hb[k] << 16;
+        memcpy(&fa[k], &ua, 4); memcpy(&fb[k], &ub, 4);
     }
-    return d;
+    return mfma_16bit(fa, fb, c);
+}
+
+f32x16_t mfma_f16_32x32x16(const void* a16, const void* b16, f32x16_t c) {
+    _Float16 ha[8], hb[8];
+    memcpy(ha, a16, 16); memcpy(hb, b16, 16);
+    float fa[8], fb[8];
+    for (int k = 0; k < 8; ++k) { fa[k] = (float)ha[k]; fb[k] = (float)hb[k]; }
+    return mfma_16bit(fa, fb, c);
 }
 
 void buf_dma16(const unsigned char* base, unsigned bytes, unsigned voff, unsigned soff, unsigned char* lds) {

@@ -91,6 +91,16 @@ template <class T> static inline T emu_buf_load16(const tsnet_rsrc_t& r, unsigne
 #define TSNET_MFMA_BF16(a, b, c) emu::mfma_bf16_32x32x16(&(a), &(b), (c))
 // hook of conv_h2.hpp: v_mfma_f32_32x32x16_f16 on raw 16-byte operands (8 fp16 per lane)
 #define TSNET_MFMA_F16(a, b, c) emu::mfma_f16_32x32x16(&(a), &(b), (c))
+// hook of conv_common.hpp: the three-instruction fp16 x 2 split (v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16) in plain C
+static inline void emu_split_pair(float a, float b, unsigned& hw, unsigned& lw) {
+    const _Float16 h0 = (_Float16)a, h1 = (_Float16)b;
+    const _Float16 l0 = (_Float16)(a - (float)h0), l1 = (_Float16)(b - (float)h1);
+    unsigned short u0, u1, v0, v1;
+    memcpy(&u0, &h0, 2); memcpy(&u1, &h1, 2); memcpy(&v0, &l0, 2); memcpy(&v1, &l1, 2);
+    hw = (unsigned)u0 | ((unsigned)u1 << 16); lw = (unsigned)v0 | ((unsigned)v1 << 16);
+}
+#define TSNET_SPLIT_PAIR(a, b, hw, lw) emu_split_pair((a), (b), (hw), (lw))
+#define TSNET_SETPRIO(n) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define TSNET_DRAIN_VMEM() ((void)0)
 // device-scope atomics of the statistics hand-off (conv_x3.hpp x3_epilogue): workgroups run one after another here
@@ -115,6 +125,7 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 #define hipStreamNonBlocking 1
 #define hipEventDisableTiming 2

@@ -30,22 +30,28 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
 
-def conv_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, norm=False, act=0, bias=True, seed=0):
-    """nn.Conv2d (+ReflectionPad2d / zero pad, + consumer-side IN+ReLU) vs tsnet_op_conv2d. Returns max|d|."""
-    x = _rand(seed, "x", (N, Cin, H, W))
+def conv_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, norm=False, bias=True, seed=0, nprod=3, kernel=0, tile=0, scale=1.0,
+              relu=None, return_output=False):
+    """nn.Conv2d (+ReflectionPad2d / zero pad), optionally on relu(x*alpha+beta) -- the consumer side of nn.InstanceNorm2d + nn.ReLU --
+    vs tsnet_op_conv2d (fp16 x 2 operands, the transform fused into the operand staging).  kernel: 0 = the forward's own choice for the
+    layer, 1 = general implicit GEMM, 2 = patch kernel.  Returns max|d| relative to max|fp64 reference| (or the NHWC output)."""
+    x = _rand(seed, "x", (N, Cin, H, W)) * scale
     w = _rand(seed, "w", (Cout, Cin, k, k)) * (2.0 / (Cin * k * k) ** 0.5)
     b = _rand(seed, "b", (Cout,)) if bias else None
     xin, al, be = x, None, None
+    relu = norm if relu is None else relu
     if norm:
         al = _rand(seed, "al", (N, Cin), 0.5, 1.5)
         be = _rand(seed, "be", (N, Cin), -0.3, 0.3)
-        xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
+        xin = x * al[:, :, None, None] + be[:, :, None, None]
+    if relu:
+        xin = F.relu(xin)
+    b64 = None if b is None else b.double()
     if reflect:
-        ref = F.conv2d(F.pad(xin, (pad,) * 4, mode="reflect"), w, b, stride=stride)
+        ref = F.conv2d(F.pad(xin.double(), (pad,) * 4, mode="reflect"), w.double(), b64, stride=stride)
     else:
-        ref = F.conv2d(xin, w, b, stride=stride, padding=pad)
-    if act:
-        ref = torch.tanh(ref)
+        ref = F.conv2d(xin.double(), w.double(), b64, stride=stride, padding=pad)
+    bound = float(xin.abs().max()) * 1.0001 + 1e-30
     Ho, Wo = ref.shape[2:]
     xd = nhwc(x).to(dev)
     y = torch.full((N, Ho, Wo, Cout), float("nan"), device=dev)
@@ -53,37 +59,7 @@ def conv_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, norm=False,
     bed = be.contiguous().to(dev) if norm else None
     wd, bd = w.to(dev), (b.to(dev) if bias else None)
     rc = lib.tsnet_op_conv2d(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), _p(bd), Cout, k, stride, pad, int(reflect),
-                             _p(ald), _p(bed), 1 if norm else 0, act, y.data_ptr(), None)
-    assert rc == 0, lib.tsnet_op_last_error().decode()
-    _sync(dev)
-    return (nchw(y.cpu()) - ref).abs().max().item()
-
-
-
-def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, nprod=3, tile_n=0, seed=0, scale=1.0, return_output=False):
-    """nn.Conv2d 3x3 / stride 1 (+ReflectionPad2d(1) or zero pad 1), optionally on relu(x*alpha+beta) -- the consumer side of
-    nn.InstanceNorm2d + nn.ReLU -- vs tsnet_op_conv2d_h2 (fp16x2 patch kernel, transform fused into the patch staging).
-    Returns max|d| relative to max|ref|."""
-    x = _rand(seed, "x", (N, Cin, H, W)) * scale
-    w = _rand(seed, "w", (Cout, Cin, 3, 3)) * (2.0 / (Cin * 9) ** 0.5)
-    b = _rand(seed, "b", (Cout,)) if bias else None
-    xin, al, be = x, None, None
-    if norm:
-        al = _rand(seed, "al", (N, Cin), 0.5, 1.5)
-        be = _rand(seed, "be", (N, Cin), -0.3, 0.3)
-        xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
-    if reflect:
-        ref = F.conv2d(F.pad(xin.double(), (1,) * 4, mode="reflect"), w.double(), None if b is None else b.double())
-    else:
-        ref = F.conv2d(xin.double(), w.double(), None if b is None else b.double(), padding=1)
-    bound = float(xin.abs().max()) * 1.0001 + 1e-30
-    xd = nhwc(x).to(dev)
-    y = torch.full((N, H, W, Cout), float("nan"), device=dev)
-    ald = al.contiguous().to(dev) if norm else None
-    bed = be.contiguous().to(dev) if norm else None
-    wd, bd = w.to(dev), (b.to(dev) if bias else None)
-    rc = lib.tsnet_op_conv2d_h2(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), _p(bd), Cout, int(reflect), _p(ald), _p(bed),
-                                1 if norm else 0, bound, nprod, tile_n, y.data_ptr(), None)
+                             _p(ald), _p(bed), int(relu), bound, nprod, kernel, tile, y.data_ptr(), None)
     assert rc == 0, lib.tsnet_op_last_error().decode()
     _sync(dev)
     if return_output:
@@ -91,33 +67,65 @@ def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, n
     return ((nchw(y.cpu()).double() - ref).abs().max() / ref.abs().max()).item()
 
 
-def conv_h2r_case(lib, dev, N, H, W, Cin, Cout, ksize, norm=False, bias=True, seed=0):
-    """the encoder's stem (7x7, reflection pad 3) and downsampling (3x3, stride 2, zero pad 1) convolutions, optionally on
-    relu(x*alpha+beta), vs tsnet_op_conv2d_h2r (fp16 x 2 implicit GEMM with the transform fused).  Returns max|d| / max|ref|."""
-    x = _rand(seed, "x", (N, Cin, H, W))
-    w = _rand(seed, "w", (Cout, Cin, ksize, ksize)) * (2.0 / (Cin * ksize * ksize) ** 0.5)
-    b = _rand(seed, "b", (Cout,)) if bias else None
-    xin, al, be = x, None, None
-    if norm:
-        al = _rand(seed, "al", (N, Cin), 0.5, 1.5)
-        be = _rand(seed, "be", (N, Cin), -0.3, 0.3)
-        xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
-    bd64 = None if b is None else b.double()
+def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, nprod=3, tile_n=0, seed=0, scale=1.0, return_output=False):
+    """3x3 / stride 1 / pad 1 on the PATCH kernel (conv_h2.hpp h2_tile); tile_n: 0, 32, 64, 128 (4-row tiles) or 2128 (2 rows x 128)."""
+    return conv_case(lib, dev, N, H, W, Cin, Cout, 3, 1, 1, reflect, norm=norm, bias=bias, seed=seed, nprod=nprod, kernel=2, tile=tile_n,
+                     scale=scale, return_output=return_output)
+
+
+def conv_h2r_case(lib, dev, N, H, W, Cin, Cout, ksize, norm=False, bias=True, seed=0, kernel=0, tile=0, return_output=False):
+    """the encoder's stem (7x7, reflection pad 3) and downsampling (3x3, stride 2, zero pad 1) convolutions; kernel as conv_case."""
     if ksize == 7:
-        ref = F.conv2d(F.pad(xin.double(), (3,) * 4, mode="reflect"), w.double(), bd64)
-    else:
-        ref = F.conv2d(xin.double(), w.double(), bd64, stride=2, padding=1)
-    bound = float(xin.abs().max()) * 1.0001 + 1e-30
-    xd = nhwc(x).to(dev)
-    y = torch.full((N, ref.shape[2], ref.shape[3], Cout), float("nan"), device=dev)
-    ald = al.contiguous().to(dev) if norm else None
-    bed = be.contiguous().to(dev) if norm else None
-    wd, bd = w.to(dev), (b.to(dev) if bias else None)
-    rc = lib.tsnet_op_conv2d_h2r(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), _p(bd), Cout, ksize, _p(ald), _p(bed), 1 if norm else 0, bound, 3,
-                                 y.data_ptr(), None)
+        return conv_case(lib, dev, N, H, W, Cin, Cout, 7, 1, 3, True, norm=norm, bias=bias, seed=seed, kernel=kernel, tile=tile, return_output=return_output)
+    return conv_case(lib, dev, N, H, W, Cin, Cout, 3, 2, 1, False, norm=norm, bias=bias, seed=seed, kernel=kernel, tile=tile, return_output=return_output)
+
+
+def conv_cat_case(lib, dev, N, H, W, C1, C2, Cout, k=1, seed=0, shared=False):
+    """convolution of torch.cat((x, x2), dim=1) with the concat formed on load (dec.map_conv on cat(pg, sg), TSNet.py:163); `shared`: x2 has
+    one image that every image of x is concatenated with (image index n % x2_nmod)."""
+    x = _rand(seed, "x", (N, C1, H, W))
+    x2 = _rand(seed, "x2", (1 if shared else N, C2, H, W)) * 3.0
+    w = _rand(seed, "w", (Cout, C1 + C2, k, k)) * (2.0 / ((C1 + C2) * k * k) ** 0.5)
+    b = _rand(seed, "b", (Cout,))
+    xin = torch.cat([x, x2.expand(N, -1, -1, -1)], dim=1)
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=k // 2)
+    y = torch.full((N, H, W, Cout), float("nan"), device=dev)
+    xd, x2d, wd, bd = nhwc(x).to(dev), nhwc(x2).to(dev), w.to(dev), b.to(dev)
+    rc = lib.tsnet_op_conv2d_cat(xd.data_ptr(), x2d.data_ptr(), N, H, W, C1, C2, x2.shape[0], wd.data_ptr(), bd.data_ptr(), Cout, k, 1, k // 2, 0,
+                                 float(xin.abs().max()) * 1.0001, 3, y.data_ptr(), None)
     assert rc == 0, lib.tsnet_op_last_error().decode()
     _sync(dev)
     return ((nchw(y.cpu()).double() - ref).abs().max() / ref.abs().max()).item()
+
+
+def head_case(lib, dev, N, H, W, C, norm=True, composite=False, seed=0):
+    """the decoder's RGB head: ReflectionPad2d(3) + Conv2d(C -> 3, 7x7) + bias + Tanh on relu(IN(x)) (TSNet.py:151-152), optional pose
+    composite (TSNet_pose.py:416-417) vs tsnet_op_head.  Returns max|d|."""
+    x = _rand(seed, "x", (N, C, H, W))
+    w = _rand(seed, "w", (3, C, 7, 7)) * (2.0 / (C * 49) ** 0.5)
+    b = _rand(seed, "b", (3,))
+    xin, al, be = x, None, None
+    if norm:
+        al = _rand(seed, "al", (N, C), 0.5, 1.5)
+        be = _rand(seed, "be", (N, C), -0.3, 0.3)
+        xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
+    ref = torch.tanh(F.conv2d(F.pad(xin, (3,) * 4, mode="reflect"), w, b))
+    bg = [0.25, -0.5, 0.75]
+    if composite:
+        for c in range(3):
+            ref[:, c, :, :64] = bg[c]
+            ref[:, c, :, 192:] = bg[c]
+    import ctypes
+    y = torch.full((N, 3, H, W), float("nan"), device=dev)
+    xd, wd, bd = nhwc(x).to(dev), w.to(dev), b.to(dev)
+    ald = al.contiguous().to(dev) if norm else None
+    bed = be.contiguous().to(dev) if norm else None
+    rc = lib.tsnet_op_head(xd.data_ptr(), N, H, W, C, _p(ald), _p(bed), wd.data_ptr(), bd.data_ptr(), int(composite), (ctypes.c_float * 3)(*bg),
+                           y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    return (y.cpu() - ref).abs().max().item()
+
 
 def instnorm_case(lib, dev, N, H, W, C, relu, resid, seed=0, offset=0.0):
     """InstanceNorm2d(eps=1e-5, biased var) [+ReLU] [+residual] vs stats + norm_act kernels."""
@@ -207,39 +215,3 @@ def warp_case(lib, dev, B, h, w, C, seed=0):
     assert rc == 0, lib.tsnet_op_last_error().decode()
     _sync(dev)
     return (nchw(out.cpu()) - ref).abs().max().item()
-
-
-def conv_x3_tiles_bitwise(lib, dev, N, H, W, Cin, Cout, tiles, reflect=True, seed=0):
-    """Largest |difference| between the outputs of several tile configurations of one kernel family on the same
-    3x3 / stride-1 layer (0.0 = bit-identical: tile choice must not change the arithmetic)."""
-    x = F.relu(_rand(seed, "x", (N, Cin, H, W), -1.0, 2.0))
-    w = _rand(seed, "w", (Cout, Cin, 3, 3)) * (2.0 / (Cin * 9) ** 0.5)
-    b = _rand(seed, "b", (Cout,))
-    xd, wd, bd = nhwc(x).to(dev), w.to(dev), b.to(dev)
-    outs = []
-    for t in tiles:
-        y = torch.full((N, H, W, Cout), float("nan"), device=dev)
-        rc = lib.tsnet_op_conv2d_x3(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), bd.data_ptr(), Cout, 3, 1, 1, int(reflect), t, y.data_ptr(), None)
-        assert rc == 0, lib.tsnet_op_last_error().decode()
-        _sync(dev)
-        outs.append(y.cpu())
-    return max((o - outs[0]).abs().max().item() for o in outs[1:])
-
-
-def conv_x3_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, tile=-1, bias=True, seed=0):
-    """nn.Conv2d (+padding) on the bf16x3 kernel (3-way bf16 operand split on the bf16 MFMA) vs PyTorch fp32."""
-    x = F.relu(_rand(seed, "x", (N, Cin, H, W), -1.0, 2.0))
-    w = _rand(seed, "w", (Cout, Cin, k, k)) * (2.0 / (Cin * k * k) ** 0.5)
-    b = _rand(seed, "b", (Cout,)) if bias else None
-    if reflect:
-        ref = F.conv2d(F.pad(x, (pad,) * 4, mode="reflect"), w, b, stride=stride)
-    else:
-        ref = F.conv2d(x, w, b, stride=stride, padding=pad)
-    Ho, Wo = ref.shape[2:]
-    xd = nhwc(x).to(dev)
-    y = torch.full((N, Ho, Wo, Cout), float("nan"), device=dev)
-    wd, bd = w.to(dev), (b.to(dev) if bias else None)
-    rc = lib.tsnet_op_conv2d_x3(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), _p(bd), Cout, k, stride, pad, int(reflect), tile, y.data_ptr(), None)
-    assert rc == 0, lib.tsnet_op_last_error().decode()
-    _sync(dev)
-    return (nchw(y.cpu()) - ref).abs().max().item()

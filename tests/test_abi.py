@@ -33,7 +33,17 @@ def test_hip_library_exports_every_symbol():
     needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
     assert "libamdhip64.so" in needed            # it is the HIP build, not a host stub
     kernels = subprocess.run(["strings", path], capture_output=True, text=True).stdout
-    assert "conv_dma_kernel" in kernels and "flow_kernel" in kernels
+    assert "conv_h2_kernel" in kernels and "conv_h2r_kernel" in kernels and "flow_kernel" in kernels
+    # ONE schedule in the product library: no superseded convolution generation, no ablation / experiment instantiation
+    for legacy in ("conv_igemm", "conv_dma", "conv_x3"):
+        assert legacy not in kernels, legacy
+
+
+def test_product_sources_do_not_read_the_environment():
+    """Behaviour of the product library must not depend on environment variables: no getenv anywhere under csrc/."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "wacv23_tsnet_amd", "csrc", "*")):
+        assert "getenv" not in open(f).read(), f
 
 
 def test_library_loads_and_reports_version():
@@ -44,7 +54,7 @@ def test_library_loads_and_reports_version():
     except RuntimeError as e:
         pytest.skip(str(e))
     lib = _lib.load()
-    assert lib.tsnet_abi_version() == 2
+    assert lib.tsnet_abi_version() == 3
     for sym in _lib.ABI_SYMBOLS:
         assert hasattr(lib, sym)
 

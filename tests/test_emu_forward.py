@@ -31,11 +31,12 @@ def test_forward_matches_oracle(emu_lib, kw):
         assert (a - b).abs().max().item() < 1e-4
     rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, B, "cpu")
     assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4 and rep["pg"] < 2e-3
-    # downstream of pg (flow error x feature gradient).  Not the last one: at ngf = 8 the MFMA head path normalises it in place
-    assert max(rep[f"dec_up{i}"] for i in range(cfg.n_downsampling - 1)) < 2e-3
+    assert max(rep[f"dec_up{i}"] for i in range(cfg.n_downsampling)) < 2e-3         # downstream of pg (flow error x feature gradient)
     cnt = (C.c_int64 * 4)()
     emu_lib.tsnet_debug_counters(cnt, 1)
-    assert cnt[2] > 0 and cnt[1] == 0        # every conv went through conv_dma_kernel
+    # 32-wide frames: the 8-channel stems (label_nc = 2: both; 5: the label encoder's) and the last decoder up-convolution split into
+    # 4 x 32 rectangles (patch kernels); everything at the lower resolutions runs on the general kernel
+    assert cnt[1] > 0 and cnt[0] == (3 if cfg.label_nc == 2 else 2) and cnt[2] == 1
     eng.close()
 
 
@@ -62,7 +63,7 @@ def test_batch_items_independent(emu_lib):
     full, _ = Hh.run_engine(eng, inp, "cpu")
     sub = ([x[1:2] for x in inp[0]], [x[1:2] for x in inp[1]], [x[1:2] for x in inp[2]], inp[3][1:2], inp[4][1:2])
     one, _ = Hh.run_engine(eng, sub, "cpu")
-    assert (one - full[1:2]).abs().max().item() <= 1e-6
+    assert torch.equal(one, full[1:2])          # per-sample statistics, scales and tiles: the same bits in any batch
     eng.close()
 
 
@@ -71,15 +72,18 @@ def test_pose_composite(emu_lib):
     ref = O.tsnet_forward(sd, cfg, *inp)
     eng = Hh.make_engine(cfg, sd, 256, 256, 1, "cpu", lib=emu_lib)
     rec, _ = Hh.run_engine(eng, inp, "cpu", return_flow=False)
-    assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
+    # 4x weights on a 256 x 256 frame: an ill-conditioned map (the fp32 oracle itself is 3.4e-4 from its fp64 evaluation); the engine must
+    # be as close to the fp64 result as the fp32 oracle is, and within the north-star 1e-3 of the fp32 oracle
+    r64 = O.tsnet_forward({k: v.double() for k, v in sd.items()}, cfg, *[[t.double() for t in x] if isinstance(x, list) else x.double() for x in inp])["rec_tar_img"]
+    assert (rec.double() - r64).abs().max().item() <= (ref["rec_tar_img"].double() - r64).abs().max().item() + 1e-4
+    assert (rec - ref["rec_tar_img"]).abs().max().item() < 1e-3
     assert torch.equal(rec[..., :64], ref["rec_tar_img"][..., :64]) and torch.equal(rec[..., 192:], ref["rec_tar_img"][..., 192:])
     eng.close()
 
 
 def test_conv_epilogue_statistics_path(emu_lib):
-    """64x64 input -> 8x8 features: P=64 is a whole number of 64-row tiles, so the conv epilogue (not the
-    stand-alone pass) produces the InstanceNorm partials for the 64x64 and 32x32 layers; the result must
-    still match the oracle."""
+    """64x64 input -> 8x8 features: every image is one ragged 128-position tile at the feature resolution, two / eight / 32 whole tiles above
+    it; the in-kernel statistics finalize (at most 32 tiles per image) and the in_finalize2 launch (the 64x64 stem is exactly 32) both run."""
     cfg, sd, inp = _case(K=1, nb=1, B=1, H=64, W=64, enc_blocks=1)
     ref = O.tsnet_forward(sd, cfg, *inp)
     eng = Hh.make_engine(cfg, sd, 64, 64, 1, "cpu", lib=emu_lib)
@@ -90,8 +94,8 @@ def test_conv_epilogue_statistics_path(emu_lib):
 
 @pytest.mark.parametrize("pose", [False, True])
 def test_vector_rgb_head(emu_lib, pose):
-    """ngf=16 is the narrowest width the dedicated RGB-head kernel (head_conv.hpp) accepts; ragged 48x40
-    frames exercise its partial tiles and reflection, the pose case (256x256) its composite epilogue."""
+    """ngf=16: head_conv3_kernel (the form every reference-width model runs); ragged 48x40 frames exercise its partial tiles and
+    reflection, the pose case (256x256) its composite epilogue."""
     H, W = (256, 256) if pose else (48, 40)
     cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=1, ngf=16, enc_blocks=0, fuse_ngf=256, pose=pose)
     sd = O.synth_state_dict(cfg, seed=8, bias_std=0.02)
@@ -106,45 +110,11 @@ def test_vector_rgb_head(emu_lib, pose):
     eng.close()
 
 
-def test_bf16x3_schedule(emu_lib, monkeypatch):
-    """ngf=16 selects the bf16x3 schedule (conv_x3.hpp: every conv input as three bf16 planes, written by the
-    producers).  Every conv must run on it, the result must match the oracle like the fp32-MFMA schedule does,
-    and the two schedules must agree closely with each other."""
-    cfg = O.TSNetConfig(label_nc=2, n_blocks=1, n_source=2, ngf=16, enc_blocks=1, fuse_ngf=256)
-    sd = O.synth_state_dict(cfg, seed=12, bias_std=0.02)
-    sd = {k: (v * 3 if k.endswith("weight") else v) for k, v in sd.items()}
-    inp = O.synth_inputs(cfg, 2, 32, 32, seed=13, mask_mode="box")
-    ref = O.tsnet_forward(sd, cfg, *inp, want_stages=True)
-    eng = Hh.make_engine(cfg, sd, 32, 32, 2, "cpu", lib=emu_lib)
-    emu_lib.tsnet_debug_counters(None, 1)
-    rec, flows = Hh.run_engine(eng, inp, "cpu")
-    cnt = (C.c_int64 * 4)()
-    emu_lib.tsnet_debug_counters(cnt, 1)
-    assert cnt[3] > 0 and cnt[2] == 0 and cnt[1] == 0 and cnt[0] == 0
-    assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
-    rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, 2, "cpu")
-    assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4
-    assert max(rep[k] for k in rep if k.startswith("dec_up")) < 2e-3
-    # clip mode on the x3 schedule
-    eng.set_sources(inp[0], inp[1], inp[2])
-    r2, _ = eng.forward_target(inp[3], inp[4])
-    assert torch.equal(rec, r2)
-    eng.close()
-    monkeypatch.setenv("TSNET_X3", "0")
-    eng32 = Hh.make_engine(cfg, sd, 32, 32, 2, "cpu", lib=emu_lib)
-    emu_lib.tsnet_debug_counters(None, 1)
-    rec32, _ = Hh.run_engine(eng32, inp, "cpu")
-    emu_lib.tsnet_debug_counters(cnt, 1)
-    assert cnt[2] > 0 and cnt[3] == 0
-    assert (rec - rec32).abs().max().item() < 2e-4
-    eng32.close()
-
-
-def test_h2_schedule(emu_lib, monkeypatch):
-    """32 x 256 frames give 4 x 32 feature maps -- one patch tile of conv_h2.hpp -- so the h2 schedule engages: ResnetBlock, FuseNet and
-    the later decoder up-convolutions read fp32 and apply the producer's InstanceNorm + ReLU while staging (no norm_act pass, fp16x2
-    operands), the decoder's unbounded stream keeps the bf16x3 planes.  Must match the oracle like the bf16x3 schedule, agree with it
-    closely, and stay bit-identical between the one-shot forward and clip mode."""
+def test_patch_kernel_schedule(emu_lib):
+    """32 x 256 frames give 4 x 32 feature maps -- one patch tile of conv_h2.hpp -- so every 3x3 layer of the forward runs on the patch
+    kernels (h2s stems, h2d downsampling, h2 ResnetBlock / FuseNet / decoder), each applying its producer's InstanceNorm + ReLU while staging;
+    only the two 1x1 convolutions run on the general kernel.  Must match the oracle and stay bit-identical between the one-shot forward and
+    clip mode."""
     cfg = O.TSNetConfig(label_nc=2, n_blocks=1, n_source=1, ngf=32, enc_blocks=1, fuse_ngf=512)
     sd = O.synth_state_dict(cfg, seed=14, bias_std=0.02)
     sd = {k: (v * 2 if k.endswith("weight") else v) for k, v in sd.items()}
@@ -155,9 +125,9 @@ def test_h2_schedule(emu_lib, monkeypatch):
     rec, flows = Hh.run_engine(eng, inp, "cpu")
     cnt = (C.c_int64 * 4)()
     emu_lib.tsnet_debug_counters(cnt, 1)
-    # conv_h2 / conv_h2r: 2 x 3 (stride-2 downsampling of both encoders) + 2 (encoder block) + 1 (target half of fuse conv1) + 2 (fuse)
-    # + 2 (decoder block; its first conv scales by the published max |D|) + 2 (dec_up0 likewise, dec_up1) = 15
-    assert cnt[0] == 15 and cnt[3] > 0 and cnt[2] == 0 and cnt[1] == 0
+    # patch kernels: 2 stems + 2 x 3 downsampling + 2 (encoder block) + 2 (halves of fuse conv1) + 1 (fuse conv2) + 2 (decoder block)
+    # + 3 (decoder up-convolutions) = 18; general kernel: fuse_net.conv and dec.map_conv
+    assert cnt[0] == 18 and cnt[1] == 2 and cnt[2] == 1
     assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
     rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, 1, "cpu")
     assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4
@@ -166,14 +136,6 @@ def test_h2_schedule(emu_lib, monkeypatch):
     r2, _ = eng.forward_target(inp[3], inp[4])
     assert torch.equal(rec, r2)
     eng.close()
-    monkeypatch.setenv("TSNET_H2", "0")
-    eng3 = Hh.make_engine(cfg, sd, 32, 256, 1, "cpu", lib=emu_lib)
-    emu_lib.tsnet_debug_counters(None, 1)
-    rec3, _ = Hh.run_engine(eng3, inp, "cpu")
-    emu_lib.tsnet_debug_counters(cnt, 1)
-    assert cnt[0] == 0 and cnt[3] > 0
-    assert (rec - rec3).abs().max().item() < 5e-4      # two fp32-class evaluations of an ill-conditioned map (each within 5e-4 of the oracle)
-    eng3.close()
 
 
 def test_h2_samples_do_not_see_their_batch(emu_lib):
@@ -189,7 +151,7 @@ def test_h2_samples_do_not_see_their_batch(emu_lib):
     rec2, _ = Hh.run_engine(eng, inp, "cpu", return_flow=False)
     cnt = (C.c_int64 * 4)()
     emu_lib.tsnet_debug_counters(cnt, 1)
-    assert cnt[0] > 0                                        # the h2 schedule ran
+    assert cnt[0] > 0                                        # patch kernels ran
     one = [[t[:1] for t in x] if isinstance(x, list) else x[:1] for x in inp]
     rec1, _ = Hh.run_engine(eng, one, "cpu", return_flow=False)
     assert torch.equal(rec2[:1], rec1)
@@ -198,7 +160,7 @@ def test_h2_samples_do_not_see_their_batch(emu_lib):
 
 def test_bf16_operand_mode(emu_lib):
     """tsnet_cfg.operand_mode = 1 (BASELINE.json configs[2] / [4]): every convolution reads ONE bf16 plane of its input and of its weights
-    (conv_h2 with one product and the transform fused, conv_x3q / conv_x3r on the hi plane), fp32 accumulate."""
+    (one product, the transform fused), fp32 accumulate."""
     cfg = O.TSNetConfig(label_nc=2, n_blocks=1, n_source=1, ngf=32, enc_blocks=1, fuse_ngf=512)
     sd = O.synth_state_dict(cfg, seed=14, bias_std=0.02)
     sd = {k: (v * 2 if k.endswith("weight") else v) for k, v in sd.items()}
@@ -208,7 +170,7 @@ def test_bf16_operand_mode(emu_lib):
     rec, flows = Hh.run_engine(eng, inp, "cpu")
     cnt = (C.c_int64 * 4)()
     emu_lib.tsnet_debug_counters(cnt, 1)
-    assert cnt[0] == 15 and cnt[3] > 0 and cnt[2] == 0 and cnt[1] == 0
+    assert cnt[0] == 18 and cnt[1] == 2
     r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, 1, "cpu")
     print("[bf16 mode] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
     assert r["src_fea"] < 5e-2 and r["tar_fea"] < 2e-2 and r["sg"] < 8e-2          # bf16 flip noise on a +-18 range

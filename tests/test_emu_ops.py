@@ -6,31 +6,41 @@ import pytest
 import op_cases as oc
 
 TOL = 2e-5
-
-
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
-def test_conv_tiles(emu_lib, tile, monkeypatch):
-    """every tile of the fp32 LDS-DMA kernel (conv_dma) and, with the in-loader IN+ReLU, of the register-staged one"""
-    monkeypatch.setenv("TSNET_DMA_TILE", str(tile))
-    monkeypatch.setenv("TSNET_CONV_TILE", str(tile))
-    for norm in (False, True):
-        assert oc.conv_case(emu_lib, "cpu", 2, 11, 13, 16, 256, 3, 1, 1, True, norm=norm) < TOL
-        assert oc.conv_case(emu_lib, "cpu", 1, 20, 13, 32, 128, 3, 2, 1, False, norm=norm) < TOL
-        assert oc.conv_case(emu_lib, "cpu", 1, 9, 9, 8, 128, 7, 1, 3, True, norm=norm) < TOL
+REL = 2e-6     # conv error relative to max|fp64 reference|: fp32-class (two-level accumulation of exact fp16 x 2 products)
 
 
 @pytest.mark.parametrize("k,stride,pad,reflect", [(7, 1, 3, True), (3, 2, 1, False), (3, 1, 1, True), (1, 1, 0, False)])
 @pytest.mark.parametrize("norm", [False, True])
-def test_conv_kinds(emu_lib, k, stride, pad, reflect, norm):
-    assert oc.conv_case(emu_lib, "cpu", 2, 12, 10, 8, 24, k, stride, pad, reflect, norm=norm) < TOL
+def test_conv_kinds_general_kernel(emu_lib, k, stride, pad, reflect, norm):
+    """every layer kind of the forward on frames that do NOT split into 4 x 32 rectangles -> the general implicit GEMM (conv_h2r.hpp):
+    ragged image tiles (12 x 10 = 120 positions per image), 8 input channels (two taps per k-group) and 16 / 48 (any multiple of 16)"""
+    for cin in ((8, 48) if k != 1 else (16, 48)):
+        assert oc.conv_case(emu_lib, "cpu", 2, 12, 10, cin, 24, k, stride, pad, reflect, norm=norm) < REL
 
 
-def test_conv_head_tanh(emu_lib):
-    assert oc.conv_case(emu_lib, "cpu", 1, 8, 8, 64, 3, 7, 1, 3, True, norm=True, act=1) < TOL
+def test_conv_general_kernel_tiles_and_shapes(emu_lib):
+    """two tiles per image with a ragged second one, 128-wide tiles, more than one N tile, no bias, a transform without ReLU; the two tile
+    widths of the general kernel run the same chains (bit-identical)"""
+    assert oc.conv_case(emu_lib, "cpu", 2, 13, 11, 32, 130, 3, 1, 1, True, bias=False) < REL
+    assert oc.conv_case(emu_lib, "cpu", 1, 20, 13, 32, 128, 3, 2, 1, False, norm=True, relu=False) < REL
+    import torch
+    a = oc.conv_case(emu_lib, "cpu", 1, 9, 17, 16, 256, 3, 1, 1, True, norm=True, kernel=1, tile=64, return_output=True)
+    b = oc.conv_case(emu_lib, "cpu", 1, 9, 17, 16, 256, 3, 1, 1, True, norm=True, kernel=1, tile=128, return_output=True)
+    assert torch.equal(a, b)
 
 
-def test_conv_ragged_m_and_no_bias(emu_lib):
-    assert oc.conv_case(emu_lib, "cpu", 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL
+def test_conv_cat_on_load(emu_lib):
+    """dec.map_conv: 1x1 on cat(pg, sg) formed on load from two tensors (TSNet.py:163); also a 3x3 and a shared second tensor"""
+    assert oc.conv_cat_case(emu_lib, "cpu", 2, 4, 8, 32, 32, 48) < REL
+    assert oc.conv_cat_case(emu_lib, "cpu", 3, 5, 6, 16, 48, 24, k=3, shared=True) < REL
+
+
+@pytest.mark.parametrize("C", [8, 16, 32])
+def test_head(emu_lib, C):
+    """RGB head (head_conv.hpp): the narrow-net form (C = 8: half a 16-channel stage; C = 16) and head_conv3 (C = 32), with the composite"""
+    assert oc.head_case(emu_lib, "cpu", 1, 16, 20, C) < TOL
+    if C == 16:
+        assert oc.head_case(emu_lib, "cpu", 1, 8, 256, C, norm=False, composite=True) < TOL
 
 
 @pytest.mark.parametrize("norm", [False, True])
@@ -38,41 +48,52 @@ def test_conv_ragged_m_and_no_bias(emu_lib):
 def test_conv_h2(emu_lib, norm, reflect):
     """fp16x2 patch convolution (conv_h2.hpp): slab parity (1, 2 and 3 slabs), zero / reflection padding, fused IN + ReLU, 3 and 4 products"""
     for cin in (16, 32, 48):
-        assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, cin, 64, reflect, norm=norm) < 2e-6
-    assert oc.conv_h2_case(emu_lib, "cpu", 2, 8, 32, 32, 96, reflect, norm=norm, bias=False, nprod=4) < 2e-6
+        assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, cin, 64, reflect, norm=norm) < REL
+    assert oc.conv_h2_case(emu_lib, "cpu", 2, 8, 32, 32, 96, reflect, norm=norm, bias=False, nprod=4, tile_n=64) < REL
 
 
-def test_conv_h2_wide_tile_and_scales(emu_lib):
-    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 64, 32, 128, True, norm=True, tile_n=128) < 2e-6
-    assert oc.conv_h2_case(emu_lib, "cpu", 1, 8, 32, 32, 96, False, norm=True, tile_n=32) < 2e-6           # small-M tiles: four waves over the four patch rows
+def test_conv_h2_tile_shapes_and_scales(emu_lib):
+    import torch
+    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 64, 32, 128, True, norm=True, tile_n=128) < REL
+    assert oc.conv_h2_case(emu_lib, "cpu", 1, 8, 32, 32, 96, False, norm=True, tile_n=32) < REL           # small-M tiles: four waves over the four patch rows
+    assert oc.conv_h2_case(emu_lib, "cpu", 2, 6, 64, 32, 128, False, norm=True, tile_n=2128) < REL        # 2-row tiles (6 rows: not a multiple of 4)
+    # every tile shape runs the same chains per output element
+    ys = [oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 48, 128, True, norm=True, tile_n=t, return_output=True) for t in (32, 64, 128, 2128)]
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
     # operands far from 1: the power-of-two scales keep the fp16 planes in range (results relative to max|ref|)
-    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=300.0) < 2e-6
-    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=1e-4) < 2e-6
-
-
-def test_conv_h2r(emu_lib):
-    """conv_h2r: 3x3 / stride-2 (with and without the fused IN + ReLU) and the 7x7 stems (8 channels: two taps per k-group; 32 channels)"""
-    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 32, 16, 16, 64, 3, norm=True) < 2e-6
-    assert oc.conv_h2r_case(emu_lib, "cpu", 2, 16, 32, 32, 128, 3, norm=False, bias=False) < 2e-6
-    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 16, 8, 64, 7) < 2e-6
-    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 16, 8, 32, 64, 7) < 2e-6
+    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=300.0) < REL
+    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=1e-4) < REL
 
 
 def test_conv_h2d_stride2_patch_kernel(emu_lib):
     """3x3 / stride-2 layers whose output splits into 4 x 32 rectangles run on the patch kernel (conv_h2.hpp h2d): one, two and four slabs
-    (stage parity; the entry takes power-of-two input widths; the kernel takes layers with at least 512 output channels), zero padding at
-    all borders, with and without the fused IN + ReLU, two images / two tiles"""
+    (stage parity), zero padding at all borders, with and without the fused IN + ReLU, two images / two tiles, both workgroup shapes
+    (four waves x 64 columns, eight waves x 128 columns) -- bit-identical to each other"""
+    import torch
     for cin in (16, 32, 64):
-        assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, cin, 512, 3, norm=True, seed=cin) < 2e-6
-    assert oc.conv_h2r_case(emu_lib, "cpu", 2, 16, 64, 32, 512, 3, norm=False, bias=False) < 2e-6
-    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 128, 16, 576, 3, norm=True) < 2e-6                 # nine N-tiles, two M-tiles
+        assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, cin, 128, 3, norm=True, seed=cin, kernel=2) < REL
+    assert oc.conv_h2r_case(emu_lib, "cpu", 2, 16, 64, 32, 64, 3, norm=False, bias=False, kernel=2) < REL
+    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 128, 16, 320, 3, norm=True, kernel=2, tile=64) < REL      # five N-tiles, two M-tiles
+    a = oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, 32, 256, 3, norm=True, kernel=2, tile=64, return_output=True)
+    b = oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, 32, 256, 3, norm=True, kernel=2, tile=128, return_output=True)
+    assert torch.equal(a, b)
 
 
 def test_conv_h2s_stem_patch_kernel(emu_lib):
     """8-channel 7x7 stems on whole 4 x 32 rectangles run on the patch kernel (conv_h2.hpp h2s): reflection at all four borders (one tile
-    high / several tiles), two images, no bias"""
-    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 4, 32, 8, 64, 7) < 2e-6
-    assert oc.conv_h2r_case(emu_lib, "cpu", 2, 8, 64, 8, 64, 7, bias=False, seed=3) < 2e-6
+    high / several tiles), two images, no bias; the general kernel on the same layer agrees to rounding (different K order)"""
+    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 4, 32, 8, 64, 7, kernel=2) < REL
+    assert oc.conv_h2r_case(emu_lib, "cpu", 2, 8, 64, 8, 64, 7, bias=False, seed=3, kernel=2) < REL
+    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 4, 32, 8, 64, 7, kernel=1) < REL
+    assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 32, 32, 64, 7, kernel=0) < REL                    # 32-channel stem (pose model): general kernel
+
+
+def test_bf16_operand_convs(emu_lib):
+    """bf16-operand mode of every kernel: one plane, one product; error of bf16 rounding (2^-9 per operand)"""
+    assert oc.conv_case(emu_lib, "cpu", 1, 4, 32, 32, 64, 3, 1, 1, True, norm=True, nprod=1) < 2e-2
+    assert oc.conv_case(emu_lib, "cpu", 1, 8, 64, 16, 128, 3, 2, 1, False, norm=True, nprod=1) < 2e-2
+    assert oc.conv_case(emu_lib, "cpu", 1, 4, 32, 8, 64, 7, 1, 3, True, nprod=1) < 2e-2
+    assert oc.conv_case(emu_lib, "cpu", 1, 5, 7, 16, 24, 1, 1, 0, False, nprod=1) < 2e-2
 
 
 @pytest.mark.parametrize("C,H,W", [(8, 6, 5), (64, 16, 16), (24, 9, 3), (1024, 2, 2)])
@@ -110,31 +131,3 @@ def test_flow_many_tiles(emu_lib):
 
 def test_warp_out_of_range(emu_lib):
     assert oc.warp_case(emu_lib, "cpu", 2, 5, 6, 16) < TOL
-
-
-def test_conv_x3_patch_kernel(emu_lib):
-    """conv_x3p.hpp x3q (weights fetched into registers, input patch resident in LDS, taps as shifted views): tiles 14 (128 x 128) and
-    15 (128 x 64); reflection and zero padding, one and several 16-channel slabs, several tiles per row / per image / per batch.
-    (The superseded generations -- LDS-DMA tiles 0..10, x3p 11..13 -- are only in the tools build, tools/x3_ablate.py.)"""
-    assert oc.conv_x3_case(emu_lib, "cpu", 2, 8, 32, 16, 128, 3, 1, 1, True, tile=14) < TOL
-    assert oc.conv_x3_case(emu_lib, "cpu", 1, 4, 64, 64, 256, 3, 1, 1, False, tile=14) < TOL
-    assert oc.conv_x3_case(emu_lib, "cpu", 1, 8, 32, 32, 64, 3, 1, 1, True, tile=15, bias=False) < TOL
-    assert oc.conv_x3_case(emu_lib, "cpu", 1, 4, 32, 32, 192, 3, 1, 1, False, tile=15) < TOL
-    # same arithmetic per output element whatever the launch shape
-    assert oc.conv_x3_tiles_bitwise(emu_lib, "cpu", 3, 4, 32, 32, 256, (14, 15)) == 0.0
-
-
-def test_conv_x3r_register_staged(emu_lib):
-    """conv_x3r.hpp (tiles 16, 17, 18 = 128 / 64 / 32 wide): A tile staged through registers, weights fetched into registers; every
-    kind of layer the patch kernels do not take; the tiles of the family are bit-identical"""
-    for tile in (16, 17, 18):
-        assert oc.conv_x3_case(emu_lib, "cpu", 2, 11, 13, 16, 256, 3, 1, 1, True, tile=tile) < TOL
-        assert oc.conv_x3_case(emu_lib, "cpu", 1, 20, 13, 32, 128, 3, 2, 1, False, tile=tile) < TOL
-        assert oc.conv_x3_case(emu_lib, "cpu", 1, 9, 9, 8, 128, 7, 1, 3, True, tile=tile) < TOL
-        assert oc.conv_x3_case(emu_lib, "cpu", 3, 6, 5, 128, 192, 1, 1, 0, False, tile=tile, bias=False) < TOL
-    assert oc.conv_x3_tiles_bitwise(emu_lib, "cpu", 2, 9, 11, 32, 128, (16, 17, 18)) == 0.0
-
-
-def test_conv_x3_1x1_and_ragged(emu_lib):
-    assert oc.conv_x3_case(emu_lib, "cpu", 3, 6, 5, 128, 160, 1, 1, 0, False) < TOL
-    assert oc.conv_x3_case(emu_lib, "cpu", 3, 5, 7, 32, 130, 3, 1, 1, True, bias=False) < TOL

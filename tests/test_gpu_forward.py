@@ -107,7 +107,9 @@ def test_cfg0_batch_items_independent(cfg0):
     sl = slice(1, 3)
     sub = ([x[sl] for x in inputs[0]], [x[sl] for x in inputs[1]], [x[sl] for x in inputs[2]], inputs[3][sl], inputs[4][sl])
     r, _ = Hh.run_engine(eng, sub, DEV)
-    assert (r - rec[sl]).abs().max().item() <= 1e-6
+    # the same bits: every tile shape of a kernel runs the same chains per output, statistics partials are per (image, tile) and added
+    # in a fixed order, operand scales are per image
+    assert torch.equal(r, rec[sl])
 
 
 def test_model_shell_matches_engine(cfg0):
@@ -212,7 +214,9 @@ def test_packed_weight_buffer_goes_through_rccl(cfg0):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     try:
         buf = eng.packed_weights(DEV)
-        assert buf.dtype == torch.uint8 and buf.numel() > 3 * 67_000_000      # fp32 packings + bf16x3 planes of 67 M weights
+        # what a replica receives is what its kernels read: two fp16 planes of the 67 M weights (+ K / N padding), the RGB-head table,
+        # biases and the per-layer un-scale factors -- nothing else (<= 300 MB)
+        assert buf.dtype == torch.uint8 and 4 * 67_000_000 < buf.numel() < 300_000_000
         dist.broadcast(buf, src=0)
         torch.cuda.synchronize()
     finally:

@@ -56,7 +56,7 @@ def _tiny(emu_lib, **kw):
 
 
 def test_create_rejects_bad_configs(emu_lib):
-    for kw in (dict(n_source=0), dict(n_source=9), dict(ngf=48), dict(height=100), dict(max_batch=0),
+    for kw in (dict(n_source=0), dict(n_source=9), dict(ngf=48), dict(ngf=4), dict(height=100), dict(max_batch=0),
                dict(pose_composite=True, height=128, width=128), dict(n_downsampling=0)):
         base = dict(label_nc=2, n_blocks=0)
         base.update(kw)

@@ -1,0 +1,60 @@
+"""GPU box: in-run A/B of the patch-convolution variants (tools build, python -m wacv23_tsnet_amd.build --tools).
+
+Per layer shape, every variant is timed in interleaved rounds inside ONE process (cdna_hip_programming.md rule 24) and the median
+reported.  variant code of tsnet_bench_conv: tile | general kernel << 12 | ablation mask << 16 | experiment mask << 24.
+  experiment mask (h2_tile OPT): 1 = legacy staging arithmetic (select + scalar converts), 2 = rotating wave priority
+  ablation mask  (h2_tile HABL, computes garbage): 1 no patch staging, 2 weights once, 4 A fragments once, 8 no fold, 16 no barrier
+usage: h2_variants.py [rounds]"""
+import ctypes as C, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wacv23_tsnet_amd import _lib
+lib = _lib.load_tools()
+torch.zeros(1, device="cuda")
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+
+
+def code(tile=0, general=False, abl=0, opt=0):
+    return tile | (4096 if general else 0) | (abl << 16) | (opt << 24)
+
+
+def run(name, shape, variants, norms=(0, 1), iters=8):
+    N, H, W, Cin, Cout, k, s, p, refl = shape
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
+    res = {}
+    for r in range(rounds):
+        for vn, v in variants:
+            for nrm in norms:
+                ms = C.c_float()
+                rc = lib.tsnet_bench_conv(N, H, W, Cin, Cout, k, s, p, refl, nrm, v, iters, C.byref(ms), None)
+                res.setdefault((vn, nrm), []).append(ms.value if rc == 0 else float("nan"))
+                if rc != 0 and r == 0:
+                    print("   ERR", vn, lib.tsnet_op_last_error().decode())
+    print(f"{name}: M={N*Ho*Wo} N={Cout} K={Cin*k*k} {flops/1e9:.1f} GFLOP")
+    for (vn, nrm), t in res.items():
+        med = statistics.median(t)
+        print(f"   {vn:28s} {'IN+ReLU' if nrm else 'raw    '}  {med*1e3:8.1f} us  {flops/med/1e9:7.1f} TF   (min {min(t)*1e3:.1f} max {max(t)*1e3:.1f})", flush=True)
+
+
+RES = (12, 32, 32, 512, 512, 3, 1, 1, 1)
+run("res (ResnetBlock conv, B=4 K=3)", RES,
+    [("4x64", code(64)), ("4x64 legacy-staging", code(64, opt=1)), ("4x64 prio", code(64, opt=2)), ("4x64 legacy+prio", code(64, opt=3)),
+     ("4x128", code(128)), ("4x128 legacy-staging", code(128, opt=1)), ("2x128", code(2128)), ("2x128 prio", code(2128, opt=2)), ("4x32", code(32))])
+run("res ablations 4x64", RES,
+    [("full", code(64))] + [(f"abl{m}", code(64, abl=m)) for m in (1, 2, 4, 7, 8, 16, 15, 31)], norms=(0,))
+run("res ablations 2x128", RES, [("full", code(2128))] + [(f"abl{m}", code(2128, abl=m)) for m in (1, 2, 7)], norms=(0,))
+run("res B=1 (3 images)", (3, 32, 32, 512, 512, 3, 1, 1, 1), [("4x32", code(32)), ("4x64", code(64)), ("2x128", code(2128))])
+run("fuse_c2 (1024->1024)", (12, 32, 32, 1024, 1024, 3, 1, 1, 1),
+    [("4x64", code(64)), ("4x128", code(128)), ("4x128 legacy-staging", code(128, opt=1)), ("2x128", code(2128)), ("2x128 prio", code(2128, opt=2))])
+run("fuse_c1_src (512->1024)", (12, 32, 32, 512, 1024, 3, 1, 1, 1), [("4x64", code(64)), ("4x128", code(128)), ("2x128", code(2128))], norms=(0,))
+run("dec_up0 (512->256 @64^2)", (4, 64, 64, 512, 256, 3, 1, 1, 1), [("4x64", code(64)), ("4x128", code(128)), ("2x128", code(2128))], norms=(0,))
+run("dec_up1 (256->128 @128^2)", (4, 128, 128, 256, 128, 3, 1, 1, 1), [("4x64", code(64)), ("4x128", code(128)), ("2x128", code(2128))], norms=(0,))
+run("dec_up2 (128->64 @256^2)", (4, 256, 256, 128, 64, 3, 1, 1, 1), [("4x32", code(32)), ("4x64", code(64))], norms=(0,))
+for nm, shp in (("down1 (64->128)", (12, 256, 256, 64, 128, 3, 2, 1, 0)), ("down2 (128->256)", (12, 128, 128, 128, 256, 3, 2, 1, 0)),
+                ("down3 (256->512)", (12, 64, 64, 256, 512, 3, 2, 1, 0))):
+    run(nm, shp, [("h2d 4 waves x 64", code(64)), ("h2d 8 waves x 128", code(128)), ("general 64", code(64, general=True)),
+                  ("general 128", code(128, general=True))], norms=(1,))
+run("stem (8->64, 7x7)", (12, 256, 256, 8, 64, 7, 1, 3, 1), [("h2s", code(0)), ("general", code(64, general=True))], norms=(0,))
+run("stem pose (32->64, 7x7)", (12, 256, 256, 32, 64, 7, 1, 3, 1), [("general", code(0))], norms=(0,))
+run("1x1 (1024->512)", (4, 32, 32, 1024, 512, 1, 1, 0, 0), [("general 64", code(64))], norms=(0,))

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "tsnet_last_error", "tsnet_num_params", "tsnet_param_info", "tsnet_packed_weights",
     "tsnet_forward", "tsnet_set_source_divisors", "tsnet_set_sources", "tsnet_forward_target", "tsnet_train_extras", "tsnet_stage_ptr",
     "tsnet_forward_macs", "tsnet_timing_enable", "tsnet_timing_read",
-    "tsnet_op_conv2d", "tsnet_op_conv2d_x3", "tsnet_op_conv2d_h2", "tsnet_op_conv2d_h2r", "tsnet_op_instnorm_stats", "tsnet_op_norm_act", "tsnet_op_upsample2x",
+    "tsnet_op_conv2d", "tsnet_op_conv2d_cat", "tsnet_op_head", "tsnet_op_instnorm_stats", "tsnet_op_norm_act", "tsnet_op_upsample2x",
     "tsnet_op_flow", "tsnet_op_warp", "tsnet_op_last_error", "tsnet_frame_stats", "tsnet_demo_postprocess", "tsnet_raster_face", "tsnet_vl2ch", "tsnet_raster_pose", "tsnet_label_bbox", "tsnet_resize_pad", "tsnet_bench_conv", "tsnet_debug_counters", "tsnet_linspace", "tsnet_coord_table",
 )
 
@@ -70,10 +70,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.tsnet_timing_enable.argtypes = [_vp, C.c_int]
     lib.tsnet_timing_read.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     lib.tsnet_op_conv2d.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]
-    lib.tsnet_op_conv2d_x3.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
-    lib.tsnet_op_conv2d_h2.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_float, C.c_int, C.c_int, _vp, _vp]
-    lib.tsnet_op_conv2d_h2r.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_float, C.c_int, _vp, _vp]
+                                    C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _vp, _vp]
+    lib.tsnet_op_conv2d_cat.argtypes = [_vp, _vp] + [C.c_int] * 6 + [_vp, _vp] + [C.c_int] * 5 + [C.c_float, C.c_int, _vp, _vp]
+    lib.tsnet_op_head.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _fp, _vp, _vp]
     lib.tsnet_op_instnorm_stats.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]
     lib.tsnet_op_norm_act.argtypes = [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
     lib.tsnet_op_upsample2x.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
@@ -123,6 +122,6 @@ def load() -> C.CDLL:
         _cached = bind(C.CDLL(LIB_PATH))
     except OSError as e:  # pragma: no cover - depends on the machine
         raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
-    if _cached.tsnet_abi_version() != 2:
+    if _cached.tsnet_abi_version() != 3:
         raise RuntimeError("libtsnet_hip.so ABI version mismatch; rebuild")
     return _cached

@@ -1,0 +1,103 @@
+// conv_h2_launch.cpp -- instantiations and launchers of the patch convolution kernels (conv_h2.hpp).
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <utility>
+
+#include "conv_h2.hpp"
+#include "kernels.hpp"
+
+namespace tsnet {
+
+void ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return;
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = done[std::make_pair(kernel, dev)];
+    if (have >= bytes) return;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: ") + hipGetErrorString(e));
+    have = bytes;
+}
+
+namespace {
+
+template <int PR, int BN, int WM, int WN, int NPROD, int HABL = 0, int OPT = 0>
+void go_h2(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)h2_lds_bytes(PR, a.Cin);
+    if (a.in_alpha) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2_kernel<PR, BN, WM, WN, NPROD, true, HABL, OPT>), lds);
+        hipLaunchKernelGGL((conv_h2_kernel<PR, BN, WM, WN, NPROD, true, HABL, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    } else {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2_kernel<PR, BN, WM, WN, NPROD, false, HABL, OPT>), lds);
+        hipLaunchKernelGGL((conv_h2_kernel<PR, BN, WM, WN, NPROD, false, HABL, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    }
+}
+
+template <int NPROD>
+void go_h2_shape(const ConvArgs& a, int pr, int bn, hipStream_t s) {
+    if (pr == 4 && bn == 32) go_h2<4, 32, 4, 1, NPROD>(a, s);
+    else if (pr == 4 && bn == 64) go_h2<4, 64, 2, 2, NPROD>(a, s);
+    else if (pr == 4 && bn == 128) go_h2<4, 128, 2, 2, NPROD>(a, s);
+    else if (pr == 2 && bn == 128) go_h2<2, 128, 1, 4, NPROD>(a, s);
+    else throw std::invalid_argument("conv(h2): tile must be 4x32, 4x64, 4x128 or 2x128");
+}
+
+template <int BN, int NWV, int NPROD>
+void go_h2d(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)kH2dLds + (size_t)2 * a.Cin * 4;
+    if (a.in_alpha) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NWV, NPROD, true>), lds);
+        hipLaunchKernelGGL((conv_h2d_kernel<BN, NWV, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(64 * NWV), lds, s, a);
+    } else {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NWV, NPROD, false>), lds);
+        hipLaunchKernelGGL((conv_h2d_kernel<BN, NWV, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(64 * NWV), lds, s, a);
+    }
+}
+
+}  // namespace
+
+void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int opt, hipStream_t s) {
+    if (abl || opt) {
+#ifdef TSNET_TOOLS
+        // experiment / ablation instantiations (tools/h2_variants.py, tools/x3_ablate.py): 3 products, raw or transformed input
+        if (nprod != 3) throw std::invalid_argument("conv(h2): experiment variants are built for three products");
+#define TSNET_H2_VAR(PR_, BN_, WM_, WN_, A_, O_) if (pr == PR_ && bn == BN_ && abl == A_ && opt == O_) { go_h2<PR_, BN_, WM_, WN_, 3, A_, O_>(a, s); return; }
+        TSNET_H2_VAR(4, 64, 2, 2, 0, 1) TSNET_H2_VAR(4, 64, 2, 2, 0, 2) TSNET_H2_VAR(4, 64, 2, 2, 0, 3)
+        TSNET_H2_VAR(4, 128, 2, 2, 0, 1) TSNET_H2_VAR(2, 128, 1, 4, 0, 2)
+        TSNET_H2_VAR(4, 64, 2, 2, 1, 0) TSNET_H2_VAR(4, 64, 2, 2, 2, 0) TSNET_H2_VAR(4, 64, 2, 2, 4, 0) TSNET_H2_VAR(4, 64, 2, 2, 7, 0)
+        TSNET_H2_VAR(4, 64, 2, 2, 8, 0) TSNET_H2_VAR(4, 64, 2, 2, 16, 0) TSNET_H2_VAR(4, 64, 2, 2, 15, 0) TSNET_H2_VAR(4, 64, 2, 2, 31, 0)
+        TSNET_H2_VAR(2, 128, 1, 4, 1, 0) TSNET_H2_VAR(2, 128, 1, 4, 2, 0) TSNET_H2_VAR(2, 128, 1, 4, 7, 0)
+#undef TSNET_H2_VAR
+        throw std::invalid_argument("conv(h2): this experiment variant is not instantiated");
+#else
+        throw std::invalid_argument("conv(h2): experiment / ablation variants are only built into the tools library");
+#endif
+    }
+    if (nprod == 3) go_h2_shape<3>(a, pr, bn, s);
+    else if (nprod == 1) go_h2_shape<1>(a, pr, bn, s);
+    else if (nprod == 4) {
+        if (pr == 4 && bn == 64) go_h2<4, 64, 2, 2, 4>(a, s);
+        else if (pr == 4 && bn == 128) go_h2<4, 128, 2, 2, 4>(a, s);
+        else throw std::invalid_argument("conv(h2): four products on 4x64 or 4x128 tiles");
+    } else throw std::invalid_argument("conv(h2): 1 (bf16 operands), 3 or 4 products");
+}
+
+void launch_conv_h2s(const ConvArgs& a, int nprod, hipStream_t s) {
+    if (nprod == 3) hipLaunchKernelGGL((conv_h2s_kernel<3>), dim3(a.tiles_m * a.tiles_n), dim3(256), kH2sLds, s, a);
+    else if (nprod == 1) hipLaunchKernelGGL((conv_h2s_kernel<1>), dim3(a.tiles_m * a.tiles_n), dim3(256), kH2sLds, s, a);
+    else throw std::invalid_argument("conv(h2s): 1 (bf16 operands) or 3 products");
+}
+
+void launch_conv_h2d(const ConvArgs& a, int bn, int nprod, hipStream_t s) {
+    if (nprod != 1 && nprod != 3) throw std::invalid_argument("conv(h2d): 1 (bf16 operands) or 3 products");
+    if (bn == 64) { if (nprod == 3) go_h2d<64, 4, 3>(a, s); else go_h2d<64, 4, 1>(a, s); }
+    else if (bn == 128) { if (nprod == 3) go_h2d<128, 8, 3>(a, s); else go_h2d<128, 8, 1>(a, s); }
+    else throw std::invalid_argument("conv(h2d): tile width must be 64 (four waves) or 128 (eight waves)");
+}
+
+}  // namespace tsnet

@@ -1,22 +1,22 @@
 // engine.cpp -- host side of the TS-Net forward engine behind include/tsnet_abi.h.
 //
-// Compiled with hipcc for gfx950 (the product) and, by tests only, with a host compiler against
-// tests/emu's HIP emulation headers so the launch geometry / indexing logic of every kernel can be
-// checked against the oracle without a GPU.  There is no CPU fallback in the product: every entry
-// point launches HIP kernels and reports HIP failures through tsnet_last_error.
+// Compiled with hipcc for gfx950 (the product) and, by tests only, with a host compiler against tests/emu's HIP emulation headers so
+// that the launch geometry / indexing logic of every kernel can be checked against the oracle without a GPU.  There is no CPU fallback
+// in the product: every entry point launches HIP kernels and reports HIP failures through tsnet_last_error.
 //
-// Schedule of one forward (reference: model/TSNet.py:309-407), NHWC fp32 throughout, the K sources
-// batched into one launch per layer (image index n = s*B + b):
+// ONE schedule (reference: model/TSNet.py:309-407), NHWC fp32 activations throughout, the K sources batched into one launch per layer
+// (image index n = s*B + b):
 //   pack_input -> img_enc (stem 7x7, 3 stride-2 convs, 9 ResnetBlocks)           [A2, A4]
-//   pack_input -> lbl_enc (stem + 3 stride-2 convs)                              [A3]
-//   l2norm x2 -> flow_kernel -> warp_mean_kernel                                 [A5, A6]
-//   fuse conv1 (cat on load) -> conv2 -> residual+mean -> 1x1 conv               [A7, A6]
+//   pack_input -> lbl_enc (stem + 3 stride-2 convs)                              [A3]      (side stream)
+//   l2norm x2 -> flow_kernel -> warp_mean_kernel                                 [A5, A6]  (side stream)
+//   fuse conv1 (per-source half + shared target half) -> conv2 -> residual+mean -> 1x1 conv   [A7, A6]
 //   dec map 1x1 (cat on load) -> ResnetBlocks -> 3x (upsample, conv) -> 7x7+tanh [A8, A9]
-// Convolutions run on the bf16x3 kernels by default (every conv input as three bf16 planes written by its
-// producer): conv_x3p.hpp x3q tiles for 3x3 / stride 1, conv_x3r.hpp / conv_x3.hpp for the rest; TSNET_X3=0
-// selects the exact-fp32 MFMA schedule (conv_dma.hpp).  InstanceNorm is split: fp64 partial sums in the
-// producing conv's epilogue (finalised there by the last-arriving workgroup, or by in_finalize2), the
-// normalise + ReLU + bf16x3 split in one elementwise pass (norm_act / upsample2x) that feeds the next conv.
+// Every convolution reads the producer's RAW fp32 output and applies that producer's InstanceNorm + ReLU while it stages its operand
+// tile; operands enter the matrix pipe as fp16 x 2 splits (three products) or, with tsnet_cfg.operand_mode = 1, as one bf16 plane.
+// Which kernel a layer runs on (patch kernels of conv_h2.hpp where the output splits into 4 x 32 rectangles, the general implicit GEMM of
+// conv_h2r.hpp elsewhere) depends on the layer and the frame size only -- never on the batch, never on the environment.
+// InstanceNorm statistics: fp64 partial sums in the producing conv's epilogue, finalised there by the last-arriving workgroup
+// (or by in_finalize2 when an image has many tiles).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -30,15 +30,11 @@
 #include <vector>
 
 #include "../../include/tsnet_abi.h"
-#include "conv_dma.hpp"
-#include "conv_igemm.hpp"
-#include "conv_x3.hpp"
-#include "conv_x3p.hpp"
-#include "conv_x3r.hpp"
-#include "conv_h2.hpp"
+#include "kernels.hpp"
 #include "flow_warp.hpp"
 #include "head_conv.hpp"
 #include "norm_elementwise.hpp"
+#include "pack_weights.hpp"
 #include "postproc.hpp"
 #include "raster.hpp"
 #include "train_extras.hpp"
@@ -48,7 +44,7 @@ using namespace tsnet;
 namespace {
 
 thread_local std::string g_op_error;
-int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] conv_h2, [1] conv_igemm, [2] conv_dma, [3] conv_x3
+int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] patch kernels (conv_h2.hpp), [1] general kernel (conv_h2r.hpp), [2] RGB head, [3] unused
 std::string g_create_error;
 
 #define HIP_TRY(expr)                                                                               \
@@ -142,7 +138,6 @@ inline int pack_grid(int hw) {
     if (g > 128) g = 128;
     return g < 1 ? 1 : g;
 }
-
 // ------------------------------------------------------------------------------------------------
 // convolution layer description + launch
 struct ConvLayer {
@@ -151,418 +146,41 @@ struct ConvLayer {
     int cin_real = 0, cin_pad = 0, cout = 0, ks = 1, stride = 1, pad = 0, reflect = 0;
     int cin_total = 0, cin_off = 0;   // window of the parameter's input channels this layer consumes
     int kpad = 0, npad = 0;
-    size_t w_off = 0, w2_off = 0, b_off = 0;  // offsets (floats) into the packed buffer
-    const float* w = nullptr;     // device, packed for conv_igemm_kernel  [K/4][Npad][4]
-    const float* w2 = nullptr;    // device, packed for conv_dma_kernel    [K/16][Npad][4 swizzled quads][4]
-    const unsigned short* w3 = nullptr;   // device, bf16x3 planes for conv_x3_kernel [3][K/16][Npad][2 octets][8]
-    const float* bias = nullptr;  // device (cout)
-    const unsigned short* wh = nullptr;   // device, fp16x2 planes for conv_h2_kernel [2][K/16][Npad][2 octets][8] of w * 2^sw, or null
-    const float* wh_unscale = nullptr;    // device scalar 2^-sw (in the packed buffer: replicas receive it with the broadcast)
+    size_t w_off = 0, b_off = 0;          // offsets into the packed buffer: operand planes (16-bit units from the plane section), bias (floats)
+    const unsigned short* wq = nullptr;   // device: operand planes [planes][K/16][Npad][2 octets][8] (conv_common.hpp pack_weights_kernel)
+    const float* w_unscale = nullptr;     // device scalar 2^-sw (in the packed buffer: replicas receive it with the broadcast); null in bf16 mode
+    const float* bias = nullptr;          // device (cout)
 };
 
 constexpr size_t kFinCounterInts = 65536;   // size of the arrival-counter arrays of the in-kernel statistics finalize
-constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded to an even number of 16-deep chunks (ring prefetch may run one past the end)
-constexpr int FLUSH_K = 64;      // fold the MFMA chain into the running total every 64 products (conv_igemm.hpp)
+constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded to an even number of 16-deep chunks (fragment prefetch runs up to two past the end)
 
 inline int conv_kpad(int ks, int cin_pad) { return round_up(ks * ks * cin_pad, KPAD_ALIGN); }
-inline int conv_npad(int cout) { return cout >= 128 ? round_up(cout, 128) : round_up(cout, 32); }
+inline int conv_npad(int cout) { return cout >= 128 ? round_up(cout, 128) : round_up(cout, 64); }
+inline int conv_cin_pad(int cin) { return cin <= 8 ? 8 : round_up(cin, 16); }     // 8 (two taps per k-group) or a multiple of 16
 
 struct ConvCall {
-    const float* x = nullptr; const float* x2 = nullptr;
-    int N = 0, H = 0, W = 0;
+    const float* x = nullptr; const float* x2 = nullptr;      // x2: channels >= csplit come from a second tensor (torch.cat on load), image n % x2_nmod
     int csplit = 0, x2_nmod = 1;
-    const float* alpha = nullptr; const float* beta = nullptr; int in_relu = 0;
-    float* y = nullptr; int act = 0; int out_nchw = 0;
-    int composite = 0; float bg[3] = {0, 0, 0};
-    int variant = -1;      // -1 = heuristic; else tile index + 8*(BK==32)   (bench / test hook)
-    const float* addend = nullptr; int add_nmod = 1;   // y += addend[img % add_nmod] (conv_dma only)
-    double* stat_part = nullptr;   // in: where the conv epilogue may leave InstanceNorm partials of y
-    mutable int stat_S = 0;        // out: partials per image actually written (0 = none: run the stats kernel)
-};
-
-struct TileCfg { int bm, bn, wm, wn; double eff; };
-// register-staged kernel (conv_igemm.hpp): kept for convs that apply IN+ReLU in the loader (op tests) and as the
-// fallback for tensors too large for 32-bit buffer offsets
-const TileCfg kTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.93}, {64, 64, 2, 2, 0.8}, {128, 32, 4, 1, 0.7}};
-constexpr int kNumTiles = 4;
-constexpr int BK = 16;
-
-template <int KS, int BM, int BN, int WM_, int WN_>
-void launch_conv_t(const ConvArgs& a, hipStream_t s) {
-    constexpr int KQ = BK / 4, PAD = 8 / KQ;
-    const size_t lds = (size_t)2 * KQ * ((BM + PAD) + (BN + PAD)) * 16;
-    hipLaunchKernelGGL((conv_igemm_kernel<KS, BM, BN, BK, WM_, WN_, FLUSH_K / BK>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
-}
-
-// Tile choice: minimise (sequential tiles per CU) x (tile area) / efficiency.  The 256 CUs each run
-// ceil(tiles/256) tiles back to back (co-resident blocks share the MFMA pipe, so residency does not
-// change this count), which makes tile-count quantisation the first-order term at B=4.
-template <int KS>
-void launch_conv_ks(const ConvArgs& a0, int forced, hipStream_t s) {
-    ConvArgs a = a0;
-    int best = forced >= 0 ? (forced & 7) : -1;
-    if (best < 0) {
-        const char* e_tile = getenv("TSNET_CONV_TILE");   // test / tuning hook
-        double best_cost = 0;
-        for (int i = 0; i < kNumTiles; ++i) {
-            if (a.Npad % kTiles[i].bn) continue;
-            if (e_tile && atoi(e_tile) == i) { best = i; break; }
-            if (kTiles[i].bn > 32 && a.Cout <= kTiles[i].bn / 2) continue;   // don't waste half the columns
-            const long tm = (a.M + kTiles[i].bm - 1) / kTiles[i].bm, tn = (a.Cout + kTiles[i].bn - 1) / kTiles[i].bn;
-            const double cost = (double)((tm * tn + 255) / 256) * kTiles[i].bm * kTiles[i].bn / kTiles[i].eff;
-            if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
-        }
-    }
-    if (best < 0 || best >= kNumTiles || a.Npad % kTiles[best].bn) throw ArgError("conv: no tile configuration for the padded width");
-    a.tiles_m = (a.M + kTiles[best].bm - 1) / kTiles[best].bm;
-    a.tiles_n = (a.Cout + kTiles[best].bn - 1) / kTiles[best].bn;
-    a.nchunks = (a.taps * a.Cin + BK - 1) / BK;
-    switch (best) {
-        case 0: launch_conv_t<KS, 128, 128, 2, 2>(a, s); break;
-        case 1: launch_conv_t<KS, 128, 64, 2, 2>(a, s); break;
-        case 2: launch_conv_t<KS, 64, 64, 2, 2>(a, s); break;
-        default: launch_conv_t<KS, 128, 32, 4, 1>(a, s); break;
-    }
-}
-
-// buffer-descriptor LDS-DMA kernel on the fp32 MFMA (conv_dma.hpp)
-struct GTileCfg { int bm, bn, wm, wn; double eff; };
-// eff = measured per-tile efficiency relative to 128x128 (gpurun sweep4, profiles/round1_notes.md)
-const GTileCfg kDTiles[] = {{128, 128, 2, 2, 1.0}, {128, 64, 2, 2, 0.99}, {64, 64, 2, 2, 0.96}, {128, 32, 2, 1, 0.7}};
-constexpr int kNumDTiles = 4;
-
-template <int KS, int BM, int BN, int WM_, int WN_>
-void launch_dma_t(const DmaArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)4 * (BM + BN) * 4 * 16;
-    const bool small = a.Cin < 16;
-    auto kern = small ? conv_dma_kernel<KS, BM, BN, WM_, WN_, true> : conv_dma_kernel<KS, BM, BN, WM_, WN_, false>;
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
-}
-
-template <int KS>
-int launch_dma_ks(DmaArgs a, int forced_tile, hipStream_t s) {   // returns stats partials per image (0 = none)
-    int best = forced_tile;
-    if (best < 0) {
-        const char* e_tile = getenv("TSNET_DMA_TILE");
-        double best_cost = 0;
-        for (int i = 0; i < kNumDTiles; ++i) {
-            if (a.Npad % kDTiles[i].bn) continue;
-            if (e_tile && atoi(e_tile) == i) { best = i; break; }
-            if (kDTiles[i].bn > 32 && a.Cout <= kDTiles[i].bn / 2) continue;
-            const long tm = (a.M + kDTiles[i].bm - 1) / kDTiles[i].bm, tn = (a.Cout + kDTiles[i].bn - 1) / kDTiles[i].bn;
-            const double cost = (double)((tm * tn + 255) / 256) * kDTiles[i].bm * kDTiles[i].bn / kDTiles[i].eff;
-            if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
-        }
-    }
-    if (best < 0 || best >= kNumDTiles || a.Npad % kDTiles[best].bn) throw ArgError("conv(dma): no tile configuration");
-    a.tiles_m = (a.M + kDTiles[best].bm - 1) / kDTiles[best].bm;
-    a.tiles_n = (a.Cout + kDTiles[best].bn - 1) / kDTiles[best].bn;
-    const int hw = a.Ho * a.Wo;
-    if (hw % kDTiles[best].bm) a.stat_part = nullptr;      // a tile would straddle two images: statistics stay separate
-    switch (best) {
-        case 0: launch_dma_t<KS, 128, 128, 2, 2>(a, s); break;
-        case 1: launch_dma_t<KS, 128, 64, 2, 2>(a, s); break;
-        case 2: launch_dma_t<KS, 64, 64, 2, 2>(a, s); break;
-        default: launch_dma_t<KS, 128, 32, 2, 1>(a, s); break;
-    }
-    return a.stat_part ? hw / kDTiles[best].bm : 0;
-}
-
-// ---- bf16x3 kernel (conv_x3.hpp)
-struct XTileCfg { int bm, bn, wm, wn, kc, nstage; double eff; bool patch = false; };
-// eff: per-tile efficiency relative to 128x128 measured by tools/conv_sweep.py (profiles/round1_notes.md); 0 = sweep only
-// Tiles 0..13 are the superseded generations (conv_x3.hpp LDS-DMA tiles, conv_x3p.hpp x3p / mixed launch): kept for the sweep and
-// ablation tools, compiled only into the tools build (-DTSNET_TOOLS -> lib/libtsnet_tools.so); the product library has 14..17.
-#ifdef TSNET_TOOLS
-#define TSNET_OLD_EFF(x) (x)
-#else
-#define TSNET_OLD_EFF(x) 0.0
-#endif
-const XTileCfg kXTiles[] = {{128, 128, 2, 2, 1, 3, TSNET_OLD_EFF(1.0)}, {128, 128, 2, 2, 1, 4, 0.0}, {128, 128, 2, 2, 2, 3, 0.0},
-                            {128, 128, 4, 2, 2, 3, 0.0}, {128, 64, 2, 2, 1, 4, TSNET_OLD_EFF(0.55)}, {64, 64, 2, 2, 1, 4, TSNET_OLD_EFF(0.52)},
-                            {64, 128, 2, 2, 1, 4, TSNET_OLD_EFF(0.62)}, {96, 128, 1, 4, 1, 3, TSNET_OLD_EFF(0.81)}, {128, 32, 4, 1, 1, 4, TSNET_OLD_EFF(0.3)},
-                            {128, 128, 4, 2, 1, 3, 0.0}, {128, 128, 2, 4, 1, 3, 0.0},
-                            // conv_x3p.hpp, LDS-resident input patch.  11-13: x3p (weights through an LDS-DMA ring; 13 = mixed
-                            // 128/64 launch).  14, 15: x3q (weights in registers), the default for 3x3 / stride 1 on the bf16x3 schedule
-                            {128, 128, 2, 2, 1, 3, 0.0, true}, {128, 64, 2, 2, 1, 3, 0.0, true}, {128, 128, 2, 2, 1, 3, 0.0, true},
-                            {128, 128, 2, 2, 1, 3, 1.4, true}, {128, 64, 2, 2, 1, 3, 1.25, true},
-                            // 16, 17: conv_x3r.hpp (register-staged A tile, weights in registers), same arithmetic as 0..10
-                            {128, 128, 2, 2, 1, 2, 1.02}, {128, 64, 2, 2, 1, 2, 0.75},
-                            // 18: conv_x3r.hpp with 32-wide tiles (narrow layers: Cout <= 32)
-                            {128, 32, 4, 1, 1, 2, 0.3}};
-constexpr int kNumXTiles = 19;
-
-#ifdef TSNET_TOOLS
-template <int KS, int BM, int BN, int WM_, int WN_, int KC, int NST>
-void launch_x3_t(const X3Args& a, hipStream_t s) {
-    const size_t lds = (size_t)NST * ((size_t)KC * 3 * (BM + BN) * 32 + 1024);
-    const bool small = a.Cin < 16;
-    auto kern = small ? conv_x3_kernel<KS, BM, BN, WM_, WN_, KC, NST, true> : conv_x3_kernel<KS, BM, BN, WM_, WN_, KC, NST, false>;
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WM_ * WN_), lds, s, a);
-}
-
-#endif
-
-// conv_x3p.hpp applies to 3x3 / stride 1 / pad 1 layers whose output splits into 4 x 32 rectangles
-template <int KS>
-bool x3p_ok(const X3Args& a) {
-    return KS == 3 && a.stride == 1 && a.pad == 1 && a.Cin >= 16 && (a.Cin & 15) == 0 && (a.Csplit & 15) == 0 &&
-           a.Ho % kPatchRows == 0 && a.Wo % kPatchCols == 0 && a.H == a.Ho && a.W == a.Wo;
-}
-
-#ifdef TSNET_TOOLS
-template <int BN, int WM_, int WN_>
-void launch_x3p(const X3Args& a, hipStream_t s) {
-    const size_t lds = 2 * 3 * 7 * 1024 + 3 * 3 * (size_t)BN * 32 + 1024;
-    auto kern = conv_x3p_kernel<BN, WM_, WN_>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-}
-
-#endif
-
-template <int BN, int WM_, int WN_>
-void launch_x3q(const X3Args& a, hipStream_t s, int np) {      // np = 1: bf16-operand mode (hi plane only)
-    const size_t lds = 2 * 3 * 7 * 1024 + 1024;
-    if (np == 1) hipLaunchKernelGGL((conv_x3q_kernel<BN, WM_, WN_, 0, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_x3q_kernel<BN, WM_, WN_>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-}
-
-#ifdef TSNET_TOOLS
-// a.tiles_n counts 128-wide units; the last `nsplit` units run as two 128 x 64 halves (conv_x3p_mixed_kernel)
-void launch_x3p_mixed(const X3Args& a, int nsplit, hipStream_t s) {
-    const size_t lds = 2 * 3 * 7 * 1024 + 3 * 3 * (size_t)128 * 32 + 1024;
-    const int units = a.tiles_m * a.tiles_n, nbig = units - nsplit;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3p_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(conv_x3p_mixed_kernel, dim3(nbig + 2 * nsplit), dim3(256), lds, s, a, nbig);
-}
-
-#endif
-
-template <int KS, int BN, int WM_, int WN_>
-void launch_x3r(const X3Args& a, hipStream_t s, int np) {
-    const size_t lds = 2 * 3 * 128 * 32;
-    if (np == 1) {
-        if (a.Cin < 16) hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, true, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, false, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-        return;
-    }
-    if (a.Cin < 16) hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_x3r_kernel<KS, BN, WM_, WN_, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-}
-
-#ifdef TSNET_TOOLS
-template <int QABL>
-void launch_x3q_abl(X3Args a, hipStream_t s) {    // diagnostic: x3q kernel, 128x64 tiles (the ResnetBlock configuration)
-    a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.Cout + 63) / 64;
-    hipLaunchKernelGGL((conv_x3q_kernel<64, 2, 2, QABL>), dim3(a.tiles_m * a.tiles_n), dim3(256), 2 * 3 * 7 * 1024 + 1024, s, a);
-}
-
-template <int ABL>
-void launch_x3p_abl(X3Args a, hipStream_t s) {    // diagnostic: patch kernel, 128x128 tiles
-    a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.Cout + 127) / 128;
-    const size_t lds = 2 * 3 * 7 * 1024 + 3 * 3 * (size_t)128 * 32 + 1024;
-    auto kern = conv_x3p_kernel<128, 2, 2, true, ABL>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-}
-
-template <int ABL>
-void launch_x3_abl(X3Args a, hipStream_t s) {     // diagnostic: 3x3, tile 0 (128x128, 4 waves, ring of 3)
-    a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.Cout + 127) / 128;
-    const size_t lds = (size_t)3 * ((size_t)3 * 256 * 32 + 1024);
-    auto kern = conv_x3_kernel<3, 128, 128, 2, 2, 1, 3, false, ABL>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-}
-
-#endif
-
-template <int KS>
-int launch_x3_ks(X3Args a, int forced_tile, hipStream_t s, int np = 3) {     // returns stats partials per image (0 = none)
-    int best = forced_tile;
-    if (best < 0) {
-        static const char* const e_tile = getenv("TSNET_X3_TILE");     // in-situ A/B switch, read once
-        double best_cost = 0;
-        // the patch kernel sums K slab-major, the others tap-major: which of the two a layer runs on must depend on
-        // the layer alone, never on the batch (results are identical for any batch size and any tile of one family)
-        const bool patch_family = !e_tile && x3p_ok<KS>(a) && a.Npad % 64 == 0;
-        for (int i = 0; i < kNumXTiles; ++i) {
-            if (!e_tile && kXTiles[i].patch != patch_family) continue;
-            if (a.Npad % kXTiles[i].bn) continue;
-            if (kXTiles[i].patch && !x3p_ok<KS>(a)) continue;
-            if (e_tile && atoi(e_tile) == i) { best = i; break; }
-            if (kXTiles[i].eff <= 0 || (kXTiles[i].bn > 32 && a.Cout <= kXTiles[i].bn / 2)) continue;
-            const long tm = (a.M + kXTiles[i].bm - 1) / kXTiles[i].bm, tn = (a.Cout + kXTiles[i].bn - 1) / kXTiles[i].bn;
-            double cost = (double)((tm * tn + 255) / 256) * kXTiles[i].bm * kXTiles[i].bn / kXTiles[i].eff;
-            if (a.stat_part && (a.Ho * a.Wo) % kXTiles[i].bm) cost *= 1.12;   // tile straddles images: statistics need their own pass
-            if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
-        }
-    }
-    if (best < 0 || best >= kNumXTiles || a.Npad % kXTiles[best].bn || (kXTiles[best].patch && !x3p_ok<KS>(a)))
-        throw ArgError("conv(x3): no tile configuration");
-    // tile 13 (sweep tool only): x3p launch with the last third of the 128-wide units cut into two 128 x 64 halves
-    const int mixed_split = best == 13 ? (int)(((a.M + 127) / 128) * ((a.Cout + 127) / 128) / 3) : 0;
-    (void)mixed_split;
-    a.tiles_m = (a.M + kXTiles[best].bm - 1) / kXTiles[best].bm;
-    a.tiles_n = (a.Cout + kXTiles[best].bn - 1) / kXTiles[best].bn;
-    const int hw = a.Ho * a.Wo;
-    if (hw % kXTiles[best].bm) a.stat_part = nullptr;
-    // few tiles per image: the last workgroup of each (image, channel tile) finalises the statistics (x3_epilogue);
-    // many tiles per image (the 128^2 / 256^2 layers): a serial tail of hundreds of partials would cost more than the
-    // in_finalize2 launch it saves.  The mixed x3p launch (tile 13) has two tile widths per launch: not counted.
-    if (!a.stat_part || hw / kXTiles[best].bm > 32 || best == 13 || (size_t)a.N * ((a.Npad + 31) / 32) > kFinCounterInts) a.fin_counter = nullptr;
-    a.fin_S = hw / kXTiles[best].bm;
-    switch (best) {
-#ifdef TSNET_TOOLS
-        case 0: launch_x3_t<KS, 128, 128, 2, 2, 1, 3>(a, s); break;
-        case 1: launch_x3_t<KS, 128, 128, 2, 2, 1, 4>(a, s); break;
-        case 2: launch_x3_t<KS, 128, 128, 2, 2, 2, 3>(a, s); break;
-        case 3: launch_x3_t<KS, 128, 128, 4, 2, 2, 3>(a, s); break;
-        case 4: launch_x3_t<KS, 128, 64, 2, 2, 1, 4>(a, s); break;
-        case 5: launch_x3_t<KS, 64, 64, 2, 2, 1, 4>(a, s); break;
-        case 6: launch_x3_t<KS, 64, 128, 2, 2, 1, 4>(a, s); break;
-        case 7: launch_x3_t<KS, 96, 128, 1, 4, 1, 3>(a, s); break;
-        case 8: launch_x3_t<KS, 128, 32, 4, 1, 1, 4>(a, s); break;
-        case 9: launch_x3_t<KS, 128, 128, 4, 2, 1, 3>(a, s); break;
-        case 10: launch_x3_t<KS, 128, 128, 2, 4, 1, 3>(a, s); break;
-        case 11: launch_x3p<128, 2, 2>(a, s); break;
-        case 12: launch_x3p<64, 2, 2>(a, s); break;
-        case 13: launch_x3p_mixed(a, mixed_split, s); break;
-#endif
-        case 14: launch_x3q<128, 2, 2>(a, s, np); break;
-        case 15: launch_x3q<64, 2, 2>(a, s, np); break;
-        case 16: launch_x3r<KS, 128, 2, 2>(a, s, np); break;
-        case 17: launch_x3r<KS, 64, 2, 2>(a, s, np); break;
-        case 18: launch_x3r<KS, 32, 4, 1>(a, s, np); break;
-        default: throw ArgError("conv(x3): this tile is only built into the tools library (superseded kernel generation)");
-    }
-    if (a.stat_part && a.fin_counter) return -1;     // statistics complete: alpha / beta written by the kernel
-    return a.stat_part ? hw / kXTiles[best].bm : 0;
-}
-
-struct X3Call {
-    const unsigned short* x3 = nullptr; const unsigned short* x23 = nullptr;   // split planes of the input(s)
-    int N = 0, H = 0, W = 0, csplit = 0, x2_nmod = 1;
-    float* y = nullptr; unsigned short* y3 = nullptr;
-    const float* addend = nullptr; int add_nmod = 1;
-    double* stat_part = nullptr; mutable int stat_S = 0;   // stat_S out: partials per image; 0 = none; -1 = finalised in the kernel
-    float* fin_alpha = nullptr; float* fin_beta = nullptr; int* fin_counter = nullptr;   // optional in-kernel finalize
-    int variant = -1;
-    int tclass = TSNET_T_CONV;
-    int np = 3;            // 1 = bf16-operand mode: only the hi plane is read (one MFMA product per k-group)
-    unsigned* amax_out = nullptr;   // publish max |y| (operand scale of a consumer without an a-priori bound)
-};
-
-void run_conv_x3(Ctx& ctx, const ConvLayer& L, const X3Call& c) {
-    X3Args g{};
-    g.x = c.x3; g.x2 = c.x23; g.w = L.w3; g.bias = L.bias; g.y = c.y; g.y3 = c.y3;
-    g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
-    g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_counter = c.stat_part ? c.fin_counter : nullptr; g.fin_eps = 1e-5f;
-    g.amax_out = c.amax_out;
-    g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
-    g.Csplit = c.x23 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
-    g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
-    g.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
-    g.Cout = L.cout; g.Npad = L.npad;
-    g.stride = L.stride; g.pad = L.pad; g.reflect = L.reflect;
-    g.taps = L.ks * L.ks; g.nchunks = (g.taps * g.Cin + 15) / 16;
-    g.M = c.N * g.Ho * g.Wo;
-    if (!L.w3) throw ArgError("conv(x3): layer has no bf16x3 weights");
-    if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
-    if ((g.Csplit & 15) && c.x23) throw ArgError("conv(x3): channel split must be a multiple of 16");
-    if ((double)c.N * c.H * c.W * L.cin_pad * 2 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
-        throw ArgError("conv(x3): tensor too large for 32-bit buffer offsets");
-    TimeScope ts(ctx, c.tclass);
-    const int forced = c.variant >= 0 ? (c.variant & 63) : -1;
-    const int abl = c.variant >= 0 ? (c.variant >> 16) & 127 : 0;
-#ifdef TSNET_TOOLS
-    if (abl && L.ks == 3 && forced == 15) {
-        if (!x3p_ok<3>(g)) throw ArgError("ablation: layer not eligible for the patch kernel");
-        switch (abl) {
-            case 1: launch_x3q_abl<1>(g, ctx.stream); break;
-            case 2: launch_x3q_abl<2>(g, ctx.stream); break;
-            case 4: launch_x3q_abl<4>(g, ctx.stream); break;
-            case 8: launch_x3q_abl<8>(g, ctx.stream); break;
-            case 16: launch_x3q_abl<16>(g, ctx.stream); break;
-            case 24: launch_x3q_abl<24>(g, ctx.stream); break;
-            case 31: launch_x3q_abl<31>(g, ctx.stream); break;
-            case 32: launch_x3q_abl<32>(g, ctx.stream); break;
-            case 33: launch_x3q_abl<33>(g, ctx.stream); break;
-            case 40: launch_x3q_abl<40>(g, ctx.stream); break;
-            case 41: launch_x3q_abl<41>(g, ctx.stream); break;
-            default: throw ArgError("unsupported ablation mask");
-        }
-        return;
-    }
-    if (abl && L.ks == 3 && forced == 11) {
-        if (!x3p_ok<3>(g)) throw ArgError("ablation: layer not eligible for the patch kernel");
-        switch (abl) {
-            case 1: launch_x3p_abl<1>(g, ctx.stream); break;
-            case 2: launch_x3p_abl<2>(g, ctx.stream); break;
-            case 3: launch_x3p_abl<3>(g, ctx.stream); break;
-            case 4: launch_x3p_abl<4>(g, ctx.stream); break;
-            case 8: launch_x3p_abl<8>(g, ctx.stream); break;
-            case 12: launch_x3p_abl<12>(g, ctx.stream); break;
-            case 15: launch_x3p_abl<15>(g, ctx.stream); break;
-            default: throw ArgError("unsupported ablation mask");
-        }
-        return;
-    }
-    if (abl && L.ks == 3) {
-        switch (abl) {
-            case 16: launch_x3_abl<16>(g, ctx.stream); break;
-            case 32: launch_x3_abl<32>(g, ctx.stream); break;
-            case 64: launch_x3_abl<64>(g, ctx.stream); break;
-            case 1: launch_x3_abl<1>(g, ctx.stream); break;
-            case 2: launch_x3_abl<2>(g, ctx.stream); break;
-            case 3: launch_x3_abl<3>(g, ctx.stream); break;
-            case 4: launch_x3_abl<4>(g, ctx.stream); break;
-            case 7: launch_x3_abl<7>(g, ctx.stream); break;
-            case 11: launch_x3_abl<11>(g, ctx.stream); break;
-            case 15: launch_x3_abl<15>(g, ctx.stream); break;
-            default: throw ArgError("unsupported ablation mask");
-        }
-        check_launch("conv_x3(abl)");
-        return;
-    }
-#else
-    if (abl) throw ArgError("ablation variants are only built into the tools library");
-#endif
-    switch (L.ks) {
-        case 1: c.stat_S = launch_x3_ks<1>(g, forced, ctx.stream, c.np); break;
-        case 3: c.stat_S = launch_x3_ks<3>(g, forced, ctx.stream, c.np); break;
-        case 7: c.stat_S = launch_x3_ks<7>(g, forced, ctx.stream, c.np); break;
-        default: throw ArgError("conv: kernel size must be 1, 3 or 7");
-    }
-    check_launch("conv_x3");
-    ++g_launch_counters[3];
-}
-
-// ---- fp16x2 patch convolution from fp32 input with the producer's InstanceNorm + ReLU fused into the patch staging (conv_h2.hpp)
-struct H2Call {
-    const float* x = nullptr;
     const float* alpha = nullptr; const float* beta = nullptr; int relu = 0;   // x*alpha+beta (+ReLU) on load, or the raw tensor
     float bound = 0.f;          // max |operand| after the transform (InstanceNorm output: sqrt(HW); residual stream: (blocks+1) sqrt(HW))
     const unsigned* in_amax = nullptr; float bound_add = 0.f;   // or: bound = max |x| published on the device by x's producer + bound_add
     int N = 0, H = 0, W = 0;
     float* y = nullptr;
     const float* addend = nullptr; int add_nmod = 1;
-    double* stat_part = nullptr; mutable int stat_S = 0;
+    double* stat_part = nullptr; mutable int stat_S = 0;        // stat_S out: partials per image; 0 = none; -1 = finalised in the kernel
     float* fin_alpha = nullptr; float* fin_beta = nullptr; int* fin_counter = nullptr;
-    int nprod = 3, bn = 0;      // products per k-group (3; 4 adds lo*lo), tile width (0 = heuristic)
-    int abl = 0;                // tools build: ablation mask of h2_tile (computes garbage)
+    unsigned* amax_out = nullptr;   // publish max |y| per image (operand scale of a consumer without an a-priori bound)
+    int nprod = 3;              // products per k-group: 3 (4 adds lo*lo), or 1 = bf16 operands
+    int kernel = 0;             // 0 = the layer's own kernel class, 1 = force the general kernel, 2 = require a patch kernel (op tests)
+    int tile = 0;               // 0 = heuristic; else rows * 1000 + width of the patch tile (32, 64, 128 = 4 rows; 2128 = 2 x 128), or 64 / 128 for the others
+    int abl = 0, opt = 0;       // tools build: ablation / experiment masks of h2_tile
     int tclass = TSNET_T_CONV;
 };
 
-inline bool h2_layer_ok(const ConvLayer& L) {
-    return L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && L.npad % 64 == 0;
-}
 // power-of-two operand scale: |x| <= bound  ->  |x * 2^sa| <= 2^15 < 65504 (fp16 max)
 inline int h2_scale_log2(float bound) {
-    if (!(bound > 0.f) || !std::isfinite(bound)) throw ArgError("conv(h2): the operand bound must be positive and finite");
+    if (!(bound > 0.f) || !std::isfinite(bound)) throw ArgError("conv: the operand bound must be positive and finite");
     int e = 0;
     (void)std::frexp(bound, &e);          // bound = m * 2^e, m in [0.5, 1)  ->  bound <= 2^e
     int sa = 15 - e;
@@ -571,254 +189,105 @@ inline int h2_scale_log2(float bound) {
     return sa;
 }
 
-template <int BN, int NPROD>
-void launch_h2(const H2Args& a, hipStream_t s) {
-    const size_t lds = 2 * 2 * 7168 + 2048 + (size_t)2 * a.Cin * 4;      // two-plane layout offsets in every mode
-    constexpr int WM = BN >= 64 ? 2 : 4, WN = 4 / WM;                     // 32-wide tiles: four waves stacked over the four patch rows
-    if (a.in_alpha) hipLaunchKernelGGL((conv_h2_kernel<BN, WM, WN, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_h2_kernel<BN, WM, WN, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-}
-
-void run_conv_h2(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
-    const bool bf16 = c.nprod == 1;                // bf16-operand mode: the hi plane of the bf16x3 packing, no scales
-    if (!h2_layer_ok(L) || !(bf16 ? (const void*)L.w3 : (const void*)L.wh)) throw ArgError("conv(h2): layer is not a 3x3 / stride-1 / pad-1 layer with packed 16-bit weights");
-    H2Args g{};
-    g.x = c.x; g.in_alpha = c.alpha; g.in_beta = c.alpha ? c.beta : nullptr; g.in_relu = c.relu;
-    const int sa = (bf16 || c.in_amax) ? 0 : h2_scale_log2(c.bound);
-    g.in_scale = std::ldexp(1.0f, sa); g.in_unscale = std::ldexp(1.0f, -sa);
-    g.in_amax = bf16 ? nullptr : c.in_amax; g.in_bound_add = c.bound_add; g.amax_out = nullptr;
-    g.w = bf16 ? L.w3 : L.wh; g.w_unscale = bf16 ? nullptr : L.wh_unscale; g.bias = L.bias; g.y = c.y; g.y3 = nullptr;
-    g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
-    g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.Ho = c.H; g.Wo = c.W; g.Cout = L.cout; g.Npad = L.npad;
-    g.reflect = L.reflect; g.nchunks = (9 * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
-    if (g.Ho % kPatchRows || g.Wo % kPatchCols) throw ArgError("conv(h2): output must split into 4 x 32 rectangles");
-    if (L.reflect && (c.H < 2 || c.W < 2)) throw ArgError("conv: reflection pad needs pad < input size");
-    if (c.alpha && !c.beta) throw ArgError("conv(h2): alpha without beta");
-    if ((double)c.N * c.H * c.W * L.cin_pad * 4 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
-        throw ArgError("conv(h2): tensor too large for 32-bit buffer offsets");
-    if ((size_t)2 * g.Cin * 4 + 2 * 2 * 7168 + 2048 > 64 * 1024) throw ArgError("conv(h2): too many input channels for the transform table");
-    int bn = c.bn;
-    if (bn == 0) {
-        // 256 CUs each run ceil(tiles / 256) tiles (co-resident workgroups share the MFMA pipe): minimise that count x tile area / efficiency.
-        // 128-wide tiles (wave tile 64 x 64) move half the LDS / L1 bytes per MFMA: measured 1.07-1.15x per unit area without the
-        // fused transform, 1.03x with it (tools/conv_sweep.py h2, profiles/round2_notes.md); the 384-tile ResnetBlock layers at
-        // batch 4 are the case where 768 64-wide tiles = exactly three per CU win.
-        const long tm = g.M / 128;
-        const double c64 = (double)((tm * ((g.Cout + 63) / 64) + 255) / 256) * 64.0;
-        const double c128 = (double)((tm * ((g.Cout + 127) / 128) + 255) / 256) * 128.0 / (c.alpha ? 1.03 : 1.10);
-        bn = (g.Npad % 128 == 0 && g.Cout > 64 && c128 < c64) ? 128 : 64;
-        // small M (one driving frame: the decoder's ResnetBlocks are 64 tiles of 128 x 64 on 256 CUs): 32-wide tiles double the number of
-        // workgroups; each stages the same patch but runs half the MFMA chain, and a tile alone on its CU is latency-, not throughput-bound
-        if (bn == 64 && tm * ((g.Cout + 63) / 64) <= 192 && c.nprod != 4) bn = 32;
-    }
-    if (bn != 32 && bn != 64 && bn != 128) throw ArgError("conv(h2): tile width must be 32, 64 or 128");
-    if (g.Npad % bn) bn = 64;
-    g.tiles_m = g.M / 128; g.tiles_n = (g.Cout + bn - 1) / bn;
-    const int hw = g.Ho * g.Wo;
-    g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f; g.fin_S = hw / 128;
-    g.fin_counter = (c.stat_part && c.fin_counter && hw / 128 <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= kFinCounterInts) ? c.fin_counter : nullptr;
-    TimeScope ts(ctx, c.tclass);
-    if (c.abl) {
-#ifdef TSNET_TOOLS
-        const size_t lds = 2 * 2 * 7168 + 2048 + (size_t)2 * g.Cin * 4;
-        g.tiles_n = (g.Cout + 63) / 64;
-#define TSNET_H2_ABL(m) case m: hipLaunchKernelGGL((conv_h2_kernel<64, 2, 2, 3, false, m>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, ctx.stream, g); break;
-        switch (c.abl) {
-            TSNET_H2_ABL(1) TSNET_H2_ABL(2) TSNET_H2_ABL(3) TSNET_H2_ABL(4) TSNET_H2_ABL(6) TSNET_H2_ABL(7) TSNET_H2_ABL(8) TSNET_H2_ABL(15) TSNET_H2_ABL(16) TSNET_H2_ABL(31)
-            default: throw ArgError("unsupported ablation mask");
-        }
-#undef TSNET_H2_ABL
-        check_launch("conv_h2(abl)");
-        return;
-#else
-        throw ArgError("ablation variants are only built into the tools library");
-#endif
-    }
-    if (c.nprod == 3) { if (bn == 32) launch_h2<32, 3>(g, ctx.stream); else if (bn == 64) launch_h2<64, 3>(g, ctx.stream); else launch_h2<128, 3>(g, ctx.stream); }
-    else if (c.nprod == 4) { if (bn == 64) launch_h2<64, 4>(g, ctx.stream); else if (bn == 128) launch_h2<128, 4>(g, ctx.stream); else throw ArgError("conv(h2): four products on 64- or 128-wide tiles"); }
-    else if (c.nprod == 1) { if (bn == 32) launch_h2<32, 1>(g, ctx.stream); else if (bn == 64) launch_h2<64, 1>(g, ctx.stream); else launch_h2<128, 1>(g, ctx.stream); }
-    else throw ArgError("conv(h2): 1 (bf16 operands), 3 or 4 products");
-    check_launch("conv_h2");
-    c.stat_S = !c.stat_part ? 0 : (g.fin_counter ? -1 : hw / 128);
-    ++g_launch_counters[0];
-}
-
-// ---- h2r: the stride-2 downsampling convolutions on the same arithmetic (conv_h2.hpp, implicit GEMM)
-inline bool h2r_layer_ok(const ConvLayer& L) {
-    const bool down = L.ks == 3 && L.stride == 2 && L.pad == 1 && !L.reflect && L.cin_pad >= 16;       // encoder downsampling (TSNet.py:70)
-    const bool stem = L.ks == 7 && L.stride == 1 && L.pad == 3 && L.reflect && L.cin_pad >= 8;         // encoder stem (TSNet.py:66)
-    return (down || stem) && (L.cin_pad & (L.cin_pad - 1)) == 0 && L.npad % 64 == 0;
-}
-
-template <int KS, int BN, int NPROD>
-void launch_h2r(const H2rArgs& a, hipStream_t s) {
-    const size_t lds = 2 * 2 * 128 * 32 + (size_t)2 * a.Cin * 4;
-    if (a.Cin < 16) {
-        if (a.in_alpha) throw ArgError("conv(h2r): 8-channel layers take no input transform");
-        hipLaunchKernelGGL((conv_h2r_kernel<KS, BN, 2, 2, NPROD, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    } else if (a.in_alpha) {
-        hipLaunchKernelGGL((conv_h2r_kernel<KS, BN, 2, 2, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    } else {
-        hipLaunchKernelGGL((conv_h2r_kernel<KS, BN, 2, 2, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    }
-}
-
-template <int BN, int NPROD>
-void launch_h2d_t(const H2Args& a, hipStream_t s) {
-    const size_t lds = kH2dLds + (size_t)2 * a.Cin * 4;
-    if (a.in_alpha) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NPROD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((conv_h2d_kernel<BN, NPROD, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    } else {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NPROD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((conv_h2d_kernel<BN, NPROD, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-    }
-}
-
-void launch_h2d(H2Args a, int nprod, hipStream_t s) {
-    // 64-wide tiles only: at 128 the tile needs more than the 256 registers two workgroups per CU leave a wave (it spills inside the slab loop)
-    a.tiles_n = (a.Cout + 63) / 64;
-    if (nprod == 3) launch_h2d_t<64, 3>(a, s); else launch_h2d_t<64, 1>(a, s);
-}
-
-void run_conv_h2r(Ctx& ctx, const ConvLayer& L, const H2Call& c) {
-    const bool bf16 = c.nprod == 1;
-    if (!h2r_layer_ok(L) || !(bf16 ? (const void*)L.w3 : (const void*)L.wh)) throw ArgError("conv(h2r): layer is not a downsampling / stem layer with packed 16-bit weights");
-    H2rArgs g{};
-    g.x = c.x; g.in_alpha = c.alpha; g.in_beta = c.alpha ? c.beta : nullptr; g.in_relu = c.relu;
-    const int sa = (bf16 || c.in_amax) ? 0 : h2_scale_log2(c.bound);
-    g.in_scale = std::ldexp(1.0f, sa); g.in_unscale = std::ldexp(1.0f, -sa);
-    g.in_amax = bf16 ? nullptr : c.in_amax; g.in_bound_add = c.bound_add; g.amax_out = nullptr;
-    g.w = bf16 ? L.w3 : L.wh; g.w_unscale = bf16 ? nullptr : L.wh_unscale; g.bias = L.bias; g.y = c.y; g.y3 = nullptr;
-    g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
-    g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
-    g.stride = L.stride; g.pad = L.pad; g.taps = L.ks * L.ks; g.reflect = L.reflect;
-    g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1; g.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
-    g.Cout = L.cout; g.Npad = L.npad; g.nchunks = (g.taps * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
-    if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
-    const int hw = g.Ho * g.Wo;
-    if (hw % 128) throw ArgError("conv(h2r): an output image must be a whole number of 128-row tiles");
-    if (c.alpha && !c.beta) throw ArgError("conv(h2r): alpha without beta");
-    if ((double)c.N * c.H * c.W * L.cin_pad * 4 >= 2147483648.0 || (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
-        throw ArgError("conv(h2r): tensor too large for 32-bit buffer offsets");
-    int bn = c.bn;
-    if (bn == 0) {       // ceil(tiles / 256) x tile area, as for the patch kernel
-        const long tm = g.M / 128;
-        const double c64 = (double)((tm * ((g.Cout + 63) / 64) + 255) / 256) * 64.0;
-        const double c128 = (double)((tm * ((g.Cout + 127) / 128) + 255) / 256) * 128.0 / 1.15;
-        bn = (L.ks == 3 && g.Npad % 128 == 0 && g.Cout > 64 && c128 < c64) ? 128 : 64;
-    }
-    if ((bn != 64 && bn != 128) || g.Npad % bn) throw ArgError("conv(h2r): tile width must be 64 or 128 and divide the padded width");
-    g.tiles_m = g.M / 128; g.tiles_n = (g.Cout + bn - 1) / bn;
-    g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f; g.fin_S = hw / 128;
-    g.fin_counter = (c.stat_part && c.fin_counter && hw / 128 <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= kFinCounterInts) ? c.fin_counter : nullptr;
-    TimeScope ts(ctx, c.tclass);
-    if (c.nprod != 1 && c.nprod != 3) throw ArgError("conv(h2r): 1 (bf16 operands) or 3 products");
-    static const bool stem_patch = [] { const char* e = getenv("TSNET_H2S"); return !e || atoi(e) != 0; }();
-    static const bool down_patch = [] { const char* e = getenv("TSNET_H2D"); return !e || atoi(e) != 0; }();
-    if (L.ks == 7 && g.Cin == 8 && bn == 64 && !c.alpha && stem_patch && g.Ho % kPatchRows == 0 && g.Wo % kPatchCols == 0 && c.H >= 4 && c.W >= 4) {
-        // 8-channel stem on whole 4 x 32 rectangles: the patch kernel (conv_h2.hpp h2s) -- same packed weights, same arithmetic, no im2col gather
-        const size_t lds = 2 * 2 * 7168 + 2048;
-        const H2Args& b = g;
-        if (c.nprod == 3) hipLaunchKernelGGL((conv_h2s_kernel<3>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, ctx.stream, b);
-        else hipLaunchKernelGGL((conv_h2s_kernel<1>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, ctx.stream, b);
-    } else if (L.ks == 3 && down_patch && g.Cout >= 512 && g.Ho % kPatchRows == 0 && g.Wo % kPatchCols == 0 && (g.Cin & 15) == 0 && g.Cin <= 256) {
-        // stride-2 layer on whole 4 x 32 output rectangles with at least 512 output channels (the 256 -> 512 layer, where the implicit GEMM
-        // runs 64-wide tiles at the headline batch anyway): the patch kernel (conv_h2.hpp h2d), 143 vs 167 us there.  The choice depends on
-        // the LAYER only, never on the batch: the two kernels add the K chunks in different orders, and a sample's result must not depend
-        // on how many samples run with it.  At 128-wide tiles conv_h2r stays ahead (150 / 141 us vs 170 / 150 us for the
-        // 64-wide patch kernel on the 64 -> 128 and 128 -> 256 layers) and a 128-wide patch tile does not fit the register file.  Same packed
-        // weights (chunk index kc = tap * Cin/16 + slab in both kernels; only the ORDER in which the chunks are visited differs)
-        launch_h2d(g, c.nprod, ctx.stream);
-    } else if (L.ks == 7) {
-        if (bn != 64) throw ArgError("conv(h2r): the 7x7 stems run on 64-wide tiles");
-        if (c.nprod == 3) launch_h2r<7, 64, 3>(g, ctx.stream); else launch_h2r<7, 64, 1>(g, ctx.stream);
-    } else if (c.nprod == 3) { if (bn == 64) launch_h2r<3, 64, 3>(g, ctx.stream); else launch_h2r<3, 128, 3>(g, ctx.stream); }
-    else { if (bn == 64) launch_h2r<3, 64, 1>(g, ctx.stream); else launch_h2r<3, 128, 1>(g, ctx.stream); }
-    check_launch("conv_h2r");
-    c.stat_S = !c.stat_part ? 0 : (g.fin_counter ? -1 : hw / 128);
-    ++g_launch_counters[0];
-}
-
-void run_split3(Ctx& ctx, const float* x, unsigned short* out, size_t elems) {
-    if (elems & 3) throw ArgError("split3: element count must be a multiple of 4");
-    TimeScope ts(ctx, TSNET_T_ELEMWISE);
-    hipLaunchKernelGGL(split3_kernel, dim3(ew_grid(elems / 4)), dim3(256), 0, ctx.stream, x, out, elems / 4);
-    check_launch("split3");
-}
-
-// fp32-MFMA path selection: conv_dma unless the call needs the in-loader IN+ReLU transform (op tests, TSNET_CONV_LEGACY=1)
-// or a tensor is too large for 32-bit buffer offsets / the out-of-range marker
-bool use_dma_path(const ConvLayer& L, const ConvCall& c, int Ho, int Wo) {
-    if (c.alpha || !L.w2) return false;
-    if (c.variant >= 0) return (c.variant & 4096) != 0;   // bench hook
-    const char* e = getenv("TSNET_CONV_LEGACY");
-    if (e && atoi(e)) return false;
-    const int csplit = c.x2 ? c.csplit : L.cin_pad;
-    return (double)c.N * c.H * c.W * csplit * 4 < 2147483648.0 && (double)(c.x2_nmod > 0 ? c.x2_nmod : 1) * c.H * c.W * (L.cin_pad - csplit) * 4 < 2147483648.0 &&
-           (double)L.kpad * L.npad * 4 < 2147483648.0 && (double)c.N * Ho * Wo * L.cout < 2147483647.0;
+// Kernel class of a layer at a frame size.  The patch kernels sum K slab-major, the general one tap-major: the class must depend on the
+// layer and the geometry alone, never on the batch (a sample's result is the same bits in any batch).
+enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3 };
+inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool transform, int rows = kPatchRows) {
+    const int Ho = (H + 2 * L.pad - L.ks) / L.stride + 1, Wo = (W + 2 * L.pad - L.ks) / L.stride + 1;
+    const bool s1 = L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H >= 2 && W >= 2;
+    if (two_sources || Ho <= 0 || Wo <= 0 || Wo % kPatchCols) return K_GENERAL;
+    if (s1 && rows == 2 && Ho % 2 == 0) return K_H2;             // an explicitly requested 2-row tile (op tests, tools)
+    if (Ho % kPatchRows) return K_GENERAL;
+    if (s1) return K_H2;
+    if (L.ks == 7 && L.stride == 1 && L.pad == 3 && L.reflect && L.cin_pad == 8 && !transform && H >= 4 && W >= 4) return K_H2S;
+    if (L.ks == 3 && L.stride == 2 && L.pad == 1 && !L.reflect && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H == 2 * Ho && W == 2 * Wo) return K_H2D;
+    return K_GENERAL;
 }
 
 void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
-    const int Ho_ = (c.H + 2 * L.pad - L.ks) / L.stride + 1, Wo_ = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
-    c.stat_S = 0;
-    if (use_dma_path(L, c, Ho_, Wo_)) {
-        DmaArgs g{};
-        g.x = c.x; g.x2 = c.x2; g.w = L.w2; g.bias = L.bias; g.y = c.y;
-        g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
-        g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
-        g.Csplit = c.x2 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
-        g.Ho = Ho_; g.Wo = Wo_;
-        g.Cout = L.cout; g.Npad = L.npad;
-        g.stride = L.stride; g.pad = L.pad; g.reflect = L.reflect;
-        g.taps = L.ks * L.ks; g.nchunks = (g.taps * g.Cin + 15) / 16;
-        g.M = c.N * g.Ho * g.Wo;
-        g.act = c.act; g.out_nchw = c.out_nchw;
-        g.composite = c.composite; g.fore_x0 = 64; g.fore_x1 = 192;
-        g.bg[0] = c.bg[0]; g.bg[1] = c.bg[1]; g.bg[2] = c.bg[2];
-        g.stat_part = (c.act == 0 && !c.out_nchw) ? c.stat_part : nullptr;
-        if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
-        if ((g.Csplit & 15) && c.x2) throw ArgError("conv(dma): channel split must be a multiple of 16");
-        TimeScope ts(ctx, TSNET_T_CONV);
-        const int forced = c.variant >= 0 ? (c.variant & 7) : -1;
-        switch (L.ks) {
-            case 1: c.stat_S = launch_dma_ks<1>(g, forced, ctx.stream); break;
-            case 3: c.stat_S = launch_dma_ks<3>(g, forced, ctx.stream); break;
-            case 7: c.stat_S = launch_dma_ks<7>(g, forced, ctx.stream); break;
-            default: throw ArgError("conv: kernel size must be 1, 3 or 7");
-        }
-        check_launch("conv_dma");
-        ++g_launch_counters[2];
-        return;
-    }
-    if (c.addend) throw ArgError("conv: an epilogue addend needs the conv_dma kernel");
-    ConvArgs a{};
-    a.x = c.x; a.x2 = c.x2; a.in_alpha = c.alpha; a.in_beta = c.beta;
-    a.w = L.w; a.bias = L.bias; a.y = c.y;
-    a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = L.cin_pad; a.cin_log2 = ilog2(L.cin_pad);
-    a.Csplit = c.x2 ? c.csplit : L.cin_pad; a.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
-    a.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1;
-    a.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
-    a.Cout = L.cout; a.Npad = L.npad;
-    a.stride = L.stride; a.pad = L.pad; a.reflect = L.reflect;
-    a.taps = L.ks * L.ks; a.nchunks = 0;   // set per BK in launch_conv_ks
-    a.M = c.N * a.Ho * a.Wo;
-    a.in_relu = c.in_relu; a.act = c.act; a.out_nchw = c.out_nchw;
-    a.composite = c.composite; a.fore_x0 = 64; a.fore_x1 = 192;   // TSNet_pose.py:279
-    a.bg[0] = c.bg[0]; a.bg[1] = c.bg[1]; a.bg[2] = c.bg[2];
+    const bool bf16 = c.nprod == 1;
+    if (!L.wq) throw ArgError("conv: layer has no packed weights");
+    if (L.ks != 1 && L.ks != 3 && L.ks != 7) throw ArgError("conv: kernel size must be 1, 3 or 7");
+    if (L.cin_pad != 8 && (L.cin_pad < 16 || (L.cin_pad & 15))) throw ArgError("conv: input channels must be 8 or a multiple of 16 (pad with zeros)");
+    ConvArgs g{};
+    g.x = c.x; g.x2 = c.x2; g.in_alpha = c.alpha; g.in_beta = c.alpha ? c.beta : nullptr; g.in_relu = c.relu;
+    if (c.alpha && !c.beta) throw ArgError("conv: alpha without beta");
+    const int sa = (bf16 || c.in_amax) ? 0 : h2_scale_log2(c.bound);
+    g.in_scale = std::ldexp(1.0f, sa); g.in_unscale = std::ldexp(1.0f, -sa);
+    g.in_amax = bf16 ? nullptr : c.in_amax; g.in_bound_add = c.bound_add; g.amax_out = c.amax_out;
+    g.w = L.wq; g.w_unscale = bf16 ? nullptr : L.w_unscale; g.bias = L.bias; g.y = c.y;
+    g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
+    g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
+    g.Csplit = c.x2 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
+    g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1; g.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
+    g.Cout = L.cout; g.Npad = L.npad; g.stride = L.stride; g.pad = L.pad; g.reflect = L.reflect;
+    g.taps = L.ks * L.ks; g.nchunks = (g.taps * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
+    if (c.N < 1 || g.Ho < 1 || g.Wo < 1) throw ArgError("conv: empty tensor");
     if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
-    if ((a.Csplit & 3) || ((L.cin_pad - a.Csplit) & 3)) throw ArgError("conv: channel split must be a multiple of 4");
-    if ((double)c.N * c.H * c.W * L.cin_pad >= 2147483647.0 || (double)a.M * L.cout >= 2147483647.0)
-        throw ArgError("conv: tensor exceeds 2^31 elements");
-    TimeScope ts(ctx, TSNET_T_CONV);
-    switch (L.ks) {
-        case 1: launch_conv_ks<1>(a, c.variant, ctx.stream); break;
-        case 3: launch_conv_ks<3>(a, c.variant, ctx.stream); break;
-        case 7: launch_conv_ks<7>(a, c.variant, ctx.stream); break;
-        default: throw ArgError("conv: kernel size must be 1, 3 or 7");
-    }
-    check_launch("conv_igemm");
-    ++g_launch_counters[1];
+    if (c.x2 && ((g.Csplit & 15) || g.Csplit <= 0 || g.Csplit >= g.Cin)) throw ArgError("conv: channel split must be a multiple of 16 inside the channel range");
+    if ((double)c.N * c.H * c.W * g.Csplit * 4 >= 2147483648.0 || (double)g.x2_nmod * c.H * c.W * (g.Cin - g.Csplit) * 4 >= 2147483648.0 ||
+        (double)g.M * L.cout >= 2147483647.0 || (double)L.kpad * L.npad * 2 >= 2147483648.0)
+        throw ArgError("conv: tensor too large for 32-bit buffer offsets");
+    if ((size_t)2 * g.Cin * 4 > 32 * 1024) throw ArgError("conv: too many input channels for the transform table");
+    const int hw = g.Ho * g.Wo;
+    const int cls = c.kernel == 1 ? K_GENERAL : conv_class(L, c.H, c.W, c.x2 != nullptr, c.alpha != nullptr, c.tile >= 1000 ? c.tile / 1000 : kPatchRows);
+    if (c.kernel == 2 && cls == K_GENERAL) throw ArgError("conv: this layer / frame size has no patch kernel");
+    g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f;
+    TimeScope ts(ctx, c.tclass);
+    auto set_tiles = [&](int rows_per_tile_m, int bn) {     // rows_per_tile_m: output positions of an M tile (patch: PR * 32; general: 128)
+        g.tpi = (hw + rows_per_tile_m - 1) / rows_per_tile_m;
+        g.tiles_m = c.N * g.tpi; g.tiles_n = (g.Cout + bn - 1) / bn;
+        g.fin_S = g.tpi;
+        // few tiles per image: the last workgroup of each (image, channel tile) finalises the statistics (conv_epilogue); many tiles per
+        // image (the 128^2 / 256^2 layers): a serial tail of hundreds of partials would cost more than the in_finalize2 launch it saves
+        g.fin_counter = (c.stat_part && c.fin_counter && g.tpi <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= kFinCounterInts) ? c.fin_counter : nullptr;
+    };
+    // 256 CUs each run ceil(tiles / 256) tiles (co-resident workgroups share the MFMA pipe): minimise that count x tile area / efficiency
+    auto wide_pays = [&](long tm, double gain) {
+        const double c64 = (double)((tm * ((g.Cout + 63) / 64) + 255) / 256) * 64.0;
+        const double c128 = (double)((tm * ((g.Cout + 127) / 128) + 255) / 256) * 128.0 / gain;
+        return g.Npad % 128 == 0 && g.Cout > 64 && c128 < c64;
+    };
+    try {
+        if (cls == K_H2) {
+            int pr = 4, bn = 0;
+            if (c.tile) { pr = c.tile >= 1000 ? c.tile / 1000 : 4; bn = c.tile % 1000; }
+            if (bn == 0) {
+                // 128-wide tiles (wave tile 64 x 64) move half the LDS / L1 bytes per MFMA: measured 1.07-1.15x per unit area without the
+                // fused transform, 1.03x with it; the 384-tile ResnetBlock layers at batch 4 are the case where 768 64-wide tiles = exactly
+                // three per CU win.  Small M (one driving frame: the decoder's ResnetBlocks are 64 tiles of 128 x 64 on 256 CUs): 32-wide
+                // tiles double the number of workgroups; each stages the same patch but runs half the MFMA chain.
+                const long tm = (long)c.N * (hw / 128);
+                bn = wide_pays(tm, c.alpha ? 1.03 : 1.10) ? 128 : 64;
+                if (bn == 64 && tm * ((g.Cout + 63) / 64) <= 192 && c.nprod != 4) bn = 32;
+            }
+            if ((pr != 2 && pr != 4) || g.Ho % pr) throw ArgError("conv(h2): the output height must be a multiple of the tile's rows (2 or 4)");
+            if (g.Npad % bn) throw ArgError("conv(h2): the tile width must divide the padded output width");
+            set_tiles(pr * kPatchCols, bn);
+            launch_conv_h2(g, pr, bn, c.nprod, c.abl, c.opt, ctx.stream);
+            ++g_launch_counters[0];
+        } else if (cls == K_H2S) {
+            set_tiles(128, 64);
+            launch_conv_h2s(g, c.nprod, ctx.stream);
+            ++g_launch_counters[0];
+        } else if (cls == K_H2D) {
+            int bn = c.tile ? c.tile : ((g.Npad % 128 == 0 && g.Cout > 64) ? 128 : 64);
+            if (g.Npad % bn) throw ArgError("conv(h2d): the tile width must divide the padded output width");
+            set_tiles(128, bn);
+            launch_conv_h2d(g, bn, c.nprod, ctx.stream);
+            ++g_launch_counters[0];
+        } else {
+            if (c.abl || c.opt) throw ArgError("conv: experiment variants exist for the 3x3 / stride-1 patch kernel only");
+            const long tm = (long)c.N * ((hw + 127) / 128);
+            int bn = c.tile ? c.tile : ((L.ks == 3 && L.cin_pad >= 16 && wide_pays(tm, 1.15)) ? 128 : 64);
+            if (g.Npad % bn) throw ArgError("conv(h2r): the tile width must divide the padded output width");
+            set_tiles(128, bn);
+            launch_conv_h2r(g, L.ks, bn, c.nprod, ctx.stream);
+            ++g_launch_counters[1];
+        }
+    } catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
+    check_launch("conv");
+    c.stat_S = !c.stat_part ? 0 : (g.fin_counter ? -1 : g.tpi);
 }
 
 // InstanceNorm statistics -> (alpha, beta); `part` must hold N*64*C*2 doubles
@@ -849,15 +318,6 @@ void launch_finalize_impl(const double* part, float* alpha, float* beta, int N, 
     check_launch("in_finalize");
 }
 
-// statistics of a conv output: reduce the partials the conv epilogue left (S per image), or run the
-// stand-alone statistics pass when the conv could not produce them
-void finish_stats(Ctx& ctx, const ConvCall& c, const float* y, int N, int HW, int C, double* part, float* alpha, float* beta) {
-    if (c.stat_S <= 0) { run_stats(ctx, y, N, HW, C, part, alpha, beta); return; }
-    TimeScope ts(ctx, TSNET_T_STATS);
-    hipLaunchKernelGGL(in_finalize2_kernel, dim3((C + kFin2Ch - 1) / kFin2Ch, N), dim3(256), 0, ctx.stream, part, alpha, beta, C, c.stat_S, HW, 1e-5f);
-    check_launch("in_finalize2");
-}
-
 // y = x + add[n % add_nmod] with the InstanceNorm statistics of y -> (alpha, beta); `part` must hold N*64*C*2 doubles
 void run_add_stats(Ctx& ctx, const float* x, const float* add, int add_nmod, float* y, int N, int HW, int C, double* part, float* alpha, float* beta) {
     if (C & 3) throw ArgError("add_stats: C must be a multiple of 4");
@@ -875,10 +335,10 @@ void run_add_stats(Ctx& ctx, const float* x, const float* add, int add_nmod, flo
 }
 
 void run_norm_act(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, const float* resid,
-                  int N, int HW, int C, float* y, unsigned short* y3 = nullptr) {
+                  int N, int HW, int C, float* y) {
     if (C & 3) throw ArgError("norm_act: C must be a multiple of 4");
     TimeScope ts(ctx, TSNET_T_ELEMWISE);
-    NormActArgs a{x, alpha, beta, resid, y, HW, C, relu, (size_t)N * HW * C / 4, y3};
+    NormActArgs a{x, alpha, beta, resid, y, HW, C, relu, (size_t)N * HW * C / 4};
     if ((double)HW * C / 4 >= 4294967295.0 || N > 65535) throw ArgError("norm_act: tensor too large");
     size_t per_img4 = (size_t)HW * C / 4, gx = (per_img4 + 255) / 256, cap = std::max<size_t>(1, 4096 / (size_t)N);
     if (gx > cap) gx = cap;
@@ -886,36 +346,30 @@ void run_norm_act(Ctx& ctx, const float* x, const float* alpha, const float* bet
     check_launch("norm_act");
 }
 
-void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, int N, int H, int W, int C, float* y,
-                  unsigned short* y3 = nullptr) {
+void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, int N, int H, int W, int C, float* y) {
     if (C & 3) throw ArgError("upsample: C must be a multiple of 4");
     TimeScope ts(ctx, TSNET_T_UPSAMPLE);
-    UpsampleArgs a{x, alpha, beta, y, N, H, W, C, relu, y3};
+    UpsampleArgs a{x, alpha, beta, y, N, H, W, C, relu};
     if (2 * H > 65535 || N > 65535) throw ArgError("upsample: tensor too large");
     const size_t row4 = (size_t)2 * W * C / 4;
     hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)std::min<size_t>((row4 + 255) / 256, 64), 2 * H, N), dim3(256), 0, ctx.stream, a);
     check_launch("upsample2x");
 }
 
-// RGB head: head_conv2_kernel (weights in LDS, two pixels per thread); TSNET_HEAD=1 selects the first-generation kernel (A/B switch)
+// RGB head (head_conv.hpp): head_conv3_kernel for widths that are multiples of 16 (every reference caller: ngf = 64), the
+// one-pixel-per-thread form for narrower nets.  The choice depends on the width alone.
 void launch_head(const HeadArgs& ha, int hh, int ww, int B, hipStream_t s) {
-    // TSNET_HEAD: 1 = first form (one pixel per thread, scalar weights), 2 = second (two pixels, weights in LDS), default = third
-    static const int form = [] { const char* e = getenv("TSNET_HEAD"); return e ? atoi(e) : 3; }();
-    if (form == 1) {
+    if (ha.C % (2 * kHead3Ch) != 0) {
         const int tiles = ((ww + kHeadT - 1) / kHeadT) * ((hh + kHeadT - 1) / kHeadT);
         hipLaunchKernelGGL(head_conv_kernel, dim3(tiles, B), dim3(256), 0, s, ha);
-    } else if (form == 2 || ha.C % (2 * kHead3Ch) != 0) {
-        const int tiles = ((ww + kHead2W - 1) / kHead2W) * ((hh + kHead2H - 1) / kHead2H);
-        const size_t lds = (size_t)((kHeadCh / 4) * kHead2Rows * kHead2Pitch + 49 * kHeadCh) * sizeof(float4);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_conv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(head_conv2_kernel, dim3(tiles, B), dim3(256), lds, s, ha);
     } else {
         const int tiles = ((ww + kHead3T - 1) / kHead3T) * ((hh + kHead3T - 1) / kHead3T);
         const size_t lds = (size_t)(2 * (kHead3PatchF4 + kHead3WtsF4) + ha.C / 2) * sizeof(float4);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_conv3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ensure_dynamic_lds(reinterpret_cast<const void*>(head_conv3_kernel), lds);
         hipLaunchKernelGGL(head_conv3_kernel, dim3(tiles, B), dim3(512), lds, s, ha);
     }
     check_launch("head_conv");
+    ++g_launch_counters[2];
 }
 
 void run_l2norm(Ctx& ctx, const float* x, float* y, int rows, int C) {
@@ -929,30 +383,23 @@ void run_flow(Ctx& ctx, FlowArgs a, int NB) {
     TimeScope ts(ctx, TSNET_T_FLOW);
     const size_t lds = ((size_t)32 * (a.C + 4) + ((a.P + 3) & ~3) + 2 * kFlowWaves * 32 * 4) * sizeof(float);
     if (lds > 160 * 1024) throw ArgError("flow: feature width / position count exceed the LDS budget");
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ensure_dynamic_lds(reinterpret_cast<const void*>(flow_kernel), lds);
     hipLaunchKernelGGL(flow_kernel, dim3((a.P + 31) / 32, NB), dim3(64 * kFlowWaves), lds, ctx.stream, a);
     check_launch("flow");
 }
 
-void run_warp(Ctx& ctx, const float* src, const float* flow, float* out, int B, int K, int h, int w, int C, unsigned short* out3 = nullptr) {
+void run_warp(Ctx& ctx, const float* src, const float* flow, float* out, int B, int K, int h, int w, int C) {
     TimeScope ts(ctx, TSNET_T_WARP);
-    WarpArgs a{src, flow, out, B, K, h, w, C, out3};
+    WarpArgs a{src, flow, out, B, K, h, w, C};
     hipLaunchKernelGGL(warp_mean_kernel, dim3(ew_grid((size_t)B * h * w * C / 4)), dim3(256), 0, ctx.stream, a);
     check_launch("warp_mean");
 }
 
-void pack_layer_weights(const float* w_oihw_dev, float* out_dev, float* out2_dev, const ConvLayer& L, hipStream_t s) {
-    const size_t total = (size_t)L.kpad * L.npad;
-    const int ct = L.cin_total > 0 ? L.cin_total : L.cin_real;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw_dev, out_dev,
-                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, ct, L.cin_off);
+// weights of one layer -> operand planes + the un-scale factor; `stage` holds the OIHW parameter on the device
+void pack_layer(const float* stage, const ConvLayer& L, unsigned short* planes_out, int planes, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid((size_t)L.kpad * L.npad)), dim3(256), 0, s, stage, planes_out, scale, planes,
+                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, L.cin_total > 0 ? L.cin_total : L.cin_real, L.cin_off);
     check_launch("pack_weights");
-    if (out2_dev) {
-        hipLaunchKernelGGL(pack_weights_dma_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw_dev, out2_dev,
-                           L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, ct, L.cin_off);
-        check_launch("pack_weights_dma");
-    }
 }
 
 // torch.linspace(-1, 1, n) in float32: step = (end-start)/(n-1); first half start+i*step, second half
@@ -992,6 +439,7 @@ struct tsnet_engine {
     bool finalized = false;
     int C = 0, h = 0, w = 0, P = 0, K = 0, Bmax = 0;
     int cp_img = 0, cp_lbl = 0;
+    int np = 3;                           // MFMA products per k-group: 3 (fp16 x 2 operands), or 1 = bf16-operand mode (cfg.operand_mode)
 
     struct Param { std::string name; std::vector<int64_t> shape; std::vector<float> host; bool loaded = false; };
     std::vector<Param> params;
@@ -999,35 +447,24 @@ struct tsnet_engine {
 
     // layers
     std::vector<ConvLayer> img_enc, lbl_enc;            // stem, downs, then 2 per resblock
-    ConvLayer fuse_c1, fuse_c2, fuse_out, dec_map, dec_head;
-    ConvLayer fuse_c1_src, fuse_c1_tar;   // fuse_c1 split at the channel concat: per-source half / shared target half
-    float* FT = nullptr;                  // (B,P,2C) target half of fuse_c1, computed once per forward
-    // ---- bf16x3 mode (conv_x3.hpp): every conv input exists as three bf16 planes
-    bool x3 = true;
-    int np = 3;                           // 1 = bf16-operand mode (cfg.operand_mode): one plane / one product everywhere
-    bool h2 = true;                       // fp16x2 patch convolution (conv_h2.hpp) for the 3x3 / stride-1 layers whose input is bounded; TSNET_H2=0: round-1 schedule
-    unsigned* amax = nullptr;             // device: max |x| PER IMAGE of tensors without an a-priori bound, as float bits; reset before each
-                                          // producer.  One slot per image: a sample's scale (hence its result, bit for bit) never depends on the
-                                          // rest of the batch.  amax_src: K*Bmax packed source inputs; amax_tar: Bmax packed label inputs;
-                                          // amax_dec: Bmax decoder streams (dec_map output)
-    unsigned* amax_src() const { return amax; }
-    unsigned* amax_tar() const { return amax + (size_t)K * Bmax; }
-    unsigned* amax_dec() const { return amax + (size_t)(K + 1) * Bmax; }
-    float* U_f32[8] = {nullptr};          // fp32 upsampled decoder inputs (h2 schedule; the bf16x3 schedule writes planes only)
-    unsigned short* wpack3 = nullptr; size_t wpack3_elems = 0;
-    unsigned short* arena3 = nullptr;
-    unsigned short *x_img3 = nullptr, *x_lbl3 = nullptr, *X3 = nullptr, *T3 = nullptr, *tar3 = nullptr, *zbar3 = nullptr,
-                   *pg3 = nullptr, *sg3 = nullptr, *D3 = nullptr;
-    std::vector<unsigned short*> raw3_img, raw3_lbl, U3;
-    float* head_w = nullptr;              // [49][ngf][4] weights of the RGB head for head_conv_kernel
-    bool vector_head = true;              // head_conv_kernel (VALU) instead of the N-padded MFMA conv
+    ConvLayer fuse_c1_src, fuse_c1_tar;   // FuseNet's first convolution split at the channel concat: per-source half / shared target half
+    ConvLayer fuse_c2, fuse_out, dec_map, dec_head;
     std::vector<ConvLayer> dec_res, dec_up;
-    std::vector<ConvLayer*> all_layers;
+    std::vector<ConvLayer*> all_layers;   // every layer that runs on the MFMA kernels (all but the RGB head)
+    float* head_w = nullptr;              // [49][ngf][4] weights of the RGB head (head_conv.hpp)
+    const float* head_bias = nullptr;
 
     // device memory
-    float* wpack = nullptr; size_t wpack_floats = 0;
+    float* wpack = nullptr; size_t wpack_floats = 0;    // ONE buffer: biases, RGB-head table, un-scale factors, operand planes of every layer
     float* arena = nullptr; size_t arena_floats = 0;
     float* d_coords = nullptr; float* d_gx = nullptr; float* d_gy = nullptr;
+    unsigned* amax = nullptr;             // device: max |x| PER IMAGE of tensors without an a-priori bound, as float bits; reset before each
+                                          // producer.  One slot per image: a sample's scale (hence its result, bit for bit) never depends on the
+                                          // rest of the batch.  K*Bmax packed source inputs | Bmax packed label inputs | Bmax sg | Bmax decoder streams
+    unsigned* amax_src() const { return amax; }
+    unsigned* amax_tar() const { return amax + (size_t)K * Bmax; }
+    unsigned* amax_sg() const { return amax + (size_t)(K + 1) * Bmax; }
+    unsigned* amax_dec() const { return amax + (size_t)(K + 2) * Bmax; }
 
     // arena buffers (sized for Bmax)
     float *x_img = nullptr, *x_lbl = nullptr;
@@ -1036,24 +473,22 @@ struct tsnet_engine {
     float *tar_fea = nullptr, *that = nullptr, *shat = nullptr, *flow = nullptr, *pg = nullptr;
     float *F1 = nullptr, *F2 = nullptr, *zbar = nullptr, *sg = nullptr;
     float* F1s = nullptr;                 // per-source half of FuseNet's first convolution (+ bias): computed by set_sources, cached in clip mode
+    float* FT = nullptr;                  // (B,P,2C) target half of it, computed once per driving frame
     float *D = nullptr, *DY1 = nullptr, *DY2 = nullptr;
     std::vector<float*> U, R;
     float* ab[4][2] = {{nullptr}};
     float* ab_side[2][2] = {{nullptr}};   // (alpha, beta) buffers of the side lane (target-label encoder)
-    int ab_side_rr = 0;
+    int ab_rr = 0, ab_side_rr = 0;
+    double* part = nullptr;
     double* part_side = nullptr;       // statistics partials / arrival counters of the side lane
+    int* fin_counter = nullptr;        // arrival counters of the in-kernel statistics finalize (conv_epilogue), all zero between launches
     int* fin_counter_side = nullptr;
     hipStream_t side_stream = nullptr; // target-label chain of a full forward runs here, concurrently with the source encoder
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
-    bool overlap = true;               // TSNET_OVERLAP=0 turns the side stream off
-    double* part = nullptr;
     float* train_ws = nullptr;         // workspace of tsnet_train_extras, allocated on first use
-    int* fin_counter = nullptr;        // arrival counters of the in-kernel statistics finalize (x3_epilogue), all zero between launches
-    int ab_rr = 0;
 
     // clip-mode cache
     int cached_B = 0;
-    const float* cached_bbox[TSNET_MAX_SOURCES] = {nullptr};
     float* bbox_copy = nullptr;     // (K, Bmax, H, W) device copies of the source bboxes
     int last_B = 0;
     float src_div[TSNET_MAX_SOURCES];  // per-source image divisor (255; 1 for use_prev sources), tsnet_set_source_divisors
@@ -1065,10 +500,10 @@ struct tsnet_engine {
         Param p; p.name = name; p.shape = std::move(shape);
         params.push_back(std::move(p));
     }
-    ConvLayer make_conv(const std::string& name, int cin_real, int cin_pad, int cout, int ks, int stride, int pad, int reflect) {
-        ConvLayer L; L.name = name; L.cin_real = cin_real; L.cin_pad = cin_pad; L.cout = cout; L.ks = ks;
+    ConvLayer make_conv(const std::string& name, int cin_real, int cout, int ks, int stride, int pad, int reflect) {
+        ConvLayer L; L.name = name; L.cin_real = cin_real; L.cin_pad = conv_cin_pad(cin_real); L.cout = cout; L.ks = ks;
         L.stride = stride; L.pad = pad; L.reflect = reflect;
-        L.kpad = conv_kpad(ks, cin_pad); L.npad = conv_npad(cout);
+        L.kpad = conv_kpad(ks, L.cin_pad); L.npad = conv_npad(cout);
         L.wparam = name + ".weight"; L.bparam = name + ".bias"; L.cin_total = cin_real; L.cin_off = 0;
         add_param(L.wparam, {cout, cin_real, ks, ks});
         add_param(L.bparam, {cout});
@@ -1076,70 +511,36 @@ struct tsnet_engine {
     }
     void build_layers();
     void alloc_all(hipStream_t s);
-    void encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin, int N, int cp, std::vector<float*>& raw, float* out_fea, int nblocks);
-    void encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned short* xin3, int N, std::vector<float*>& raw,
-                   std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks,
-                   const float* xin_f32 = nullptr, const unsigned* xin_amax = nullptr);
-    // the 7x7 stem runs on conv_h2r (fp32 packed input, operand scale from its published maximum) when the h2 schedule is on
-    bool stem_h2r(const std::vector<ConvLayer>& L) const {
-        return h2 && h2r_layer_ok(L[0]) && (cfg.height * cfg.width) % 128 == 0 && (np == 1 ? L[0].w3 != nullptr : L[0].wh != nullptr);
+
+    std::pair<float*, float*> next_ab(const Ctx& ctx) {
+        if (!ctx.lane) { auto r = std::make_pair(ab[ab_rr][0], ab[ab_rr][1]); ab_rr = (ab_rr + 1) & 3; return r; }
+        auto r = std::make_pair(ab_side[ab_side_rr][0], ab_side[ab_side_rr][1]); ab_side_rr ^= 1; return r;
     }
-    void resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float* y1, float* y2, int N, int hh, int ww);
-    void forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
-    // every convolution of the forward goes through these two: they apply the engine's operand mode
-    void rx3(Ctx& ctx, const ConvLayer& L, X3Call& c) { c.np = np; run_conv_x3(ctx, L, c); }
-    void rh2(Ctx& ctx, const ConvLayer& L, H2Call& c) { c.nprod = np == 1 ? 1 : 3; run_conv_h2(ctx, L, c); }
-    void conv_stats_x3(Ctx& ctx, const ConvLayer& L, X3Call& c, int N, int HW, float* alpha, float* beta) {
+    float enc_bound() const { return (float)(cfg.enc_blocks + 1) * std::sqrt((float)P); }  // bound of the source features: |relu(IN)| <= sqrt(P), + one IN output per block
+    // every convolution of the forward goes through here: the engine's operand mode, the lane's statistics scratch, the finalize
+    void conv(Ctx& ctx, const ConvLayer& L, ConvCall& c) { c.nprod = np; run_conv(ctx, L, c); }
+    void conv_stats(Ctx& ctx, const ConvLayer& L, ConvCall& c, int N, int HW, float* alpha, float* beta) {
         double* pt = ctx.lane ? part_side : part;
         c.stat_part = pt;
         c.fin_alpha = alpha; c.fin_beta = beta; c.fin_counter = ctx.lane ? fin_counter_side : fin_counter;
-        rx3(ctx, L, c);
-        if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
-        if (c.stat_S > 0) {
-            TimeScope ts(ctx, TSNET_T_STATS);
-            hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + kFin2Ch - 1) / kFin2Ch, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
-            check_launch("in_finalize2");
-        } else {
-            run_stats(ctx, c.y, N, HW, L.cout, pt, alpha, beta);
-        }
-    }
-    void conv_stats_h2(Ctx& ctx, const ConvLayer& L, H2Call& c, int N, int HW, float* alpha, float* beta) {
-        double* pt = ctx.lane ? part_side : part;
-        c.stat_part = pt;
-        c.fin_alpha = alpha; c.fin_beta = beta; c.fin_counter = ctx.lane ? fin_counter_side : fin_counter;
-        if (L.stride == 2 || L.ks == 7) { c.nprod = np == 1 ? 1 : 3; run_conv_h2r(ctx, L, c); }
-        else rh2(ctx, L, c);
+        conv(ctx, L, c);
         if (c.stat_S < 0) return;              // finalised by the last workgroups of the convolution itself
         TimeScope ts(ctx, TSNET_T_STATS);
         hipLaunchKernelGGL(in_finalize2_kernel, dim3((L.cout + kFin2Ch - 1) / kFin2Ch, N), dim3(256), 0, ctx.stream, pt, alpha, beta, L.cout, c.stat_S, HW, 1e-5f);
         check_launch("in_finalize2");
     }
-    // ResnetBlock on the h2 schedule.  stream_bound > 0: the residual stream Xs has an a-priori bound (encoder: (blocks+1) sqrt(HW));
-    // stream_amax: its bound is measured -- max |first value| published by the producer + amax_add (decoder: the stream starts at a raw
-    // convolution output); neither: the first convolution reads the bf16x3 planes Xs3.
-    void resblock_h2(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float stream_bound, float* y1, float* y2, int N, int hh, int ww,
-                     const unsigned* stream_amax = nullptr, float amax_add = 0.f);
-    void resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww);
+    void encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin, const unsigned* xin_amax, int N, std::vector<float*>& raw, float* out_fea, int nblocks);
+    // ResnetBlock.  stream_amax == null: the residual stream Xs has the a-priori bound stream_bound (encoder: (blocks+1) sqrt(HW));
+    // else its bound is measured: max |first value| published by the producer + amax_add (decoder: the stream starts at a raw conv output)
+    void resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float stream_bound, const unsigned* stream_amax, float amax_add,
+                  float* y1, float* y2, int N, int hh, int ww);
     void set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B);
-    void forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
-    // A conv whose input is ReLU(IN(raw)): materialise it in place (one HBM-bound pass; required by the
-    // LDS-DMA conv kernel, which cannot transform data in flight) or, on the legacy register-staged
-    // kernel (TSNET_CONV_LEGACY=1), apply it inside the loader.
-    bool split_fuse = true;           // needs conv_dma's epilogue addend; off with the legacy kernels
-    bool fuse_norm_in_loader = false;
-    void norm_input(Ctx& ctx, float* raw, const float* alpha, const float* beta, int N, int HW, int Cc, ConvCall& call) {
-        if (fuse_norm_in_loader) { call.alpha = alpha; call.beta = beta; call.in_relu = 1; return; }
-        run_norm_act(ctx, raw, alpha, beta, 1, nullptr, N, HW, Cc, raw);
+    void target_chain(Ctx& ctx, const float* tar_lbl, int B);
+    void forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
+    void forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
+        target_chain(ctx, tar_lbl, B);
+        forward_rest(ctx, tar_bbox, out_rgb, out_flow, B);
     }
-    std::pair<float*, float*> next_ab() { auto r = std::make_pair(ab[ab_rr][0], ab[ab_rr][1]); ab_rr = (ab_rr + 1) & 3; return r; }
-    std::pair<float*, float*> next_ab(const Ctx& ctx) {
-        if (!ctx.lane) return next_ab();
-        auto r = std::make_pair(ab_side[ab_side_rr][0], ab_side[ab_side_rr][1]); ab_side_rr ^= 1; return r;
-    }
-    bool h2_feat() const { return h2 && h % kPatchRows == 0 && w % kPatchCols == 0; }   // the feature-resolution layers run on conv_h2
-    float enc_bound() const { return (float)(cfg.enc_blocks + 1) * std::sqrt((float)P); }  // bound of the source features (encode_x3)
-    void target_chain_x3(Ctx& ctx, const float* tar_lbl, int B);
-    void forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
 };
 
 void tsnet_engine::build_layers() {
@@ -1147,149 +548,111 @@ void tsnet_engine::build_layers() {
     const int coords = c.addcoords ? 3 : 0;
     auto enc = [&](const std::string& net, int cin, int nblocks, std::vector<ConvLayer>& out) {
         const int cin_real = cin + coords;
-        const int cp = next_pow2(cin_real);
-        out.push_back(make_conv(net + ".model.1", cin_real, cp, c.ngf, 7, 1, 3, 1));
+        out.push_back(make_conv(net + ".model.1", cin_real, c.ngf, 7, 1, 3, 1));
         int idx = 4, ch = c.ngf;
         for (int i = 0; i < c.n_downsampling; ++i) {
-            out.push_back(make_conv(net + ".model." + std::to_string(idx), ch, ch, ch * 2, 3, 2, 1, 0));
+            out.push_back(make_conv(net + ".model." + std::to_string(idx), ch, ch * 2, 3, 2, 1, 0));
             ch *= 2; idx += 3;
         }
         for (int i = 0; i < nblocks; ++i) {
-            out.push_back(make_conv(net + ".model." + std::to_string(idx) + ".conv_block.1", ch, ch, ch, 3, 1, 1, 1));
-            out.push_back(make_conv(net + ".model." + std::to_string(idx) + ".conv_block.5", ch, ch, ch, 3, 1, 1, 1));
+            out.push_back(make_conv(net + ".model." + std::to_string(idx) + ".conv_block.1", ch, ch, 3, 1, 1, 1));
+            out.push_back(make_conv(net + ".model." + std::to_string(idx) + ".conv_block.5", ch, ch, 3, 1, 1, 1));
             idx += 1;
         }
-        return cp;
+        return out[0].cin_pad;
     };
     cp_img = enc("img_enc", 3 + c.label_nc, c.enc_blocks, img_enc);
     cp_lbl = enc("lbl_enc", c.label_nc, 0, lbl_enc);
     const int fc = 2 * C;   // FuseNet width: cat of two feature maps (1024 in the reference, TSNet.py:227)
-    fuse_c1 = make_conv("fuse_net.model.0.conv_block.1", fc, fc, fc, 3, 1, 1, 1);
-    fuse_c2 = make_conv("fuse_net.model.0.conv_block.5", fc, fc, fc, 3, 1, 1, 1);
-    // conv(cat(src, tar)) = conv_src(src) + conv_tar(tar): the target half is shared by the K sources
-    // (SURVEY.md 7.2, -9.66 GMAC/frame).  Both halves read windows of the same OIHW parameter.
-    fuse_c1_src = fuse_c1; fuse_c1_src.name += "[src]"; fuse_c1_src.cin_real = fuse_c1_src.cin_pad = C; fuse_c1_src.cin_off = 0;
-    fuse_c1_src.kpad = conv_kpad(3, C);
-    fuse_c1_tar = fuse_c1_src; fuse_c1_tar.name = fuse_c1.name + "[tar]"; fuse_c1_tar.cin_off = C; fuse_c1_tar.bparam.clear();
-    fuse_out = make_conv("fuse_net.conv", fc, fc, fc / 2, 1, 1, 0, 0);
-    dec_map = make_conv("dec.map_conv", 2 * C, 2 * C, C, 1, 1, 0, 0);
+    // conv(cat(src, tar)) = conv_src(src) + conv_tar(tar): the target half is shared by the K sources (SURVEY.md 7.2, -9.66 GMAC/frame).
+    // Both halves read windows of the same OIHW parameter.
+    fuse_c1_src = make_conv("fuse_net.model.0.conv_block.1", fc, fc, 3, 1, 1, 1);
+    fuse_c1_src.name += "[src]"; fuse_c1_src.cin_real = C; fuse_c1_src.cin_pad = conv_cin_pad(C); fuse_c1_src.cin_off = 0;
+    fuse_c1_src.kpad = conv_kpad(3, fuse_c1_src.cin_pad);
+    fuse_c1_tar = fuse_c1_src; fuse_c1_tar.name = "fuse_net.model.0.conv_block.1[tar]"; fuse_c1_tar.cin_off = C; fuse_c1_tar.bparam.clear();
+    fuse_c2 = make_conv("fuse_net.model.0.conv_block.5", fc, fc, 3, 1, 1, 1);
+    fuse_out = make_conv("fuse_net.conv", fc, fc / 2, 1, 1, 0, 0);
+    dec_map = make_conv("dec.map_conv", 2 * C, C, 1, 1, 0, 0);
     int n = 0;
     for (int i = 0; i < c.n_blocks; ++i) {
-        dec_res.push_back(make_conv("dec.model" + std::to_string(n) + ".0.conv_block.1", C, C, C, 3, 1, 1, 1));
-        dec_res.push_back(make_conv("dec.model" + std::to_string(n) + ".0.conv_block.5", C, C, C, 3, 1, 1, 1));
+        dec_res.push_back(make_conv("dec.model" + std::to_string(n) + ".0.conv_block.1", C, C, 3, 1, 1, 1));
+        dec_res.push_back(make_conv("dec.model" + std::to_string(n) + ".0.conv_block.5", C, C, 3, 1, 1, 1));
         ++n;
     }
     for (int i = 0; i < c.n_downsampling; ++i) {
         const int ci = c.ngf << (c.n_downsampling - i);
-        dec_up.push_back(make_conv("dec.model" + std::to_string(n) + ".2", ci, ci, ci / 2, 3, 1, 1, 1));
+        dec_up.push_back(make_conv("dec.model" + std::to_string(n) + ".2", ci, ci / 2, 3, 1, 1, 1));
         ++n;
     }
-    dec_head = make_conv("dec.model" + std::to_string(n) + ".1", c.ngf, c.ngf, 3, 7, 1, 3, 1);
+    dec_head = make_conv("dec.model" + std::to_string(n) + ".1", c.ngf, 3, 7, 1, 3, 1);
     for (auto& L : img_enc) all_layers.push_back(&L);
     for (auto& L : lbl_enc) all_layers.push_back(&L);
-    all_layers.push_back(&fuse_c1); all_layers.push_back(&fuse_c1_src); all_layers.push_back(&fuse_c1_tar);
+    all_layers.push_back(&fuse_c1_src); all_layers.push_back(&fuse_c1_tar);
     all_layers.push_back(&fuse_c2); all_layers.push_back(&fuse_out);
     all_layers.push_back(&dec_map);
     for (auto& L : dec_res) all_layers.push_back(&L);
     for (auto& L : dec_up) all_layers.push_back(&L);
-    all_layers.push_back(&dec_head);
 }
 
 void tsnet_engine::alloc_all(hipStream_t s) {
-    // ---- packed weights: one contiguous buffer (single RCCL broadcast replicates a model)
+    // ---- packed weights: ONE contiguous buffer (a single RCCL broadcast replicates a model): biases, the RGB-head table, the per-layer
+    // un-scale factors 2^-sw, then the operand planes of every layer -- fp16 (hi, lo) of w * 2^sw, or one bf16 plane in the bf16-operand
+    // mode.  Nothing else is packed: what a replica receives is exactly what its kernels read.
+    const int planes = np == 1 ? 1 : 2;
     size_t off = 0;
-    for (ConvLayer* L : all_layers) {
-        L->w_off = off; off += (size_t)L->kpad * L->npad;
-        L->w2_off = off; off += (size_t)L->kpad * L->npad;
-        L->b_off = off; off += (size_t)round_up(L->cout, 4);
-    }
-    // the derived layouts live in the same allocation -- RGB-head table, bf16x3 planes -- so that the ONE broadcast
-    // of dist.build_replica carries everything a replica computes with
-    const bool want_head = cfg.ngf % kHeadCh == 0;
+    for (ConvLayer* L : all_layers) { L->b_off = off; off += (size_t)round_up(L->cout, 4); }
+    dec_head.b_off = off; off += 4;
     off = (off + 63) / 64 * 64;            // 256-byte aligned sections
     const size_t head_off = off;
-    if (want_head) off += (size_t)49 * cfg.ngf * 4;
-    size_t o3 = 0;
-    std::vector<size_t> offs;
-    if (x3) for (ConvLayer* L : all_layers) { offs.push_back(o3); o3 += 3 * (size_t)L->kpad * L->npad; }
+    off += (size_t)49 * cfg.ngf * 4 + 64;  // + one 16-channel row: the narrow-net head kernel reads whole 16-channel rows of the last tap
     off = (off + 63) / 64 * 64;
-    const size_t x3_off = off;
-    off += (o3 + 1) / 2;                   // two bf16 per float slot
-    // fp16x2 planes (conv_h2.hpp) of the 3x3 / stride-1 layers + one un-scale factor per layer
-    off = (off + 63) / 64 * 64;
-    const size_t h2tab_off = off;
+    const size_t tab_off = off;
     off += round_up((int)all_layers.size(), 64);
-    size_t oh = 0;
-    std::vector<size_t> offs_h(all_layers.size(), 0);
-    if (x3 && h2) for (size_t i = 0; i < all_layers.size(); ++i) if (h2_layer_ok(*all_layers[i]) || h2r_layer_ok(*all_layers[i])) { offs_h[i] = oh; oh += 2 * (size_t)all_layers[i]->kpad * all_layers[i]->npad; }
     off = (off + 63) / 64 * 64;
-    const size_t h2_off = off;
-    off += (oh + 1) / 2;
+    const size_t planes_off = off;
+    size_t o16 = 0;
+    for (ConvLayer* L : all_layers) { L->w_off = o16; o16 += (size_t)planes * L->kpad * L->npad; o16 = (o16 + 127) / 128 * 128; }
+    off += (o16 + 1) / 2;                  // two 16-bit values per float slot
     wpack_floats = off;
     HIP_TRY(hipMalloc((void**)&wpack, wpack_floats * sizeof(float)));
     HIP_TRY(hipMemsetAsync(wpack, 0, wpack_floats * sizeof(float), s));
     size_t max_w = 0;
     for (ConvLayer* L : all_layers) max_w = std::max(max_w, (size_t)L->cout * L->cin_total * L->ks * L->ks);
+    max_w = std::max(max_w, (size_t)3 * cfg.ngf * 49);
     float* stage = nullptr;
     HIP_TRY(hipMalloc((void**)&stage, max_w * sizeof(float)));
-    for (ConvLayer* L : all_layers) {
+    unsigned short* planes_base = reinterpret_cast<unsigned short*>(wpack + planes_off);
+    for (size_t i = 0; i < all_layers.size(); ++i) {
+        ConvLayer* L = all_layers[i];
         const Param& pw = params[pindex[L->wparam]];
+        // per layer a power-of-two scale from the largest |weight|: |w * 2^sw| <= 2^15
+        float mx = 0.f;
+        for (float v : pw.host) { const float av = std::fabs(v); if (av > mx) mx = av; }
+        if (!std::isfinite(mx)) throw WeightError("parameter '" + L->wparam + "' holds a non-finite value");
+        const int sw = (np != 1 && mx > 0.f) ? h2_scale_log2(mx) : 0;
+        const float unscale = std::ldexp(1.0f, -sw);
         HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        pack_layer_weights(stage, wpack + L->w_off, wpack + L->w2_off, *L, s);
+        HIP_TRY(hipMemcpyAsync(wpack + tab_off + i, &unscale, sizeof(float), hipMemcpyHostToDevice, s));
+        pack_layer(stage, *L, planes_base + L->w_off, planes, std::ldexp(1.0f, sw), s);
         if (!L->bparam.empty()) {
             const Param& pb = params[pindex[L->bparam]];
             HIP_TRY(hipMemcpyAsync(wpack + L->b_off, pb.host.data(), pb.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
         }
         HIP_TRY(hipStreamSynchronize(s));   // host vectors / staging buffer reused next iteration
-        L->w = wpack + L->w_off;
-        L->w2 = wpack + L->w2_off;
+        L->wq = planes_base + L->w_off;
+        L->w_unscale = np == 1 ? nullptr : wpack + tab_off + i;
         L->bias = L->bparam.empty() ? nullptr : wpack + L->b_off;
     }
-    if (x3) {                              // bf16x3 planes of every layer's weights
-        wpack3_elems = o3;
-        wpack3 = reinterpret_cast<unsigned short*>(wpack + x3_off);
-        size_t li = 0;
-        for (ConvLayer* L : all_layers) {
-            const Param& pw = params[pindex[L->wparam]];
-            HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(pack_weights_x3_kernel, dim3(ew_grid((size_t)L->kpad * L->npad)), dim3(256), 0, s, stage, wpack3 + offs[li],
-                               L->cout, L->cin_real, L->cin_pad, L->ks, L->kpad, L->npad, L->cin_total > 0 ? L->cin_total : L->cin_real, L->cin_off);
-            check_launch("pack_weights_x3");
-            HIP_TRY(hipStreamSynchronize(s));
-            L->w3 = wpack3 + offs[li];
-            ++li;
-        }
-    }
-    if (x3 && h2 && np != 1) {             // fp16x2 planes: per layer a power-of-two scale from the largest |weight| (the bf16-operand mode reads the bf16x3 hi plane)
-        unsigned short* wh_base = reinterpret_cast<unsigned short*>(wpack + h2_off);
-        for (size_t i = 0; i < all_layers.size(); ++i) {
-            ConvLayer* L = all_layers[i];
-            if (!h2_layer_ok(*L) && !h2r_layer_ok(*L)) continue;
-            const Param& pw = params[pindex[L->wparam]];
-            float mx = 0.f;
-            for (float v : pw.host) { const float av = std::fabs(v); if (av > mx) mx = av; }
-            if (!std::isfinite(mx)) throw WeightError("parameter '" + L->wparam + "' holds a non-finite value");
-            const int sw = mx > 0.f ? h2_scale_log2(mx) : 0;
-            const float unscale = std::ldexp(1.0f, -sw);
-            HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(wpack + h2tab_off + i, &unscale, sizeof(float), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(pack_weights_h2_kernel, dim3(ew_grid((size_t)L->kpad * L->npad)), dim3(256), 0, s, stage, wh_base + offs_h[i], std::ldexp(1.0f, sw),
-                               L->cout, L->cin_real, L->cin_pad, L->ks, L->kpad, L->npad, L->cin_total > 0 ? L->cin_total : L->cin_real, L->cin_off);
-            check_launch("pack_weights_h2");
-            HIP_TRY(hipStreamSynchronize(s));
-            L->wh = wh_base + offs_h[i];
-            L->wh_unscale = wpack + h2tab_off + i;
-        }
-    }
-    if (want_head) {                       // RGB head weights for the vector kernel (else the MFMA path is used)
+    {                                      // RGB head: fp32 weights in the vector kernel's order + bias
         const Param& pw = params[pindex[dec_head.wparam]];
+        const Param& pb = params[pindex[dec_head.bparam]];
         HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(wpack + dec_head.b_off, pb.host.data(), pb.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
         head_w = wpack + head_off;
+        head_bias = wpack + dec_head.b_off;
         hipLaunchKernelGGL(pack_head_weights_kernel, dim3(64), dim3(256), 0, s, stage, head_w, cfg.ngf);
         check_launch("pack_head_weights");
         HIP_TRY(hipStreamSynchronize(s));
-    } else {
-        vector_head = false;
     }
     HIP_TRY(hipFree(stage));
     for (auto& p : params) { std::vector<float>().swap(p.host); }   // host copies no longer needed
@@ -1325,7 +688,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     const size_t fe = (size_t)P * C;
     want(&X, NB * fe); want(&Y1, NB * fe); want(&Y2, NB * fe);
     want(&tar_fea, B * fe); want(&that, B * fe); want(&shat, NB * fe); want(&flow, NB * P * 2); want(&pg, B * fe);
-    want(&F1, NB * fe * 2); want(&F2, NB * fe * 2); if (x3) want(&F1s, NB * fe * 2); want(&zbar, B * fe * 2); want(&sg, B * fe); want(&FT, B * fe * 2);
+    want(&F1, NB * fe * 2); want(&F2, NB * fe * 2); want(&F1s, NB * fe * 2); want(&zbar, B * fe * 2); want(&sg, B * fe); want(&FT, B * fe * 2);
     want(&D, B * fe); want(&DY1, B * fe); want(&DY2, B * fe);
     U.assign(cfg.n_downsampling, nullptr); R.assign(cfg.n_downsampling, nullptr);
     for (int i = 0; i < cfg.n_downsampling; ++i) {
@@ -1333,12 +696,18 @@ void tsnet_engine::alloc_all(hipStream_t s) {
         want(&U[i], B * sp * (C >> i));
         want(&R[i], B * sp * (C >> (i + 1)));
     }
-    if (x3 && h2) for (int i = 0; i < cfg.n_downsampling && i < 8; ++i) want(&U_f32[i], B * (size_t)(h << (i + 1)) * (w << (i + 1)) * (C >> i));
     for (int i = 0; i < 4; ++i) { want(&ab[i][0], NB * 2 * C); want(&ab[i][1], NB * 2 * C); }
+    for (int i = 0; i < 2; ++i) { want(&ab_side[i][0], NB * 2 * C); want(&ab_side[i][1], NB * 2 * C); }
     want(&bbox_copy, NB * H * W);
-    float* part_f = nullptr;
-    // InstanceNorm partials (doubles, 2 floats each): stand-alone pass N*64*C*2, conv-epilogue N*(HW/64)*C*2
-    want(&part_f, 2 * std::max(NB * 64 * 2 * C * 2, NB * (size_t)H * W * cfg.ngf / 32 + 1024));
+    // InstanceNorm partials (doubles = 2 floats each): the stand-alone pass N*64*C*2, a conv epilogue N * tiles-per-image * Cout * 2
+    // with tiles of at least 64 positions (ceil for ragged images), per lane
+    size_t part_doubles = NB * 64 * 2 * C * 2;
+    for (int l = 0; l <= cfg.n_downsampling; ++l) {
+        const size_t hw = (size_t)(H >> l) * (W >> l), tpi = (hw + 63) / 64;
+        part_doubles = std::max(part_doubles, NB * tpi * (size_t)std::max(cfg.ngf << l, 2 * C) * 2);
+    }
+    float *part_f = nullptr, *part_side_f = nullptr;
+    want(&part_f, 2 * part_doubles); want(&part_side_f, 2 * part_doubles);
     size_t total = 0;
     for (auto& r : req) total += r.second;
     arena_floats = total;
@@ -1346,164 +715,111 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     size_t o = 0;
     for (auto& r : req) { *r.first = arena + o; o += r.second; }
     part = reinterpret_cast<double*>(part_f);
+    part_side = reinterpret_cast<double*>(part_side_f);
+    HIP_TRY(hipMalloc((void**)&amax, (size_t)(K + 3) * Bmax * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(amax, 0, (size_t)(K + 3) * Bmax * sizeof(unsigned), s));
     // arrival counters: one per (image, 32-channel group) of a launch; launches with more (image, group) pairs than kFinCounterInts
-    // fall back to the in_finalize2 kernel (launch_x3_ks / run_conv_h2 check the index range against this size)
-    HIP_TRY(hipMalloc((void**)&amax, (size_t)(K + 2) * Bmax * sizeof(unsigned)));
-    HIP_TRY(hipMemsetAsync(amax, 0, (size_t)(K + 2) * Bmax * sizeof(unsigned), s));
-    HIP_TRY(hipMalloc((void**)&fin_counter, kFinCounterInts * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(fin_counter, 0, kFinCounterInts * sizeof(int), s));
-    if (x3) {      // side lane (tsnet_forward): own statistics scratch, counters, (alpha, beta) pairs, stream and events
-        const size_t part_bytes = (size_t)2 * std::max((size_t)NB * 64 * 2 * C * 2, (size_t)NB * H * W * cfg.ngf / 32 + 1024) * sizeof(float);
-        HIP_TRY(hipMalloc((void**)&part_side, part_bytes));
-        HIP_TRY(hipMalloc((void**)&fin_counter_side, kFinCounterInts * sizeof(int)));
-        HIP_TRY(hipMemsetAsync(fin_counter_side, 0, kFinCounterInts * sizeof(int), s));
-        for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < 2; ++j) HIP_TRY(hipMalloc((void**)&ab_side[i][j], (size_t)NB * 2 * C * sizeof(float)));
-        HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
-        const char* e = getenv("TSNET_OVERLAP");
-        overlap = !(e && atoi(e) == 0);
-    }
-
-    if (x3) {    // ---- bf16x3 planes of every conv input (3 planes x 2 bytes per element)
-        std::vector<std::pair<unsigned short**, size_t>> rq;
-        auto want3 = [&](unsigned short** p, size_t elems) { rq.emplace_back(p, (3 * elems + 63) & ~(size_t)63); };
-        want3(&x_img3, NB * H * W * cp_img);
-        want3(&x_lbl3, B * H * W * cp_lbl);
-        raw3_img.assign(cfg.n_downsampling, nullptr);
-        raw3_lbl.assign(cfg.n_downsampling, nullptr);
-        for (int l = 0; l < cfg.n_downsampling; ++l) {
-            const size_t e = (size_t)(H >> l) * (W >> l) * (cfg.ngf << l);
-            want3(&raw3_img[l], NB * e);
-            want3(&raw3_lbl[l], B * e);
-        }
-        want3(&X3, NB * fe); want3(&T3, NB * fe * 2); want3(&tar3, B * fe); want3(&zbar3, B * fe * 2);
-        want3(&pg3, B * fe); want3(&sg3, B * fe); want3(&D3, B * fe);
-        U3.assign(cfg.n_downsampling, nullptr);
-        for (int i = 0; i < cfg.n_downsampling; ++i) want3(&U3[i], B * (size_t)(h << (i + 1)) * (w << (i + 1)) * (C >> i));
-        size_t tot3 = 0;
-        for (auto& r : rq) tot3 += r.second;
-        HIP_TRY(hipMalloc((void**)&arena3, tot3 * sizeof(unsigned short)));
-        size_t o3 = 0;
-        for (auto& r : rq) { *r.first = arena3 + o3; o3 += r.second; }
-    }
+    // fall back to the in_finalize2 kernel (run_conv checks the index range against this size)
+    HIP_TRY(hipMalloc((void**)&fin_counter, 2 * kFinCounterInts * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(fin_counter, 0, 2 * kFinCounterInts * sizeof(int), s));
+    fin_counter_side = fin_counter + kFinCounterInts;
+    // side lane (tsnet_forward): own statistics scratch, counters, (alpha, beta) pairs (above), stream and events
+    HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
 }
 
-// ---- h2 schedule: the 3x3 / stride-1 convolutions read fp32 and apply the producer's InstanceNorm + ReLU while staging (conv_h2.hpp)
-void tsnet_engine::resblock_h2(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float stream_bound,
-                               float* y1, float* y2, int N, int hh, int ww, const unsigned* stream_amax, float amax_add) {
+void tsnet_engine::resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float stream_bound, const unsigned* stream_amax,
+                            float amax_add, float* y1, float* y2, int N, int hh, int ww) {
     const int Cc = c1.cout, HW = hh * ww;
-    auto s1 = next_ab();
-    const bool fp32_stream = stream_bound > 0.f || stream_amax != nullptr;
-    if (fp32_stream) {
-        H2Call a; a.x = Xs; a.bound = stream_bound; a.in_amax = stream_bound > 0.f ? nullptr : stream_amax; a.bound_add = amax_add;
-        a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
-        conv_stats_h2(ctx, c1, a, N, HW, s1.first, s1.second);
-    } else {
-        X3Call a; a.x3 = Xs3; a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
-        conv_stats_x3(ctx, c1, a, N, HW, s1.first, s1.second);
-    }
-    H2Call b; b.x = y1; b.alpha = s1.first; b.beta = s1.second; b.relu = 1; b.bound = std::sqrt((float)HW);   // |IN(.)| <= sqrt(HW - 1)
+    auto s1 = next_ab(ctx);
+    ConvCall a; a.x = Xs; a.bound = stream_bound; a.in_amax = stream_amax; a.bound_add = amax_add;
+    a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
+    conv_stats(ctx, c1, a, N, HW, s1.first, s1.second);
+    ConvCall b; b.x = y1; b.alpha = s1.first; b.beta = s1.second; b.relu = 1; b.bound = std::sqrt((float)HW);   // |IN(.)| <= sqrt(HW - 1)
     b.N = N; b.H = hh; b.W = ww; b.y = y2; b.tclass = TSNET_T_CONV_RES;
-    auto s2 = next_ab();
-    conv_stats_h2(ctx, c2, b, N, HW, s2.first, s2.second);
-    run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs, fp32_stream ? nullptr : Xs3);   // X += IN(y2)
+    auto s2 = next_ab(ctx);
+    conv_stats(ctx, c2, b, N, HW, s2.first, s2.second);
+    run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs);   // X += IN(y2)
 }
 
-// ---- bf16x3 schedule: same graph as the fp32 one; every conv reads planes, producers write planes
-void tsnet_engine::resblock_x3(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, unsigned short* Xs3, float* y1, float* y2, int N, int hh, int ww) {
-    const int Cc = c1.cout, HW = hh * ww;
-    X3Call a; a.x3 = Xs3; a.N = N; a.H = hh; a.W = ww; a.y = y1; a.tclass = TSNET_T_CONV_RES;
-    auto s1 = next_ab();
-    conv_stats_x3(ctx, c1, a, N, HW, s1.first, s1.second);
-    run_norm_act(ctx, y1, s1.first, s1.second, 1, nullptr, N, HW, Cc, nullptr, T3);            // relu(IN(y1)) -> planes only
-    X3Call b; b.x3 = T3; b.N = N; b.H = hh; b.W = ww; b.y = y2; b.tclass = TSNET_T_CONV_RES;
-    auto s2 = next_ab();
-    conv_stats_x3(ctx, c2, b, N, HW, s2.first, s2.second);
-    run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs, Xs3);                       // X += IN(y2): fp32 + planes
-}
-
-void tsnet_engine::encode_x3(Ctx& ctx, std::vector<ConvLayer>& L, const unsigned short* xin3, int N, std::vector<float*>& raw,
-                             std::vector<unsigned short*>& raw3, float* out_fea, unsigned short* out_fea3, int nblocks,
-                             const float* xin_f32, const unsigned* xin_amax) {
+// Encoder.forward (TSNet.py:52-105) on a packed NHWC input whose maximum its producer published; out_fea = final feature map
+void tsnet_engine::encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin, const unsigned* xin_amax, int N, std::vector<float*>& raw,
+                          float* out_fea, int nblocks) {
     int hh = cfg.height, ww = cfg.width;
     auto st = next_ab(ctx);
-    if (xin_f32 && stem_h2r(L)) {
-        H2Call a; a.x = xin_f32; a.in_amax = xin_amax; a.bound = 1.f; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
-        conv_stats_h2(ctx, L[0], a, N, hh * ww, st.first, st.second);
-    } else {
-        X3Call a; a.x3 = xin3; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
-        conv_stats_x3(ctx, L[0], a, N, hh * ww, st.first, st.second);
+    {
+        ConvCall a; a.x = xin; a.in_amax = xin_amax; a.bound = 1.f; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
+        conv_stats(ctx, L[0], a, N, hh * ww, st.first, st.second);
     }
     for (int l = 1; l <= cfg.n_downsampling; ++l) {
-        // the downsampling convolution reads relu(IN(previous)): on the h2 schedule the transform is applied while the im2col tile is
-        // staged (conv_h2r), otherwise one elementwise pass materialises it as bf16x3 planes for conv_x3r
-        const bool via_h2r = h2 && h2r_layer_ok(L[l]) && ((hh / 2) * (ww / 2)) % 128 == 0 && (np == 1 ? L[l].w3 != nullptr : L[l].wh != nullptr);
+        // the downsampling convolution reads relu(IN(previous)): the transform is applied while its operand tile is staged
         auto prev = st;
         st = next_ab(ctx);
-        if (via_h2r) {
-            H2Call d; d.x = raw[l - 1]; d.alpha = prev.first; d.beta = prev.second; d.relu = 1; d.bound = std::sqrt((float)(hh * ww));
-            d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
-            hh /= 2; ww /= 2;
-            conv_stats_h2(ctx, L[l], d, N, hh * ww, st.first, st.second);
-        } else {
-            run_norm_act(ctx, raw[l - 1], prev.first, prev.second, 1, nullptr, N, hh * ww, L[l].cin_pad, nullptr, raw3[l - 1]);
-            X3Call d; d.x3 = raw3[l - 1]; d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
-            hh /= 2; ww /= 2;
-            conv_stats_x3(ctx, L[l], d, N, hh * ww, st.first, st.second);
-        }
+        ConvCall d; d.x = raw[l - 1]; d.alpha = prev.first; d.beta = prev.second; d.relu = 1; d.bound = std::sqrt((float)(hh * ww));
+        d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
+        hh /= 2; ww /= 2;
+        conv_stats(ctx, L[l], d, N, hh * ww, st.first, st.second);
     }
-    const bool use_h2 = h2 && (hh % kPatchRows == 0) && (ww % kPatchCols == 0);
-    run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea, use_h2 ? nullptr : out_fea3);
+    run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea);
     // |relu(IN(.))| <= sqrt(HW) and every block adds one more InstanceNorm output: the stream stays below (blocks + 1) sqrt(HW)
     const float bound = (float)(nblocks + 1) * std::sqrt((float)(hh * ww));
-    for (int i = 0; i < nblocks; ++i) {
-        const ConvLayer &c1 = L[cfg.n_downsampling + 1 + 2 * i], &c2 = L[cfg.n_downsampling + 2 + 2 * i];
-        if (use_h2) resblock_h2(ctx, c1, c2, out_fea, nullptr, bound, Y1, Y2, N, hh, ww);
-        else resblock_x3(ctx, c1, c2, out_fea, out_fea3, Y1, Y2, N, hh, ww);
-    }
+    for (int i = 0; i < nblocks; ++i)
+        resblock(ctx, L[cfg.n_downsampling + 1 + 2 * i], L[cfg.n_downsampling + 2 + 2 * i], out_fea, bound, nullptr, 0.f, Y1, Y2, N, hh, ww);
 }
 
-void tsnet_engine::forward_target_x3(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
-    target_chain_x3(ctx, tar_lbl, B);
-    forward_rest_x3(ctx, tar_bbox, out_rgb, out_flow, B);
+void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B) {
+    const int H = cfg.height, W = cfg.width;
+    {
+        TimeScope ts(ctx, TSNET_T_PACK);
+        PackArgs p{};
+        for (int s = 0; s < K; ++s) { p.img[s] = src_img[s]; p.lbl[s] = src_lbl[s]; p.img_div[s] = src_div[s]; }
+        p.coords = cfg.addcoords ? d_coords : nullptr;
+        p.out = x_img; p.S = K; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 3; p.Cp = cp_img;
+        HIP_TRY(hipMemsetAsync(amax_src(), 0, (size_t)K * B * sizeof(unsigned), ctx.stream));
+        p.amax_out = amax_src();
+        hipLaunchKernelGGL(pack_input_kernel, dim3(pack_grid(H * W), K * B), dim3(256), 0, ctx.stream, p);
+        check_launch("pack_input(img)");
+        for (int s = 0; s < K; ++s)
+            HIP_TRY(hipMemcpyAsync(bbox_copy + (size_t)s * Bmax * H * W, src_bbox[s], (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
+    }
+    encode(ctx, img_enc, x_img, amax_src(), K * B, raw_img, X, cfg.enc_blocks);
+    run_l2norm(ctx, X, shat, K * B * P, C);
+    // the per-source half of FuseNet's first convolution (conv(cat(src, tar)) = conv_src(src) + conv_tar(tar), TSNet.py:195-197)
+    // depends on the sources only: computed here, so a driving frame of a clip does not pay for it
+    ConvCall a; a.x = X; a.bound = enc_bound(); a.N = K * B; a.H = h; a.W = w; a.y = F1s;
+    conv(ctx, fuse_c1_src, a);
+    cached_B = B;
 }
 
 // Everything that depends on the driving frame only: label encoder, its L2-normalised features and the target half of
 // FuseNet's first convolution.  Independent of the source encoder, so a full forward runs it on the side stream.
-void tsnet_engine::target_chain_x3(Ctx& ctx, const float* tar_lbl, int B) {
+void tsnet_engine::target_chain(Ctx& ctx, const float* tar_lbl, int B) {
     const int H = cfg.height, W = cfg.width;
     {
         TimeScope ts(ctx, TSNET_T_PACK);
         PackArgs p{};
         p.img[0] = nullptr; p.lbl[0] = tar_lbl;
         p.coords = cfg.addcoords ? d_coords : nullptr;
-        const bool f32 = stem_h2r(lbl_enc);
-        p.out = f32 ? x_lbl : nullptr; p.out3 = f32 ? nullptr : x_lbl3; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
-        if (f32) { HIP_TRY(hipMemsetAsync(amax_tar(), 0, (size_t)B * sizeof(unsigned), ctx.stream)); p.amax_out = amax_tar(); }
+        p.out = x_lbl; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
+        HIP_TRY(hipMemsetAsync(amax_tar(), 0, (size_t)B * sizeof(unsigned), ctx.stream));
+        p.amax_out = amax_tar();
         hipLaunchKernelGGL(pack_input_kernel, dim3(pack_grid(H * W), B), dim3(256), 0, ctx.stream, p);
         check_launch("pack_input(lbl)");
     }
-    encode_x3(ctx, lbl_enc, x_lbl3, B, raw_lbl, raw3_lbl, tar_fea, tar3, 0, x_lbl, amax_tar());
+    encode(ctx, lbl_enc, x_lbl, amax_tar(), B, raw_lbl, tar_fea, 0);
     run_l2norm(ctx, tar_fea, that, B * P, C);
-    if (h2_feat()) {                                                                   // shared target half of fuse conv1
-        H2Call t; t.x = tar_fea; t.bound = std::sqrt((float)P); t.N = B; t.H = h; t.W = w; t.y = FT;
-        rh2(ctx, fuse_c1_tar, t);
-    } else {
-        X3Call t; t.x3 = tar3; t.N = B; t.H = h; t.W = w; t.y = FT;
-        rx3(ctx, fuse_c1_tar, t);
-    }
+    ConvCall t; t.x = tar_fea; t.bound = std::sqrt((float)P); t.N = B; t.H = h; t.W = w; t.y = FT;      // shared target half of fuse conv1
+    conv(ctx, fuse_c1_tar, t);
 }
 
-void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
+void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
     const int H = cfg.height, W = cfg.width, NB = K * B;
-    // ---- transformation branch (fp32 features; unchanged kernels).  Its result (pg) is first needed by the decoder, and
-    // its kernels are latency-bound (384 workgroups): with the side stream available it runs there, concurrently with the
-    // MFMA-bound synthesis branch below, and joins before dec_map.
-    const bool fork = overlap && side_stream && !ctx.timing && ctx.lane == 0;
+    // ---- transformation branch.  Its result (pg) is first needed by the decoder, and its kernels are latency-bound (384 workgroups):
+    // with the side stream available it runs there, concurrently with the MFMA-bound synthesis branch below, and joins before dec_map.
+    const bool fork = side_stream && !ctx.timing && ctx.lane == 0;
     Ctx cside; cside.stream = side_stream; cside.lane = 1;
     Ctx& cx = fork ? cside : ctx;
     SideJoin join2{fork ? side_stream : nullptr, ctx.stream, ev_join2};
@@ -1519,249 +835,73 @@ void tsnet_engine::forward_rest_x3(Ctx& ctx, const float* tar_bbox, float* out_r
     run_flow(cx, fa, NB);
     if (out_flow)
         HIP_TRY(hipMemcpyAsync(out_flow, flow, (size_t)NB * P * 2 * sizeof(float), hipMemcpyDeviceToDevice, cx.stream));
-    run_warp(cx, X, flow, pg, B, K, h, w, C, pg3);
+    run_warp(cx, X, flow, pg, B, K, h, w, C);
     if (fork) HIP_TRY(hipEventRecord(ev_join2, side_stream));
 
     // ---- synthesis branch
+    const float sqP = std::sqrt((float)P);
     {
-        auto s1 = next_ab();
-        auto s2 = next_ab();
+        auto s1 = next_ab(ctx);
+        auto s2 = next_ab(ctx);
         // F1 = conv_src(src) [from set_sources] + conv_tar(tar) [target chain], and its InstanceNorm statistics
         run_add_stats(ctx, F1s, FT, B, F1, NB, P, 2 * C, part, s1.first, s1.second);
-        if (h2_feat()) {
-            H2Call b; b.x = F1; b.alpha = s1.first; b.beta = s1.second; b.relu = 1; b.bound = std::sqrt((float)P);
-            b.N = NB; b.H = h; b.W = w; b.y = F2;
-            conv_stats_h2(ctx, fuse_c2, b, NB, P, s2.first, s2.second);
-        } else {
-            run_norm_act(ctx, F1, s1.first, s1.second, 1, nullptr, NB, P, 2 * C, nullptr, T3);
-            X3Call b; b.x3 = T3; b.N = NB; b.H = h; b.W = w; b.y = F2;
-            conv_stats_x3(ctx, fuse_c2, b, NB, P, s2.first, s2.second);
-        }
+        ConvCall b; b.x = F1; b.alpha = s1.first; b.beta = s1.second; b.relu = 1; b.bound = sqP;
+        b.N = NB; b.H = h; b.W = w; b.y = F2;
+        conv_stats(ctx, fuse_c2, b, NB, P, s2.first, s2.second);
         {
             TimeScope ts(ctx, TSNET_T_ELEMWISE);
-            FuseTailArgs t2{X, tar_fea, F2, s2.first, s2.second, nullptr, B, K, P, C, zbar3};
+            FuseTailArgs t2{X, tar_fea, F2, s2.first, s2.second, zbar, B, K, P, C};
             hipLaunchKernelGGL(fuse_resid_mean_kernel, dim3(ew_grid((size_t)B * P * 2 * C / 4)), dim3(256), 0, ctx.stream, t2);
             check_launch("fuse_resid_mean");
         }
-        X3Call c; c.x3 = zbar3; c.N = B; c.H = h; c.W = w; c.y = sg; c.y3 = sg3;
-        rx3(ctx, fuse_out, c);
+        // zbar = mean over sources of cat(src_fea, tar_fea) + IN(.): bounded by enc_bound + sqrt(P).  fuse_net.conv has no norm behind it:
+        // it publishes max |sg| per image for dec.map_conv's operand scale
+        ConvCall c; c.x = zbar; c.bound = enc_bound() + sqP; c.N = B; c.H = h; c.W = w; c.y = sg;
+        HIP_TRY(hipMemsetAsync(amax_sg(), 0, (size_t)B * sizeof(unsigned), ctx.stream));
+        c.amax_out = amax_sg();
+        conv(ctx, fuse_out, c);
     }
 
     // ---- decoder
     if (fork) HIP_TRY(hipStreamWaitEvent(ctx.stream, ev_join2, 0));
     join2.done = true;
-    // The decoder's stream starts at dec_map's raw output: no a-priori bound.  On the h2 schedule dec_map publishes max |D| (one atomic
-    // max per wave, order-independent) and the convolutions reading the stream derive their fp16 operand scale from it on the device:
-    // D_i = D_0 + (i InstanceNorm outputs), |D_i| <= max |D_0| + i sqrt(P).  (bf16-operand mode: no scales, nothing to publish.)
-    const bool dyn = h2_feat() && np != 1 && P % 128 == 0;      // x3 tiles of dec_map (128 positions) must lie inside one image
-    const float sqP = std::sqrt((float)P);
+    // dec.map_conv reads cat(pg, sg) (TSNet.py:163) formed on load: |pg| <= enc_bound (a convex combination of source features, zero
+    // padded), |sg| <= its published maximum.  The decoder's stream starts at map_conv's raw output: no a-priori bound either, so map_conv
+    // publishes max |D| and the convolutions reading the stream derive their operand scale from it on the device:
+    // D_i = D_0 + (i InstanceNorm outputs), |D_i| <= max |D_0| + i sqrt(P).  (bf16-operand mode: no scales; the maxima are not read.)
     {
-        X3Call a; a.x3 = pg3; a.x23 = sg3; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
-        a.y3 = (cfg.n_blocks > 0 && !h2_feat()) ? D3 : nullptr;
-        if (dyn) { HIP_TRY(hipMemsetAsync(amax_dec(), 0, (size_t)B * sizeof(unsigned), ctx.stream)); a.amax_out = amax_dec(); }
-        rx3(ctx, dec_map, a);
+        ConvCall a; a.x = pg; a.x2 = sg; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
+        a.in_amax = amax_sg(); a.bound_add = enc_bound();
+        HIP_TRY(hipMemsetAsync(amax_dec(), 0, (size_t)B * sizeof(unsigned), ctx.stream));
+        a.amax_out = amax_dec();
+        conv(ctx, dec_map, a);
     }
-    for (int i = 0; i < cfg.n_blocks; ++i) {
-        if (h2_feat()) resblock_h2(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, np == 1 ? 1.f : 0.f, DY1, DY2, B, h, w, dyn ? amax_dec() : nullptr, (float)i * sqP);
-        else resblock_x3(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, D3, DY1, DY2, B, h, w);
-    }
+    for (int i = 0; i < cfg.n_blocks; ++i)
+        resblock(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, 0.f, amax_dec(), (float)i * sqP, DY1, DY2, B, h, w);
     const float* cur = D; const float* cal = nullptr; const float* cbe = nullptr;
     int hh = h, ww = w, cc = C;
     for (int i = 0; i < cfg.n_downsampling; ++i) {
         // input of up-convolution i = bilinear x2 of relu(IN(previous)) -- a convex combination of InstanceNorm outputs, bounded by
-        // sqrt(HW) of the low-resolution map; the first one upsamples the unnormalised decoder stream and keeps the bf16x3 path
-        // (the first one upsamples the decoder stream itself: bound = the published max |D_0| + n_blocks sqrt(P), or none needed in bf16 mode)
-        const bool via_h2 = h2 && (cal || dyn || np == 1) && i < 8 && U_f32[i] && (2 * hh) % kPatchRows == 0 && (2 * ww) % kPatchCols == 0 && h2_layer_ok(dec_up[i]) &&
-                            (np == 1 ? dec_up[i].w3 != nullptr : dec_up[i].wh != nullptr) && h2_feat();
+        // sqrt(HW) of the low-resolution map; the first one upsamples the decoder stream itself: published max |D_0| + n_blocks sqrt(P)
         const float in_bound = std::sqrt((float)(hh * ww));
-        run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, via_h2 ? U_f32[i] : nullptr, via_h2 ? nullptr : U3[i]);
-        hh *= 2; ww *= 2;
-        cc /= 2;
-        auto st = next_ab();
-        if (via_h2) {
-            H2Call a; a.x = U_f32[i]; a.bound = in_bound; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
-            if (!cal && np != 1) { a.in_amax = amax_dec(); a.bound_add = (float)cfg.n_blocks * sqP; }
-            conv_stats_h2(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
-        } else {
-            X3Call a; a.x3 = U3[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
-            conv_stats_x3(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
-        }
-        cur = R[i]; cal = st.first; cbe = st.second;
-    }
-    if (!vector_head) throw ArgError("bf16x3 mode needs the vector RGB head (ngf % 16 == 0)");
-    {
-        TimeScope ts(ctx, TSNET_T_CONV);
-        HeadArgs ha{};
-        ha.x = cur; ha.alpha = cal; ha.beta = cbe; ha.w = head_w; ha.bias = dec_head.bias; ha.y = out_rgb;
-        ha.N = B; ha.H = hh; ha.W = ww; ha.C = cc;
-        ha.composite = cfg.pose_composite; ha.fore_x0 = 64; ha.fore_x1 = 192;
-        for (int c = 0; c < 3; ++c) ha.bg[c] = (-cfg.pose_mean[c]) / 255.0f;
-        launch_head(ha, hh, ww, B, ctx.stream);
-    }
-    last_B = B;
-}
-
-// one ResnetBlock on a materialised NHWC tensor Xs (in place): Xs += IN(conv2(relu(IN(conv1(Xs)))))
-void tsnet_engine::resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float* y1, float* y2, int N, int hh, int ww) {
-    const int Cc = c1.cout, HW = hh * ww;
-    ConvCall a; a.x = Xs; a.N = N; a.H = hh; a.W = ww; a.y = y1; a.stat_part = part;
-    run_conv(ctx, c1, a);
-    auto s1 = next_ab();
-    finish_stats(ctx, a, y1, N, HW, Cc, part, s1.first, s1.second);
-    ConvCall b; b.x = y1; b.N = N; b.H = hh; b.W = ww; b.y = y2; b.stat_part = part;
-    norm_input(ctx, y1, s1.first, s1.second, N, HW, Cc, b);
-    run_conv(ctx, c2, b);
-    auto s2 = next_ab();
-    finish_stats(ctx, b, y2, N, HW, Cc, part, s2.first, s2.second);
-    run_norm_act(ctx, y2, s2.first, s2.second, 0, Xs, N, HW, Cc, Xs);
-}
-
-// Encoder.forward on a packed NHWC input; out_fea = final feature map (materialised)
-void tsnet_engine::encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin, int N, int cp, std::vector<float*>& raw, float* out_fea, int nblocks) {
-    (void)cp;
-    int hh = cfg.height, ww = cfg.width;
-    ConvCall a; a.x = xin; a.N = N; a.H = hh; a.W = ww; a.y = raw[0]; a.stat_part = part;
-    run_conv(ctx, L[0], a);
-    auto st = next_ab();
-    finish_stats(ctx, a, raw[0], N, hh * ww, L[0].cout, part, st.first, st.second);
-    for (int l = 1; l <= cfg.n_downsampling; ++l) {
-        ConvCall d; d.x = raw[l - 1]; d.N = N; d.H = hh; d.W = ww; d.y = raw[l]; d.stat_part = part;
-        norm_input(ctx, raw[l - 1], st.first, st.second, N, hh * ww, L[l].cin_pad, d);
-        run_conv(ctx, L[l], d);
-        hh /= 2; ww /= 2;
-        st = next_ab();
-        finish_stats(ctx, d, raw[l], N, hh * ww, L[l].cout, part, st.first, st.second);
-    }
-    run_norm_act(ctx, raw[cfg.n_downsampling], st.first, st.second, 1, nullptr, N, hh * ww, C, out_fea);
-    for (int i = 0; i < nblocks; ++i)
-        resblock(ctx, L[cfg.n_downsampling + 1 + 2 * i], L[cfg.n_downsampling + 2 + 2 * i], out_fea, Y1, Y2, N, hh, ww);
-}
-
-void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B) {
-    const int H = cfg.height, W = cfg.width;
-    {
-        TimeScope ts(ctx, TSNET_T_PACK);
-        PackArgs p{};
-        for (int s = 0; s < K; ++s) { p.img[s] = src_img[s]; p.lbl[s] = src_lbl[s]; p.img_div[s] = src_div[s]; }
-        p.coords = cfg.addcoords ? d_coords : nullptr;
-        const bool f32 = !x3 || stem_h2r(img_enc);
-        p.out = f32 ? x_img : nullptr; p.out3 = f32 ? nullptr : x_img3;
-        p.S = K; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 3; p.Cp = cp_img;
-        if (x3 && f32) { HIP_TRY(hipMemsetAsync(amax_src(), 0, (size_t)K * B * sizeof(unsigned), ctx.stream)); p.amax_out = amax_src(); }
-        hipLaunchKernelGGL(pack_input_kernel, dim3(pack_grid(H * W), K * B), dim3(256), 0, ctx.stream, p);
-        check_launch("pack_input(img)");
-        for (int s = 0; s < K; ++s)
-            HIP_TRY(hipMemcpyAsync(bbox_copy + (size_t)s * Bmax * H * W, src_bbox[s], (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
-    }
-    if (x3) encode_x3(ctx, img_enc, x_img3, K * B, raw_img, raw3_img, X, X3, cfg.enc_blocks, x_img, amax_src());
-    else encode(ctx, img_enc, x_img, K * B, cp_img, raw_img, X, cfg.enc_blocks);
-    run_l2norm(ctx, X, shat, K * B * P, C);
-    if (x3) {
-        // the per-source half of FuseNet's first convolution (conv(cat(src, tar)) = conv_src(src) + conv_tar(tar), TSNet.py:195-197)
-        // depends on the sources only: computed here, so a driving frame of a clip does not pay for it
-        if (h2_feat()) {
-            H2Call a; a.x = X; a.bound = enc_bound(); a.N = K * B; a.H = h; a.W = w; a.y = F1s;
-            rh2(ctx, fuse_c1_src, a);
-        } else {
-            X3Call a; a.x3 = X3; a.N = K * B; a.H = h; a.W = w; a.y = F1s;
-            rx3(ctx, fuse_c1_src, a);
-        }
-    }
-    cached_B = B;
-}
-
-void tsnet_engine::forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
-    if (x3) { forward_target_x3(ctx, tar_lbl, tar_bbox, out_rgb, out_flow, B); return; }
-    const int H = cfg.height, W = cfg.width, NB = K * B;
-    {
-        TimeScope ts(ctx, TSNET_T_PACK);
-        PackArgs p{};
-        p.img[0] = nullptr; p.lbl[0] = tar_lbl;
-        p.coords = cfg.addcoords ? d_coords : nullptr;
-        p.out = x_lbl; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
-        hipLaunchKernelGGL(pack_input_kernel, dim3(pack_grid(H * W), B), dim3(256), 0, ctx.stream, p);
-        check_launch("pack_input(lbl)");
-    }
-    encode(ctx, lbl_enc, x_lbl, B, cp_lbl, raw_lbl, tar_fea, 0);
-
-    // ---- transformation branch
-    run_l2norm(ctx, tar_fea, that, B * P, C);
-    FlowArgs fa{};
-    fa.that = that; fa.shat = shat; fa.tar_bbox = tar_bbox;
-    for (int s = 0; s < K; ++s) fa.src_bbox[s] = bbox_copy + (size_t)s * Bmax * H * W;
-    fa.gx = d_gx; fa.gy = d_gy; fa.flow = flow;
-    fa.B = B; fa.P = P; fa.C = C; fa.h = h; fa.w = w; fa.H = H; fa.W = W; fa.sy = H / h; fa.sx = W / w;
-    run_flow(ctx, fa, NB);
-    if (out_flow)
-        HIP_TRY(hipMemcpyAsync(out_flow, flow, (size_t)NB * P * 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
-    run_warp(ctx, X, flow, pg, B, K, h, w, C);
-
-    // ---- synthesis branch (FuseNet), cat(src_fea, tar_fea) formed inside the conv loader
-    {
-        ConvCall a; a.N = NB; a.H = h; a.W = w; a.y = F1; a.stat_part = part;
-        if (split_fuse) {
-            ConvCall t; t.x = tar_fea; t.N = B; t.H = h; t.W = w; t.y = FT;          // shared target half, once per batch item
-            run_conv(ctx, fuse_c1_tar, t);
-            a.x = X; a.addend = FT; a.add_nmod = B;                                   // per-source half + bias + target half
-            run_conv(ctx, fuse_c1_src, a);
-        } else {
-            a.x = X; a.x2 = tar_fea; a.csplit = C; a.x2_nmod = B;                     // cat formed inside the conv loader
-            run_conv(ctx, fuse_c1, a);
-        }
-        auto s1 = next_ab();
-        finish_stats(ctx, a, F1, NB, P, 2 * C, part, s1.first, s1.second);
-        ConvCall b; b.x = F1; b.N = NB; b.H = h; b.W = w; b.y = F2; b.stat_part = part;
-        norm_input(ctx, F1, s1.first, s1.second, NB, P, 2 * C, b);
-        run_conv(ctx, fuse_c2, b);
-        auto s2 = next_ab();
-        finish_stats(ctx, b, F2, NB, P, 2 * C, part, s2.first, s2.second);
-        {
-            TimeScope ts(ctx, TSNET_T_ELEMWISE);
-            FuseTailArgs t{X, tar_fea, F2, s2.first, s2.second, zbar, B, K, P, C};
-            hipLaunchKernelGGL(fuse_resid_mean_kernel, dim3(ew_grid((size_t)B * P * 2 * C / 4)), dim3(256), 0, ctx.stream, t);
-            check_launch("fuse_resid_mean");
-        }
-        ConvCall c; c.x = zbar; c.N = B; c.H = h; c.W = w; c.y = sg;
-        run_conv(ctx, fuse_out, c);
-    }
-
-    // ---- decoder
-    {
-        ConvCall a; a.x = pg; a.x2 = sg; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
-        run_conv(ctx, dec_map, a);
-    }
-    for (int i = 0; i < cfg.n_blocks; ++i) resblock(ctx, dec_res[2 * i], dec_res[2 * i + 1], D, DY1, DY2, B, h, w);
-    const float* cur = D; const float* cal = nullptr; const float* cbe = nullptr;
-    int hh = h, ww = w, cc = C;
-    for (int i = 0; i < cfg.n_downsampling; ++i) {
         run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, U[i]);
         hh *= 2; ww *= 2;
-        ConvCall a; a.x = U[i]; a.N = B; a.H = hh; a.W = ww; a.y = R[i]; a.stat_part = part;
-        run_conv(ctx, dec_up[i], a);
         cc /= 2;
-        auto st = next_ab();
-        finish_stats(ctx, a, R[i], B, hh * ww, cc, part, st.first, st.second);
+        auto st = next_ab(ctx);
+        ConvCall a; a.x = U[i]; a.bound = in_bound; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
+        if (!cal) { a.in_amax = amax_dec(); a.bound_add = (float)cfg.n_blocks * sqP; }
+        conv_stats(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
         cur = R[i]; cal = st.first; cbe = st.second;
     }
-    if (vector_head) {
+    {
         TimeScope ts(ctx, TSNET_T_CONV);     // it is a convolution: keep it in the conv class for the roofline accounting
         HeadArgs ha{};
-        ha.x = cur; ha.alpha = cal; ha.beta = cbe; ha.w = head_w; ha.bias = dec_head.bias; ha.y = out_rgb;
+        ha.x = cur; ha.alpha = cal; ha.beta = cbe; ha.w = head_w; ha.bias = head_bias; ha.y = out_rgb;
         ha.N = B; ha.H = hh; ha.W = ww; ha.C = cc;
         ha.composite = cfg.pose_composite; ha.fore_x0 = 64; ha.fore_x1 = 192;          // TSNet_pose.py:279
         for (int c = 0; c < 3; ++c) ha.bg[c] = (-cfg.pose_mean[c]) / 255.0f;             // TSNet_pose.py:276
         launch_head(ha, hh, ww, B, ctx.stream);
-        last_B = B;
-        return;
     }
-    ConvCall hd; hd.x = cur; hd.N = B; hd.H = hh; hd.W = ww;
-    norm_input(ctx, R[cfg.n_downsampling - 1], cal, cbe, B, hh * ww, cc, hd);
-    hd.y = out_rgb; hd.act = 1; hd.out_nchw = 1;
-    if (cfg.pose_composite) {
-        hd.composite = 1;
-        for (int c = 0; c < 3; ++c) hd.bg[c] = (-cfg.pose_mean[c]) / 255.0f;   // TSNet_pose.py:276
-    }
-    run_conv(ctx, dec_head, hd);
     last_B = B;
 }
 
@@ -1788,7 +928,7 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
     if (cfg->n_source < 1 || cfg->n_source > TSNET_MAX_SOURCES) return bad("n_source must be in 1..8");
     if (cfg->label_nc < 1) return bad("label_nc must be >= 1");
     if (cfg->n_downsampling < 1 || cfg->n_downsampling > 5) return bad("n_downsampling must be in 1..5");
-    if (cfg->ngf < 4 || (cfg->ngf & (cfg->ngf - 1))) return bad("ngf must be a power of two >= 4");
+    if (cfg->ngf < 8 || (cfg->ngf & (cfg->ngf - 1))) return bad("ngf must be a power of two >= 8");
     if (cfg->n_blocks < 0 || cfg->enc_blocks < 0) return bad("block counts must be >= 0");
     const int ds = 1 << cfg->n_downsampling;
     if (cfg->height < ds * 2 || cfg->width < ds * 2 || cfg->height % ds || cfg->width % ds)
@@ -1796,6 +936,7 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
     if (cfg->max_batch < 1) return bad("max_batch must be >= 1");
     if (cfg->pose_composite && (cfg->height != 256 || cfg->width != 256))
         return bad("pose composite is defined for 256x256 frames only (TSNet_pose.py:277-280)");
+    if (cfg->operand_mode != 0 && cfg->operand_mode != 1) return bad("operand_mode must be 0 (fp32-class) or 1 (bf16 operands)");
     try {
         tsnet_engine* e = new tsnet_engine();
         e->cfg = *cfg;
@@ -1803,19 +944,8 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
         for (int s = 0; s < TSNET_MAX_SOURCES; ++s) e->src_div[s] = 255.0f;
         e->C = cfg->ngf << cfg->n_downsampling;
         e->h = cfg->height / ds; e->w = cfg->width / ds; e->P = e->h * e->w;
+        e->np = cfg->operand_mode == 1 ? 1 : 3;
         e->build_layers();
-        { const char* lg = getenv("TSNET_CONV_LEGACY"); e->fuse_norm_in_loader = lg && atoi(lg); }
-        { const char* vh = getenv("TSNET_VECTOR_HEAD"); e->vector_head = !(vh && !atoi(vh)); }
-        { const char* x = getenv("TSNET_X3");
-          // bf16x3 convs (conv_x3.hpp): needs 16-channel granularity everywhere except the stems, and the vector head
-          e->x3 = !(x && !atoi(x)) && (cfg->ngf % 16 == 0) && e->vector_head && !e->fuse_norm_in_loader; }
-        { const char* hh2 = getenv("TSNET_H2"); e->h2 = e->x3 && !(hh2 && !atoi(hh2)); }
-        if (cfg->operand_mode != 0 && cfg->operand_mode != 1) return bad("operand_mode must be 0 (fp32-class) or 1 (bf16 operands)");
-        if (cfg->operand_mode == 1) {
-            if (!e->x3) return bad("bf16 operands need the split-plane schedule (ngf % 16 == 0)");
-            e->np = 1;
-        }
-        { const char* sf = getenv("TSNET_SPLIT_FUSE"); e->split_fuse = !e->fuse_norm_in_loader && !(sf && !atoi(sf)); }
         *out = e;
     } catch (const std::exception& ex) { g_create_error = ex.what(); return TSNET_ERR_NOMEM; }
     return TSNET_OK;
@@ -1871,9 +1001,7 @@ int tsnet_finalize(tsnet_handle h, void* stream) {
 
 void tsnet_destroy(tsnet_handle h) {
     if (!h) return;
-    (void)hipFree(h->arena3); (void)hipFree(h->fin_counter); (void)hipFree(h->train_ws); (void)hipFree(h->amax);
-    (void)hipFree(h->part_side); (void)hipFree(h->fin_counter_side);
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) (void)hipFree(h->ab_side[i][j]);
+    (void)hipFree(h->fin_counter); (void)hipFree(h->train_ws); (void)hipFree(h->amax);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1933,7 +1061,7 @@ int tsnet_forward_target(tsnet_handle h, const float* tar_lbl, const float* tar_
 
 int tsnet_forward(tsnet_handle h, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox,
                   const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B, void* stream) {
-    if (h && h->finalized && h->x3 && h->overlap && h->side_stream && !h->timing.on && tar_lbl && tar_bbox && out_rgb) {
+    if (h && h->finalized && h->side_stream && !h->timing.on && tar_lbl && tar_bbox && out_rgb) {
         // Full forward on two lanes: the driving-frame chain (label encoder, L2 norm, target half of FuseNet conv1 --
         // small launches that leave most CUs idle at B = 4) runs on the engine's side stream while the caller's stream
         // encodes the sources; they join before the flow kernel.  Same kernels, same arithmetic: the result is
@@ -1947,14 +1075,14 @@ int tsnet_forward(tsnet_handle h, const float* const* src_img, const float* cons
         // from here on the side lane has work in flight: whatever happens below (an exception included), the caller's stream waits
         // for it before this call returns -- the side lane must not outlive the call
         SideJoin join{h->side_stream, main, h->ev_join};
-        h->target_chain_x3(cs, tar_lbl, B);
+        h->target_chain(cs, tar_lbl, B);
         HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
         const int rc = tsnet_set_sources(h, src_img, src_lbl, src_bbox, B, stream);
         HIP_TRY(hipStreamWaitEvent(main, h->ev_join, 0));
         join.done = true;
         if (rc != TSNET_OK) return rc;
         Ctx ctx; ctx.stream = main;
-        h->forward_rest_x3(ctx, tar_bbox, out_rgb, out_flow, B);
+        h->forward_rest(ctx, tar_bbox, out_rgb, out_flow, B);
         API_END(h)
     }
     int rc = tsnet_set_sources(h, src_img, src_lbl, src_bbox, B, stream);
@@ -2079,140 +1207,95 @@ const char* tsnet_op_last_error(void) { return g_op_error.c_str(); }
       catch (const std::exception& e) { g_op_error = e.what(); return TSNET_ERR_HIP; } \
     return TSNET_OK;
 
+namespace {
+// one convolution layer with its own packed weights, for the operator entry points
+struct OpLayer {
+    ConvLayer L;
+    float* wd = nullptr; float* bd = nullptr; float* un = nullptr; unsigned short* wq = nullptr;
+    OpLayer(const float* w_oihw, const float* bias, int Cin, int Cout, int ks, int stride, int pad, int reflect, int nprod, hipStream_t s) {
+        L.name = "op"; L.cin_real = Cin; L.cin_pad = conv_cin_pad(Cin); L.cin_total = Cin; L.cout = Cout; L.ks = ks; L.stride = stride; L.pad = pad;
+        L.reflect = reflect; L.kpad = conv_kpad(ks, L.cin_pad); L.npad = conv_npad(Cout);
+        if (L.cin_pad != Cin) throw ArgError("conv2d op: Cin must be 8 or a multiple of 16 (pad channels with zeros)");
+        const size_t wn = (size_t)Cout * Cin * ks * ks;
+        std::vector<float> hw(wn);
+        HIP_TRY(hipMemcpy(hw.data(), w_oihw, wn * sizeof(float), hipMemcpyDefault));
+        float mx = 0.f;
+        for (float v : hw) mx = std::max(mx, std::fabs(v));
+        const int planes = nprod == 1 ? 1 : 2;
+        const int sw = (nprod != 1 && mx > 0.f) ? h2_scale_log2(mx) : 0;
+        HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&wq, (size_t)L.kpad * L.npad * 2 * planes));
+        HIP_TRY(hipMalloc((void**)&un, sizeof(float)));
+        HIP_TRY(hipMemcpy(wd, hw.data(), wn * sizeof(float), hipMemcpyHostToDevice));
+        const float unscale = std::ldexp(1.0f, -sw);
+        HIP_TRY(hipMemcpy(un, &unscale, sizeof(float), hipMemcpyHostToDevice));
+        pack_layer(wd, L, wq, planes, std::ldexp(1.0f, sw), s);
+        if (bias) {
+            HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
+            HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
+        }
+        L.wq = wq; L.w_unscale = nprod == 1 ? nullptr : un; L.bias = bd;
+    }
+    ~OpLayer() { (void)hipFree(wd); (void)hipFree(wq); (void)hipFree(un); (void)hipFree(bd); }
+    OpLayer(const OpLayer&) = delete;
+    OpLayer& operator=(const OpLayer&) = delete;
+};
+}  // namespace
+
 int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
-                    int ksize, int stride, int pad, int pad_mode, const float* in_alpha, const float* in_beta,
-                    int in_relu, int act, float* y, void* stream) {
+                    int ksize, int stride, int pad, int pad_mode, const float* in_alpha, const float* in_beta, int in_relu,
+                    float bound, int nprod, int kernel, int tile, float* y, void* stream) {
     OP_BEGIN
     if (!x || !w_oihw || !y) throw ArgError("null tensor");
-    if (Cin < 4 || (Cin & (Cin - 1))) throw ArgError("conv2d op: Cin must be a power of two >= 4 (pad channels with zeros)");
+    if (nprod != 1 && nprod != 3 && nprod != 4) throw ArgError("conv2d op: 1 (bf16 operands), 3 or 4 products");
     hipStream_t s = (hipStream_t)stream;
     Ctx ctx; ctx.stream = s;
-    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
-    L.reflect = pad_mode; L.kpad = conv_kpad(ksize, Cin); L.npad = conv_npad(Cout);
-    const size_t wn = (size_t)Cout * Cin * ksize * ksize;
-    float *wd = nullptr, *wp = nullptr, *wp2 = nullptr, *bd = nullptr;
+    OpLayer op(w_oihw, bias, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s);
+    ConvCall c; c.x = x; c.alpha = in_alpha; c.beta = in_beta; c.relu = in_relu; c.bound = bound; c.N = N; c.H = H; c.W = W; c.y = y;
+    c.nprod = nprod; c.kernel = kernel; c.tile = tile;
+    run_conv(ctx, op.L, c);
+    HIP_TRY(hipStreamSynchronize(s));
+    OP_END
+}
+
+int tsnet_op_conv2d_cat(const float* x, const float* x2, int N, int H, int W, int C1, int C2, int x2_nmod, const float* w_oihw, const float* bias, int Cout,
+                        int ksize, int stride, int pad, int pad_mode, float bound, int nprod, float* y, void* stream) {
+    OP_BEGIN
+    if (!x || !x2 || !w_oihw || !y) throw ArgError("null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    Ctx ctx; ctx.stream = s;
+    OpLayer op(w_oihw, bias, C1 + C2, Cout, ksize, stride, pad, pad_mode, nprod, s);
+    ConvCall c; c.x = x; c.x2 = x2; c.csplit = C1; c.x2_nmod = x2_nmod; c.bound = bound; c.N = N; c.H = H; c.W = W; c.y = y; c.nprod = nprod;
+    run_conv(ctx, op.L, c);
+    HIP_TRY(hipStreamSynchronize(s));
+    OP_END
+}
+
+int tsnet_op_head(const float* x, int N, int H, int W, int C, const float* in_alpha, const float* in_beta, const float* w_oihw, const float* bias,
+                  int composite, const float* bg, float* y, void* stream) {
+    OP_BEGIN
+    if (!x || !w_oihw || !bias || !y) throw ArgError("null tensor");
+    if (C < 4 || (C & 3)) throw ArgError("head op: C must be a multiple of 4");
+    if (in_alpha && !in_beta) throw ArgError("head op: alpha without beta");
+    hipStream_t s = (hipStream_t)stream;
+    float *wd = nullptr, *tab = nullptr, *bd = nullptr;
+    const size_t wn = (size_t)3 * C * 49;
     HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&wp, (size_t)L.kpad * L.npad * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&wp2, (size_t)L.kpad * L.npad * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&tab, ((size_t)49 * C * 4 + 64) * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&bd, 4 * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(tab, 0, ((size_t)49 * C * 4 + 64) * sizeof(float), s));
     HIP_TRY(hipMemcpy(wd, w_oihw, wn * sizeof(float), hipMemcpyDefault));
-    pack_layer_weights(wd, wp, wp2, L, s);
-    if (bias) {
-        HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
-        HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
-    }
-    L.w = wp; L.w2 = wp2; L.bias = bd;
-    ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.alpha = in_alpha; c.beta = in_beta; c.in_relu = in_relu; c.y = y; c.act = act;
-    run_conv(ctx, L, c);
+    HIP_TRY(hipMemcpy(bd, bias, 3 * sizeof(float), hipMemcpyDefault));
+    hipLaunchKernelGGL(pack_head_weights_kernel, dim3(64), dim3(256), 0, s, wd, tab, C);
+    check_launch("pack_head_weights");
+    HeadArgs ha{};
+    ha.x = x; ha.alpha = in_alpha; ha.beta = in_alpha ? in_beta : nullptr; ha.w = tab; ha.bias = bd; ha.y = y;
+    ha.N = N; ha.H = H; ha.W = W; ha.C = C;
+    ha.composite = composite; ha.fore_x0 = 64; ha.fore_x1 = 192;
+    for (int c = 0; c < 3; ++c) ha.bg[c] = bg ? bg[c] : 0.f;
+    launch_head(ha, H, W, N, s);
     HIP_TRY(hipStreamSynchronize(s));
-    (void)hipFree(wd); (void)hipFree(wp); (void)hipFree(wp2); (void)hipFree(bd);
-    OP_END
-}
-
-int tsnet_op_conv2d_x3(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
-                       int ksize, int stride, int pad, int pad_mode, int tile, float* y, void* stream) {
-    OP_BEGIN
-    if (!x || !w_oihw || !y) throw ArgError("null tensor");
-    if (Cin < 8 || (Cin & (Cin - 1))) throw ArgError("conv2d_x3 op: Cin must be a power of two >= 8");
-    hipStream_t s = (hipStream_t)stream;
-    Ctx ctx; ctx.stream = s;
-    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
-    L.reflect = pad_mode; L.kpad = conv_kpad(ksize, Cin); L.npad = conv_npad(Cout);
-    const size_t wn = (size_t)Cout * Cin * ksize * ksize, xn = (size_t)N * H * W * Cin;
-    float *wd = nullptr, *bd = nullptr; unsigned short *w3 = nullptr, *x3 = nullptr;
-    HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&w3, (size_t)L.kpad * L.npad * 6));
-    HIP_TRY(hipMalloc((void**)&x3, xn * 6));
-    HIP_TRY(hipMemcpy(wd, w_oihw, wn * sizeof(float), hipMemcpyDefault));
-    hipLaunchKernelGGL(pack_weights_x3_kernel, dim3(ew_grid((size_t)L.kpad * L.npad)), dim3(256), 0, s, wd, w3,
-                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, Cin, 0);
-    check_launch("pack_weights_x3");
-    if (bias) {
-        HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
-        HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
-    }
-    run_split3(ctx, x, x3, xn);
-    L.w3 = w3; L.bias = bd;
-    X3Call c; c.x3 = x3; c.N = N; c.H = H; c.W = W; c.y = y; c.variant = tile;
-    run_conv_x3(ctx, L, c);
-    HIP_TRY(hipStreamSynchronize(s));
-    (void)hipFree(wd); (void)hipFree(w3); (void)hipFree(x3); (void)hipFree(bd);
-    OP_END
-}
-
-int tsnet_op_conv2d_h2(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int pad_mode,
-                       const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, int tile_n, float* y, void* stream) {
-    OP_BEGIN
-    if (!x || !w_oihw || !y) throw ArgError("null tensor");
-    if (Cin < 16 || (Cin & 15)) throw ArgError("conv2d_h2 op: Cin must be a multiple of 16");
-    hipStream_t s = (hipStream_t)stream;
-    Ctx ctx; ctx.stream = s;
-    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = 3; L.stride = 1; L.pad = 1;
-    L.reflect = pad_mode; L.kpad = conv_kpad(3, Cin); L.npad = conv_npad(Cout);
-    if (L.npad % 64) L.npad = round_up(Cout, 64);
-    const size_t wn = (size_t)Cout * Cin * 9;
-    std::vector<float> hw(wn);
-    HIP_TRY(hipMemcpy(hw.data(), w_oihw, wn * sizeof(float), hipMemcpyDefault));
-    float mx = 0.f;
-    for (float v : hw) mx = std::max(mx, std::fabs(v));
-    const int sw = mx > 0.f ? h2_scale_log2(mx) : 0;
-    float *wd = nullptr, *bd = nullptr, *un = nullptr; unsigned short* wh = nullptr;
-    HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&wh, (size_t)L.kpad * L.npad * 4));
-    HIP_TRY(hipMalloc((void**)&un, sizeof(float)));
-    HIP_TRY(hipMemcpy(wd, hw.data(), wn * sizeof(float), hipMemcpyHostToDevice));
-    const float unscale = std::ldexp(1.0f, -sw);
-    HIP_TRY(hipMemcpy(un, &unscale, sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(pack_weights_h2_kernel, dim3(ew_grid((size_t)L.kpad * L.npad)), dim3(256), 0, s, wd, wh, std::ldexp(1.0f, sw),
-                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, Cin, 0);
-    check_launch("pack_weights_h2");
-    if (bias) {
-        HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
-        HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
-    }
-    L.wh = wh; L.wh_unscale = un; L.bias = bd;
-    H2Call c; c.x = x; c.alpha = in_alpha; c.beta = in_beta; c.relu = in_relu; c.bound = bound; c.N = N; c.H = H; c.W = W; c.y = y;
-    c.nprod = nprod; c.bn = tile_n;
-    run_conv_h2(ctx, L, c);
-    HIP_TRY(hipStreamSynchronize(s));
-    (void)hipFree(wd); (void)hipFree(wh); (void)hipFree(un); (void)hipFree(bd);
-    OP_END
-}
-
-int tsnet_op_conv2d_h2r(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int ksize,
-                        const float* in_alpha, const float* in_beta, int in_relu, float bound, int nprod, float* y, void* stream) {
-    OP_BEGIN
-    if (!x || !w_oihw || !y) throw ArgError("null tensor");
-    if (ksize != 3 && ksize != 7) throw ArgError("conv2d_h2r op: 3 (stride 2, zero pad 1) or 7 (stride 1, reflection pad 3)");
-    hipStream_t s = (hipStream_t)stream;
-    Ctx ctx; ctx.stream = s;
-    ConvLayer L; L.name = "op"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = ksize;
-    L.stride = ksize == 3 ? 2 : 1; L.pad = ksize == 3 ? 1 : 3; L.reflect = ksize == 7;
-    L.kpad = conv_kpad(ksize, Cin); L.npad = std::max(conv_npad(Cout), round_up(Cout, 64));
-    const size_t wn = (size_t)Cout * Cin * ksize * ksize;
-    std::vector<float> hw(wn);
-    HIP_TRY(hipMemcpy(hw.data(), w_oihw, wn * sizeof(float), hipMemcpyDefault));
-    float mx = 0.f;
-    for (float v : hw) mx = std::max(mx, std::fabs(v));
-    const int sw = mx > 0.f ? h2_scale_log2(mx) : 0;
-    float *wd = nullptr, *bd = nullptr, *un = nullptr; unsigned short* wh = nullptr;
-    HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&wh, (size_t)L.kpad * L.npad * 4));
-    HIP_TRY(hipMalloc((void**)&un, sizeof(float)));
-    HIP_TRY(hipMemcpy(wd, hw.data(), wn * sizeof(float), hipMemcpyHostToDevice));
-    const float unscale = std::ldexp(1.0f, -sw);
-    HIP_TRY(hipMemcpy(un, &unscale, sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(pack_weights_h2_kernel, dim3(ew_grid((size_t)L.kpad * L.npad)), dim3(256), 0, s, wd, wh, std::ldexp(1.0f, sw),
-                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, Cin, 0);
-    check_launch("pack_weights_h2");
-    if (bias) {
-        HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
-        HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
-    }
-    L.wh = wh; L.wh_unscale = un; L.bias = bd;
-    H2Call c; c.x = x; c.alpha = in_alpha; c.beta = in_beta; c.relu = in_relu; c.bound = bound; c.N = N; c.H = H; c.W = W; c.y = y; c.nprod = nprod;
-    run_conv_h2r(ctx, L, c);
-    HIP_TRY(hipStreamSynchronize(s));
-    (void)hipFree(wd); (void)hipFree(wh); (void)hipFree(un); (void)hipFree(bd);
+    (void)hipFree(wd); (void)hipFree(tab); (void)hipFree(bd);
     OP_END
 }
 
@@ -2370,88 +1453,45 @@ int tsnet_vl2ch(const float* labels, int B, int HW, int num_classes, float* out,
 int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int pad_mode, int norm,
                      int variant, int iters, float* ms_out, void* stream) {
     OP_BEGIN
-    if (Cin < 4 || (Cin & (Cin - 1)) || iters < 1 || !ms_out) throw ArgError("bench_conv: bad argument");
+    if (iters < 1 || !ms_out) throw ArgError("bench_conv: bad argument");
     hipStream_t s = (hipStream_t)stream;
     Ctx ctx; ctx.stream = s;
-    ConvLayer L; L.name = "bench"; L.cin_real = Cin; L.cin_pad = Cin; L.cin_total = Cin; L.cout = Cout; L.ks = ksize; L.stride = stride; L.pad = pad;
-    L.reflect = pad_mode; L.kpad = conv_kpad(ksize, Cin); L.npad = conv_npad(Cout);
+    // variant (-1 = the layer's own kernel and tile): bits 0-11 tile code (ConvCall::tile), bit 12 general kernel, bit 13 bf16 operands,
+    // bits 16-23 ablation mask, bits 24-31 experiment mask (tools build)
+    const int v = variant < 0 ? 0 : variant;
+    const int nprod = (v & 8192) ? 1 : 3;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
-    const size_t xn = (size_t)N * H * W * Cin, yn = (size_t)N * Ho * Wo * Cout, wn = (size_t)L.kpad * L.npad;
-    float *x = nullptr, *y = nullptr, *w = nullptr, *al = nullptr, *be = nullptr;
-    if (norm && variant >= 0 && (variant & (4096 | 8192)) && !(variant & 16384)) throw ArgError("bench_conv: the LDS-DMA kernels take no input transform");
-    HIP_TRY(hipMalloc((void**)&x, xn * 4)); HIP_TRY(hipMalloc((void**)&y, yn * 4)); HIP_TRY(hipMalloc((void**)&w, wn * 4));
+    const size_t xn = (size_t)N * H * W * Cin, yn = (size_t)N * Ho * Wo * Cout, wn = (size_t)Cout * Cin * ksize * ksize;
+    float *x = nullptr, *y = nullptr, *al = nullptr, *be = nullptr;
+    HIP_TRY(hipMalloc((void**)&x, xn * 4)); HIP_TRY(hipMalloc((void**)&y, yn * 4));
     HIP_TRY(hipMalloc((void**)&al, (size_t)N * Cin * 4)); HIP_TRY(hipMalloc((void**)&be, (size_t)N * Cin * 4));
     // pseudo-random fill (not zeros: MI355X clocks higher on zero operands, cdna_hip_programming.md rule 25)
     std::vector<float> hbuf(std::max(std::max(xn, wn), (size_t)N * Cin));
     unsigned st = 12345u;
     auto fill = [&](float* d, size_t n, float scale, float off) {
         for (size_t i = 0; i < n; ++i) { st = st * 1664525u + 1013904223u; hbuf[i] = off + scale * ((float)(st >> 8) / 16777216.0f - 0.5f); }
-        HIP_TRY(hipMemcpy(d, hbuf.data(), n * 4, hipMemcpyHostToDevice));
+        if (d) HIP_TRY(hipMemcpy(d, hbuf.data(), n * 4, hipMemcpyHostToDevice));
     };
-    fill(x, xn, 2.f, 0.f); fill(w, wn, 0.1f, 0.f); fill(al, (size_t)N * Cin, 1.f, 1.f); fill(be, (size_t)N * Cin, 0.5f, 0.f);
-    L.w = w; L.w2 = w; L.bias = nullptr;   // timing only: both kernels stream the same random buffer
-    if (variant >= 0 && (variant & 8192)) {        // bf16x3 kernel: split the same random operands into planes
-        unsigned short *x3 = nullptr, *w3 = nullptr;
-        HIP_TRY(hipMalloc((void**)&x3, xn * 6)); HIP_TRY(hipMalloc((void**)&w3, wn * 6));
-        run_split3(ctx, x, x3, xn); run_split3(ctx, w, w3, wn);
-        L.w3 = w3;
-        X3Call xc; xc.x3 = x3; xc.N = N; xc.H = H; xc.W = W; xc.y = y; xc.variant = variant;
-        for (int i = 0; i < 2; ++i) run_conv_x3(ctx, L, xc);
+    fill(x, xn, 2.f, 0.f); fill(al, (size_t)N * Cin, 1.f, 1.f); fill(be, (size_t)N * Cin, 0.5f, 0.f);
+    fill(nullptr, wn, 0.1f, 0.f);
+    {
+        OpLayer op(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s);
+        ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = norm ? 64.f : 1.f; c.nprod = nprod;
+        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : 0; c.abl = (v >> 16) & 255; c.opt = (v >> 24) & 255;
+        if (norm) { c.alpha = al; c.beta = be; c.relu = 1; }
+        for (int i = 0; i < 2; ++i) run_conv(ctx, op.L, c);
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) run_conv_x3(ctx, L, xc);
+        for (int i = 0; i < iters; ++i) run_conv(ctx, op.L, c);
         HIP_TRY(hipEventRecord(e1, s));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         *ms_out = ms / iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(al); (void)hipFree(be); (void)hipFree(x3); (void)hipFree(w3);
-        return TSNET_OK;
     }
-    if (variant >= 0 && (variant & 16384)) {       // conv_h2: fp32 input (optionally normalised on load), fp16x2 weight planes
-        unsigned short* wh = nullptr; float* un = nullptr;
-        HIP_TRY(hipMalloc((void**)&wh, wn * 4)); HIP_TRY(hipMalloc((void**)&un, 4));
-        const float unscale = 1.0f / 262144.f;
-        HIP_TRY(hipMemcpy(un, &unscale, 4, hipMemcpyHostToDevice));
-        {   // the random buffer is already laid out [K][Npad]-like: split it in place order (timing only)
-            hipLaunchKernelGGL(pack_weights_h2_kernel, dim3(ew_grid(wn)), dim3(256), 0, s, w, wh, 262144.f, L.npad, L.kpad / (ksize * ksize), L.kpad / (ksize * ksize), ksize, L.kpad, L.npad,
-                               L.kpad / (ksize * ksize), 0);
-            check_launch("pack_weights_h2(bench)");
-        }
-        L.wh = wh; L.wh_unscale = un;
-        H2Call hc; hc.x = x; hc.N = N; hc.H = H; hc.W = W; hc.y = y; hc.bound = norm ? 64.f : 1.f;
-        hc.bn = (variant & 1) ? 128 : 64; hc.nprod = (variant & 4) ? 4 : 3; hc.abl = (variant >> 16) & 127;
-        if (norm) { hc.alpha = al; hc.beta = be; hc.relu = 1; }
-        for (int i = 0; i < 2; ++i) run_conv_h2(ctx, L, hc);
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) run_conv_h2(ctx, L, hc);
-        HIP_TRY(hipEventRecord(e1, s));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        *ms_out = ms / iters;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(al); (void)hipFree(be); (void)hipFree(wh); (void)hipFree(un);
-        return TSNET_OK;
-    }
-    ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.variant = variant;
-    if (norm) { c.alpha = al; c.beta = be; c.in_relu = 1; }
-    for (int i = 0; i < 2; ++i) run_conv(ctx, L, c);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) run_conv(ctx, L, c);
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *ms_out = ms / iters;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(al); (void)hipFree(be);
+    (void)hipFree(x); (void)hipFree(y); (void)hipFree(al); (void)hipFree(be);
     OP_END
 }
 

@@ -14,8 +14,7 @@
 // (NOT -inf), as in the reference.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "conv_igemm.hpp"
-#include "split3.hpp"
+#include "conv_common.hpp"
 
 namespace tsnet {
 
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(64 * kFlowWaves) void flow_kernel(FlowArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         for (int k = 0; k < a.C; k += 8) {
-            const F4 av = ld4(ap + k);
+            const F4 av = *reinterpret_cast<const F4*>(ap + k);
             const F4 bv = *reinterpret_cast<const F4*>(bp + k);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -148,7 +147,6 @@ struct WarpArgs {
     const float* flow;   // (K*B, P, 2)
     float* out;          // (B, P, C)
     int B, K, h, w, C;
-    unsigned short* out3;  // null, or bf16x3 planes of out
 };
 
 __global__ __launch_bounds__(256) void warp_mean_kernel(WarpArgs a) {
@@ -187,7 +185,6 @@ __global__ __launch_bounds__(256) void warp_mean_kernel(WarpArgs a) {
         const float kf = (float)a.K;
         sum.x /= kf; sum.y /= kf; sum.z /= kf; sum.w /= kf;
         *reinterpret_cast<float4*>(a.out + ((size_t)b * P + p) * a.C + c) = sum;
-        if (a.out3) split3_store_at(sum, a.out3, total * 4, i * 4);
     }
 }
 

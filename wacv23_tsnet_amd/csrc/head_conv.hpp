@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256) void head_conv_kernel(HeadArgs a) {
             iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);       // tiles hanging over the edge: any valid address
             ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
             const int c = c0 + q * 4;
-            float4 v = *reinterpret_cast<const float4*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.C + c);
-            if (a.alpha) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < a.C) v = *reinterpret_cast<const float4*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.C + c);
+            if (a.alpha && c < a.C) {
                 const float4 al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * a.C + c);
                 const float4 be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * a.C + c);
                 v.x = __builtin_fmaf(v.x, al.x, be.x); v.y = __builtin_fmaf(v.y, al.y, be.y);
@@ -92,94 +93,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(HeadArgs a) {
     }
 }
 
-// Second generation (round 2).  PMC of the kernel above (profiles/round1_pmc_summary.txt): 0.28 ms for 35 us of FMAs -- every
-// (tap, channel quad) iteration waits for a 64-byte scalar load AND an LDS read on the one lgkm counter (scalar loads return out of
-// order, so the compiler drains it to zero each time), and the 22-pixel row pitch costs 12.8 M LDS bank conflicts per launch.  Here:
-//   * the slab's weights (49 taps x 16 channels x (3+1) floats = 9.4 KB) are staged in LDS next to the patch and read as wave-uniform
-//     broadcasts -- LDS returns in order, the compiler counts lgkmcnt and keeps several reads in flight;
-//   * every thread owns TWO output pixels 16 columns apart (24 FMAs per 6 LDS reads instead of 12 per 2 + a scalar load);
-//   * the patch row pitch is 48 pixels (768 B = 0 mod 256 B): the two rows a 16-lane read group touches never share a bank.
-// Same fmaf chains per output (tap-major, then channel) as the first kernel: the two produce identical bits.
-constexpr int kHead2W = 32, kHead2H = 16, kHead2Pitch = 48, kHead2Rows = kHead2H + 6;
-
-__global__ __launch_bounds__(256) void head_conv2_kernel(HeadArgs a) {
-    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
-    float4* tile = reinterpret_cast<float4*>(smem_raw);                                   // [channel quad][22 rows][48 pixels]
-    float4* wts = tile + (kHeadCh / 4) * kHead2Rows * kHead2Pitch;                        // [49 taps][16 channels]: (w_r, w_g, w_b, 0)
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int tiles_x = (a.W + kHead2W - 1) / kHead2W;
-    const int n = blockIdx.y;
-    const int bx = (blockIdx.x % tiles_x) * kHead2W, by = (blockIdx.x / tiles_x) * kHead2H;
-    float tot[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    constexpr int PW = kHead2W + 6;                                                       // 38 patch columns in use
-    for (int c0 = 0; c0 < a.C; c0 += kHeadCh) {
-        for (int i = tid; i < (kHeadCh / 4) * kHead2Rows * PW; i += 256) {
-            const int q = i / (kHead2Rows * PW), p = i - q * (kHead2Rows * PW);
-            const int py = p / PW, px = p - py * PW;
-            int iy = by + py - 3, ix = bx + px - 3;
-            iy = iy < 0 ? -iy : iy; iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
-            ix = ix < 0 ? -ix : ix; ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
-            iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);       // tiles hanging over the edge: any valid address
-            ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
-            const int c = c0 + q * 4;
-            float4 v = *reinterpret_cast<const float4*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.C + c);
-            if (a.alpha) {
-                const float4 al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * a.C + c);
-                const float4 be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * a.C + c);
-                v.x = __builtin_fmaf(v.x, al.x, be.x); v.y = __builtin_fmaf(v.y, al.y, be.y);
-                v.z = __builtin_fmaf(v.z, al.z, be.z); v.w = __builtin_fmaf(v.w, al.w, be.w);
-                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-                v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-            }
-            tile[(q * kHead2Rows + py) * kHead2Pitch + px] = v;
-        }
-        for (int i = tid; i < 49 * kHeadCh; i += 256) {
-            const int tap = i / kHeadCh, c = i - tap * kHeadCh;
-            wts[i] = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.C + c0 + c) * 4);
-        }
-        __syncthreads();
-        float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // one fmaf chain per 16-channel slab (784 products), then folded
-        for (int ky = 0; ky < 7; ++ky) {
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const float4* wt = wts + (ky * 7 + kx) * kHeadCh;
-#pragma unroll
-                for (int q = 0; q < kHeadCh / 4; ++q) {
-                    const float4* row = tile + (q * kHead2Rows + ty + ky) * kHead2Pitch + tx + kx;
-                    const float4 v0 = row[0], v1 = row[16];
-                    const float4 wx = wt[q * 4], wy = wt[q * 4 + 1], wz = wt[q * 4 + 2], ww = wt[q * 4 + 3];
-                    const float pv[2][4] = {{v0.x, v0.y, v0.z, v0.w}, {v1.x, v1.y, v1.z, v1.w}};
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        acc[k][0] = __builtin_fmaf(pv[k][0], wx.x, acc[k][0]); acc[k][1] = __builtin_fmaf(pv[k][0], wx.y, acc[k][1]); acc[k][2] = __builtin_fmaf(pv[k][0], wx.z, acc[k][2]);
-                        acc[k][0] = __builtin_fmaf(pv[k][1], wy.x, acc[k][0]); acc[k][1] = __builtin_fmaf(pv[k][1], wy.y, acc[k][1]); acc[k][2] = __builtin_fmaf(pv[k][1], wy.z, acc[k][2]);
-                        acc[k][0] = __builtin_fmaf(pv[k][2], wz.x, acc[k][0]); acc[k][1] = __builtin_fmaf(pv[k][2], wz.y, acc[k][1]); acc[k][2] = __builtin_fmaf(pv[k][2], wz.z, acc[k][2]);
-                        acc[k][0] = __builtin_fmaf(pv[k][3], ww.x, acc[k][0]); acc[k][1] = __builtin_fmaf(pv[k][3], ww.y, acc[k][1]); acc[k][2] = __builtin_fmaf(pv[k][3], ww.z, acc[k][2]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { tot[k][0] += acc[k][0]; tot[k][1] += acc[k][1]; tot[k][2] += acc[k][2]; }
-        __syncthreads();
-    }
-    const size_t hw = (size_t)a.H * a.W;
-    const int oy = by + ty;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int ox = bx + tx + 16 * k;
-        if (ox < a.W && oy < a.H) {
-            float o[3] = {tanhf(tot[k][0] + a.bias[0]), tanhf(tot[k][1] + a.bias[1]), tanhf(tot[k][2] + a.bias[2])};
-            if (a.composite && (ox < a.fore_x0 || ox >= a.fore_x1)) { o[0] = a.bg[0]; o[1] = a.bg[1]; o[2] = a.bg[2]; }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) a.y[((size_t)n * 3 + c) * hw + (size_t)oy * a.W + ox] = o[c];
-        }
-    }
-}
-
-// OIHW (3, C, 7, 7) -> [tap][cin][4]
-// Third form.  head_conv2 is bound by LDS bandwidth, not by the VALU: every (pixel, tap) re-reads its 64 channels from LDS
+// The kernel of the forward (ngf a multiple of 16).  A two-pixel-per-thread form was bound by LDS bandwidth, not by the VALU: every (pixel, tap) re-reads its 64 channels from LDS
 // (262144 px x 4 images x 49 taps x 256 B = 13.2 GB per forward = 168 us at 128 B/clk/CU; measured 177 us).  Here
 //   * every thread owns FOUR horizontally adjacent output pixels: per (tap row, channel quad) it reads 4 + 6 pixel quads once and
 //     slides the seven horizontal taps over them in registers -- 10 LDS reads where 28 were needed -- and the (wave-uniform,

@@ -1,0 +1,24 @@
+// kernels.hpp -- launchers of the convolution kernels.  Each kernel family lives in its own translation unit (conv_h2_launch.cpp,
+// conv_h2r_launch.cpp) so that the library builds in parallel; engine.cpp holds the host logic and the small kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_common.hpp"
+
+namespace tsnet {
+
+// conv_h2.hpp -- patch kernels.  a.tiles_m / tiles_n / tpi are set by the caller; throws std::invalid_argument for a combination that
+// is not instantiated.  nprod: 1 (bf16 operands), 3, or 4 (h2 only); affine = a.in_alpha != null.
+//   h2  (3x3 / stride 1): pr x bn in {4x32, 4x64, 4x128, 2x128}; abl / opt: tools build only (ablation / experiment masks)
+//   h2s (7x7 stem, 8 input channels): 4 x 64
+//   h2d (3x3 / stride 2): bn = 64 (four waves) or 128 (eight waves)
+void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int opt, hipStream_t s);
+void launch_conv_h2s(const ConvArgs& a, int nprod, hipStream_t s);
+void launch_conv_h2d(const ConvArgs& a, int bn, int nprod, hipStream_t s);
+// conv_h2r.hpp -- general implicit GEMM: ks in {1, 3, 7}, bn = 64 (any) or 128 (ks = 3, Cin >= 16); Cin = 8 or a power of two >= 16
+void launch_conv_h2r(const ConvArgs& a, int ks, int bn, int nprod, hipStream_t s);
+
+// dynamic LDS above the default limit needs hipFuncAttributeMaxDynamicSharedMemorySize: set once per (kernel, device), not per launch
+void ensure_dynamic_lds(const void* kernel, size_t bytes);
+
+}  // namespace tsnet

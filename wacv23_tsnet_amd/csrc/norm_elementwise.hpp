@@ -13,13 +13,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "split3.hpp"
+#include "conv_common.hpp"
 
 namespace tsnet {
-
-#ifndef TSNET_F4_DEFINED
-#define TSNET_F4_DEFINED
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // InstanceNorm statistics, stage 1: per (image n, split s) partial sum / sum of squares per channel,
@@ -187,10 +183,9 @@ struct NormActArgs {
     const float* alpha;
     const float* beta;
     const float* resid;
-    float* y;              // fp32 output or null
+    float* y;
     int HW, C, relu;
     size_t total4;   // N*HW*C/4
-    unsigned short* y3;    // null, or bf16x3 planes of the output (conv_x3 operand format)
 };
 
 // grid = (chunks, N): the image comes from blockIdx.y and the channel quad is advanced incrementally -- no per-element
@@ -233,8 +228,7 @@ __global__ __launch_bounds__(256) void norm_act_kernel(NormActArgs a) {
             const float4 r = reinterpret_cast<const float4*>(a.resid)[i];
             v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
         }
-        if (a.y) reinterpret_cast<float4*>(a.y)[i] = v;
-        if (a.y3) split3_store_at(v, a.y3, a.total4 * 4, i * 4);
+        reinterpret_cast<float4*>(a.y)[i] = v;
     }
 }
 
@@ -248,9 +242,8 @@ struct FuseTailArgs {
     const float* y2;        // (K*B, P, 2*C1)
     const float* alpha;     // (K*B * 2*C1)
     const float* beta;
-    float* zbar;            // (B, P, 2*C1) fp32 or null
+    float* zbar;            // (B, P, 2*C1)
     int B, K, P, C1;
-    unsigned short* zbar3;  // null, or bf16x3 planes of zbar
 };
 
 __global__ __launch_bounds__(256) void fuse_resid_mean_kernel(FuseTailArgs a) {
@@ -278,8 +271,7 @@ __global__ __launch_bounds__(256) void fuse_resid_mean_kernel(FuseTailArgs a) {
         }
         const float kf = (float)a.K;
         acc.x /= kf; acc.y /= kf; acc.z /= kf; acc.w /= kf;
-        if (a.zbar) *reinterpret_cast<float4*>(a.zbar + ((size_t)b * a.P + p) * C + c) = acc;
-        if (a.zbar3) split3_store_at(acc, a.zbar3, total * 4, i * 4);
+        *reinterpret_cast<float4*>(a.zbar + ((size_t)b * a.P + p) * C + c) = acc;
     }
 }
 
@@ -291,9 +283,8 @@ struct UpsampleArgs {
     const float* x;       // (N,H,W,C)
     const float* alpha;   // (N*C) or null
     const float* beta;
-    float* y;             // (N,2H,2W,C) fp32 or null
+    float* y;             // (N,2H,2W,C)
     int N, H, W, C, relu;
-    unsigned short* y3;   // null, or bf16x3 planes of the output
 };
 
 __device__ __forceinline__ float4 na4(float4 v, const float4& al, const float4& be, bool norm, bool relu) {
@@ -312,7 +303,6 @@ __device__ __forceinline__ float4 na4(float4 v, const float4& al, const float4& 
 __global__ __launch_bounds__(256) void upsample2x_kernel(UpsampleArgs a) {
     const unsigned c4n = (unsigned)a.C >> 2;
     const int Ho = 2 * a.H, Wo = 2 * a.W;
-    const size_t total = (size_t)a.N * Ho * Wo * c4n;
     const int oy = blockIdx.y, n = blockIdx.z;
     const unsigned row4 = (unsigned)Wo * c4n;
     for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < row4; j += gridDim.x * 256u) {
@@ -340,8 +330,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(UpsampleArgs a) {
         o.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
         o.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
         o.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
-        if (a.y) reinterpret_cast<float4*>(a.y)[i] = o;
-        if (a.y3) split3_store_at(o, a.y3, total * 4, i * 4);
+        reinterpret_cast<float4*>(a.y)[i] = o;
     }
 }
 
@@ -352,9 +341,8 @@ struct PackArgs {
     const float* img[8];   // per source: (B,3,H,W) or null (label encoder input)
     const float* lbl[8];   // per source: (B,L,H,W)
     const float* coords;   // (H,W,3) table or null
-    float* out;            // (S*B, H, W, Cp) fp32 or null
+    float* out;            // (S*B, H, W, Cp)
     int S, B, H, W, L, nimg, Cp;
-    unsigned short* out3;  // null, or bf16x3 planes of the packed input
     float img_div[8];      // per source: 255 (set_test_input's /255, TSNet.py:286) or 1 (use_prev: a frame already in [0,1], TSNet.py:269-276)
     unsigned* amax_out;    // null, or amax_out[image] <- max |packed value| of that image (float bits; operand scale of the fp16 x 2 stem)
 };
@@ -362,7 +350,6 @@ struct PackArgs {
 // grid = (blocks per image, S * B images)
 __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
     const size_t HW = (size_t)a.H * a.W;
-    const size_t total = (size_t)a.S * a.B * HW;
     const int creal = a.nimg + a.L + (a.coords ? 3 : 0);
     const int n = blockIdx.y;
     const int s = n / a.B, b = n - s * a.B;
@@ -383,8 +370,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
                 vmax = __builtin_fmaxf(vmax, __builtin_fabsf(t));
             }
             const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
-            if (a.out) *reinterpret_cast<float4*>(o + c0) = v4;
-            if (a.out3) split3_store_at(v4, a.out3, total * a.Cp, i * a.Cp + c0);
+            *reinterpret_cast<float4*>(o + c0) = v4;
         }
     }
     if (a.amax_out) tsnet_publish_amax(a.amax_out + n, vmax);      // per image; block-uniform branch: every thread of the workgroup arrives
