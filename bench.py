@@ -33,10 +33,9 @@ B_PER_GPU = 4
 H = W = 256
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA (v_mfma_f32_32x32x16_{f16,bf16})
-# conv_h2.hpp evaluates every fp32 product as 3 fp16 MFMA products (2-way operand split of the scaled fp32 value), conv_x3*.hpp as
-# 6 bf16 products (3-way split): the ceiling of each method in algorithmic (fp32) FLOPs is the MFMA peak / products.
+# every convolution evaluates an fp32 product as 3 fp16 MFMA products (2-way operand split of the scaled fp32 value, conv_common.hpp):
+# the method's ceiling in algorithmic (fp32) FLOPs is the MFMA peak / 3.
 PEAK_H2_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
-PEAK_X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 6.0
 
 
 def _usable_cores() -> int:
@@ -53,13 +52,20 @@ def _usable_cores() -> int:
 
 
 def _pmc_traffic_bytes(kernel_prefix: str):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this round's build
-    (profiles/round2_pmc_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_table.py).  bench.py cannot run
-    rocprofv3 on itself; None when the table is absent."""
-    path = os.path.join(ROOT, "profiles", "round2_pmc_summary.txt")
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/round3_pmc_summary.txt: FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, tools/pmc_table.py).  bench.py cannot run rocprofv3 on itself.  The table records a digest of the kernel
+    sources it was measured on (tools/src_digest.py): when the tree this process runs from differs, the number belongs to another build and
+    is NOT quoted (None, with the reason)."""
+    path = os.path.join(ROOT, "profiles", "round3_pmc_summary.txt")
     try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from src_digest import digest
+        lines = open(path).read().splitlines()
+        rec = [l.split(":", 1)[1].strip() for l in lines if l.startswith("# source_digest:")]
+        if not rec or rec[0] != digest():
+            return None, "%s was measured on another build of the kernels (digest %s, this tree %s)" % (os.path.relpath(path, ROOT), rec[0] if rec else "none", digest())
         tot, n = 0.0, 0          # launch-weighted mean over the template variants of the kernel (raw input / fused InstanceNorm + ReLU)
-        for line in open(path):
+        for line in lines:
             if line.startswith(kernel_prefix):
                 f = line.split()
                 tot += (float(f[-2]) + float(f[-1])) * int(f[-4])
@@ -68,9 +74,9 @@ def _pmc_traffic_bytes(kernel_prefix: str):
                 break                # the byte table ends at the first blank line
         if n:
             return int(tot / n * 2**20), os.path.relpath(path, ROOT)
-    except Exception:
-        pass
-    return None, None
+    except Exception as e:           # no table committed yet
+        return None, "no PMC table (%s)" % type(e).__name__
+    return None, "kernel not in the PMC table"
 
 
 def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None, batch: int = B_PER_GPU, height: int = H,
@@ -149,44 +155,30 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
         res_ms, res_launches = tm.get("conv_res", (0.0, 0))
         conv_ms, conv_launches = tm["conv"][0] + res_ms, tm["conv"][1] + res_launches
         conv_tf = conv_flops * nprobe / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        x3 = os.environ.get("TSNET_X3", "1") != "0"
-        h2 = x3 and os.environ.get("TSNET_H2", "1") != "0"
         class_ms = {k: round(v[0] / nprobe, 3) for k, v in tm.items() if v[1]}
-        if x3 and res_launches and cuda:
+        if res_launches:
             # dominant kernel: the 3x3 convolution of the encoder's residual blocks (2 per block): M = K*B*h*w output positions,
-            # Cin = Cout = C, 9 taps -- SURVEY.md section 8-d: 2*M*C*9C flop per launch
+            # Cin = Cout = C, 9 taps -- SURVEY.md section 8-d: 2*M*C*9C flop per launch.  Its tile shape is read back from the engine.
+            import ctypes
+            cnt = (ctypes.c_int64 * 4)()
+            eng.lib.tsnet_debug_counters(cnt, 0)
+            pr, bn = int(cnt[3]) // 1000, int(cnt[3]) % 1000
             flop_per_launch = 2.0 * (K * batch * P) * C * (9 * C)
             avg_ms = res_ms / res_launches
             achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
-            peak = PEAK_H2_TFLOPS if h2 else PEAK_X3_TFLOPS
-            kname = "conv_h2_kernel<64,2,2,3" if h2 else "conv_x3q<64,2,2"
-            traffic, traffic_src = _pmc_traffic_bytes("conv_h2<64,2,2,3" if h2 else "conv_x3q<64,2,2")
+            traffic, traffic_src = _pmc_traffic_bytes("conv_h2<%d,%d," % (pr, bn)) if cuda else (None, "not a GPU run")
             roofline = {"bound": "mfma",
-                        "kernel": "%s,...> (3x3 ResnetBlock convolution, %d launches per forward = %.0f %% of the forward)"
-                                  % (kname, res_launches // nprobe, 100.0 * res_ms / nprobe / (dt * 1e3 / steps)),
-                        "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "kernel": "conv_h2_kernel<%d rows, %d channels, ...> (3x3 ResnetBlock convolution, %d launches per forward = %.0f %% of the forward)"
+                                  % (pr, bn, res_launches // nprobe, 100.0 * res_ms / nprobe / (dt * 1e3 / steps)),
+                        "achieved": round(achieved, 2), "peak": round(PEAK_H2_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(achieved / PEAK_H2_TFLOPS, 4),
                         "traffic": traffic, "traffic_source": traffic_src,
-                        "peak_basis": ("2500 TF dense fp16 MFMA / 3 fp16 products per fp32 product (2-way split of the scaled operand, conv_h2.hpp)" if h2
-                                       else "2500 TF dense bf16 MFMA / 6 bf16 products per fp32 product (3-way operand split)"),
-                        "mfma_flops_issued_tflops": round(achieved * (3 if h2 else 6), 1),
-                        "frac_of_bf16x3_method_ceiling": round(achieved / PEAK_X3_TFLOPS, 4),
+                        "peak_basis": "2500 TF dense fp16 MFMA / 3 fp16 products per fp32 product (2-way split of the scaled operand, conv_common.hpp)",
+                        "mfma_flops_issued_tflops": round(achieved * 3, 1),
                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                         "algorithmic_gflop_per_launch": round(flop_per_launch / 1e9, 2),
                         "avg_launch_ms": round(avg_ms, 4), "launches_per_forward": res_launches // nprobe,
                         "all_conv_launches": {"achieved": round(conv_tf, 2), "launches_per_forward": conv_launches // nprobe,
                                               "algorithmic_gflop": round(conv_flops / 1e9, 2)},
-                        "class_ms_per_forward": class_ms}
-        else:
-            peak = PEAK_X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
-            roofline = {"bound": "mfma",
-                        "kernel": ("conv_x3_kernel" if x3 else "conv_dma_kernel") + " (all conv launches of one forward)",
-                        "achieved": round(conv_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(conv_tf / peak, 4), "traffic": None,
-                        "peak_basis": ("2500 TF dense bf16 MFMA / 6 bf16 products per fp32 product (3-way split)" if x3
-                                       else "157.3 TF exact-fp32 MFMA"),
-                        "frac_of_fp32_mfma_peak": round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "algorithmic_gflop_per_launch_set": round(conv_flops / 1e9, 2),
-                        "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4), "launches_per_forward": conv_launches // nprobe,
                         "class_ms_per_forward": class_ms}
 
     # ---- CPU baseline beside it (rank 0, N=1 only): the oracle on the host cores, same workload
@@ -239,10 +231,7 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
 
     frames = world * batch * steps
     gflop_frame = 2.0 * eng.forward_macs(1) / 1e9
-    x3on = os.environ.get("TSNET_X3", "1") != "0"
-    h2on = x3on and os.environ.get("TSNET_H2", "1") != "0"
-    dtype = ("f32 (3x3 convs: fp16 x 2 split of the scaled operands, 3 MFMA products, fp32 accumulate; other convs: bf16 x 3 split, 6 products; fp32-class accuracy)" if h2on
-             else "f32 (convs: 3 x bf16 operand split on the bf16 MFMA, fp32 accumulate; fp32-class accuracy)" if x3on else "f32")
+    dtype = "f32 (convolutions: fp16 x 2 split of the scaled fp32 operands, 3 exact MFMA products, two-level fp32 accumulate; fp32-class accuracy)"
     line = {
         "metric": "retargeted frames/sec at bs=4, 256x256, n_source=3; max-abs delta vs ref",
         "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,

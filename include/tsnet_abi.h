@@ -201,18 +201,27 @@ int tsnet_demo_postprocess(const float* rec, int B, int H, int W, const float* g
                            unsigned char* out_rgb, void* stream);
 
 /* Input rasterisation, one call per clip.
- * tsnet_raster_face <- FaceDatasetTest.get_face_image + get_bbox_image (dataset/dataset_video_face.py:466-495; utils/keypoint2img.py
- *                      interp_points :319-354, draw_edge :298-316).  keypoints: (F,68,2) device doubles, (x, y) already relative to
- *                      the crop (read_keypoints, :497-505); edges / bbox: (F,h,w) device bytes, 0 / 255, either may be NULL.
+ * tsnet_fit_face_curves <- utils/keypoint2img.py interp_points (:319-354) up to the fitted curve, HOST code: for each of the 34 pieces of
+ *                      FaceDatasetTest.part_list (dataset/dataset_video_face.py:271-280, 473-477) the axis choice and scipy.optimize.curve_fit's
+ *                      Levenberg-Marquardt fit (MINPACK lmdif from p0 = ones), reproduced bit for bit (csrc/lmfit.hpp).  keypoints: (F,68,2)
+ *                      HOST doubles, (x, y) already relative to the crop (read_keypoints, :497-505); curves: (F,34,8) HOST doubles
+ *                      {kind, a, b, c, u_first, u_last, 0, 0}, kind 0 = nothing drawn (|a| > 1), bit 1 = curve is x(y), bit 2 = quadratic.
+ * tsnet_raster_face <- FaceDatasetTest.get_face_image + get_bbox_image (:466-495; interp_points' sampling + draw_edge, keypoint2img.py:298-316,
+ *                      335-354).  keypoints (F,68,2) and curves (F,34,8): DEVICE doubles; edges / bbox: (F,h,w) device bytes, 0 / 255,
+ *                      either may be NULL (edges needs curves, bbox needs keypoints).
  * tsnet_vl2ch       <- utils/misc.py vl2ch (:50-67): labels (B,HW) class indices as floats -> out (B,num_classes,HW) one-hot floats. */
-int tsnet_raster_face(const double* keypoints, int F, int h, int w, int bw, unsigned char* edges, unsigned char* bbox, void* stream);
+int tsnet_fit_face_curves(const double* keypoints, int F, double* curves);
+int tsnet_raster_face(const double* keypoints, const double* curves, int F, int h, int w, int bw, unsigned char* edges, unsigned char* bbox, void* stream);
 int tsnet_vl2ch(const float* labels, int B, int HW, int num_classes, float* out, void* stream);
 
 /* Pose clips (dataset/dataset_video_pose.py PoseDatasetTestVideo.get_image / get_smooth_lbl :489-536, test mode).
- * tsnet_raster_pose <- utils/keypoint2img_posenorm.py connect_keypoints (:265-311; draw_edge :469-487, interp_points :490-516) followed by
+ * tsnet_fit_pose_curves <- interp_points (utils/keypoint2img_posenorm.py:490-516) of every stroke of connect_keypoints (:265-311), HOST code as
+ *                      tsnet_fit_face_curves: pts (F,137,2) HOST doubles, flags as below; curves (F,118,8) HOST doubles (24 limb strokes, 40 finger
+ *                      segments, 54 face pieces; kind 0 = dropped by the flags or a missing point).
+ * tsnet_raster_pose <- utils/keypoint2img_posenorm.py connect_keypoints (:265-311; draw_edge :469-487, interp_points' sampling) followed by
  *                      crop_person_region (:538-552) and utils/misc.py im2vl (:27-47).  pts: (F,137,2) device doubles in frame coordinates =
  *                      the four arrays connect_keypoints takes, concatenated (pose 25 | face 70 | left hand 21 | right hand 21), invalid points
- *                      zero (extract_valid_keypoints, :242-262).  The skeleton is drawn on the h x w frame; labels (F, win_y1-win_y0,
+ *                      zero (extract_valid_keypoints, :242-262); curves (F,118,8) device doubles from tsnet_fit_pose_curves.  The skeleton is drawn on the h x w frame; labels (F, win_y1-win_y0,
  *                      win_x1-win_x0) receives the CLASS INDEX (0..24) of every pixel of the window [win_x0,win_x1) x [win_y0,win_y1) -- what
  *                      im2vl makes of the cropped colour image.  labels must be 4-byte aligned and its allocation a multiple of 4 bytes.
  *                      flags: 1 = basic_point_only, 2 = remove_face_labels.  Stroke widths are the test-mode ones (isTrain = False).
@@ -220,7 +229,8 @@ int tsnet_vl2ch(const float* labels, int B, int HW, int num_classes, float* out,
  * tsnet_resize_pad  <- Image.resize(size, NEAREST) + resize_square (:425-432, :471-477): out[f, pad_top+y, pad_left+x] = in[f, ytab[y], xtab[x]],
  *                      zero elsewhere; out (F,OH,OW) floats (binarise: != 0 -> 1, the `bbox != 0` of :441, :448).  ytab / xtab: device ints, the
  *                      source row / column of every output row / column (wacv23_tsnet_amd/raster.py computes them in PIL's order). */
-int tsnet_raster_pose(const double* pts, int F, int h, int w, int win_x0, int win_y0, int win_x1, int win_y1, int flags,
+int tsnet_fit_pose_curves(const double* pts, int F, int flags, double* curves);
+int tsnet_raster_pose(const double* pts, const double* curves, int F, int h, int w, int win_x0, int win_y0, int win_x1, int win_y1, int flags,
                       unsigned char* labels, void* stream);
 int tsnet_label_bbox(const unsigned char* labels, int F, int h, int w, unsigned char* bbox, void* stream);
 int tsnet_resize_pad(const unsigned char* in, int F, int h, int w, const int* ytab, const int* xtab, int oh, int ow,
@@ -233,7 +243,8 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
                      int variant, int iters, float* ms_out, void* stream);
 
 /* Launch counters since the last reset: out[0] = patch convolution kernels (conv_h2.hpp), out[1] = general convolution kernel
- * (conv_h2r.hpp), out[2] = RGB head, out[3] unused.  Diagnostic. */
+ * (conv_h2r.hpp), out[2] = RGB head; out[3] = tile code (rows * 1000 + width) of the last ResnetBlock-class patch convolution launched
+ * (bench.py labels the roofline kernel with it).  Diagnostic. */
 void tsnet_debug_counters(int64_t out[4], int reset);
 
 /* Host-side constant tables, exported so CPU tests can pin them against torch:

@@ -2,8 +2,12 @@
 usage: pmc_table.py <prof_dir>   (expects <prof_dir>/{fetch,write,sq}/**/*.db)
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch; on gfx950 FETCH_SIZE under-reports wide coalesced reads by
 2x (MI355X_MICROARCH.md, HBM section): fetch_MB_corrected = 2 x raw.  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES /
-(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); the wait/active columns are fractions of SQ_WAVE_CYCLES."""
+(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); the wait/active columns are fractions of SQ_WAVE_CYCLES.
+clock_GHz = (GRBM_GUI_ACTIVE / 8 XCDs) / the kernel's average duration in the kernel-trace pass of the same command (<prof_dir>/trace):
+the effective shader clock while the kernel runs (DVFS: MI355X_MICROARCH.md, "DVFS give-back")."""
 import collections, glob, os, re, sqlite3, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from src_digest import digest
 
 def load(dbdir):
     dbs = glob.glob(os.path.join(dbdir, "**", "*.db"), recursive=True)
@@ -18,12 +22,26 @@ def load(dbdir):
     return agg
 
 def short(n):
-    m = re.search(r"(conv_h2|conv_x3q|conv_x3r|conv_x3p_mixed|conv_x3p|conv_x3|conv_dma)_kernel(?:<([^>]*)>)?", n)
+    m = re.search(r"(conv_h2[a-z]?)_kernel(?:<([^>]*)>)?", n)
     if m: return m.group(1) + ("<" + m.group(2).replace(" ", "").replace("false", "f").replace("true", "t") + ">" if m.group(2) else "")
     return re.sub(r"\(.*", "", n).split("::")[-1][:34]
 
+def durations(dbdir):
+    """kernel -> average duration in ns from the kernel-trace pass"""
+    dbs = glob.glob(os.path.join(dbdir, "**", "*.db"), recursive=True)
+    if not dbs: return {}
+    agg = collections.defaultdict(list)
+    try:
+        for name, dur in sqlite3.connect(dbs[0]).cursor().execute("select name, duration from kernels"):
+            agg[short(name)].append(dur)
+    except sqlite3.Error:
+        return {}
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
 d = sys.argv[1]
 fetch, write, sq = load(os.path.join(d, "fetch")), load(os.path.join(d, "write")), load(os.path.join(d, "sq"))
+dur = durations(os.path.join(d, "trace"))
+print("# source_digest: %s" % digest())
 avg = lambda v: sum(v) / len(v) if v else 0.0
 order = sorted(fetch, key=lambda k: -sum(fetch[k].get("FETCH_SIZE", [0])))
 print("# per launch; bytes from separate --pmc FETCH_SIZE / WRITE_SIZE passes")
@@ -33,9 +51,11 @@ for k in order:
     w = avg(write.get(k, {}).get("WRITE_SIZE", [])) / 1024.0
     print("%-36s %8d %14.2f %20.2f %12.2f" % (k, len(fetch[k].get("FETCH_SIZE", [])), f, 2 * f, w))
 print()
-print("%-36s %8s %10s %10s %10s %10s %12s" % ("kernel", "launches", "mfma_util", "wait_any", "wait_inst", "active", "lds_conflict"))
+print("%-36s %8s %10s %10s %10s %10s %12s %10s %10s" % ("kernel", "launches", "mfma_util", "wait_any", "wait_inst", "active", "lds_conflict", "trace_us", "clock_GHz"))
 for k in sorted(sq, key=lambda k: -sum(sq[k].get("GRBM_GUI_ACTIVE", [0]))):
     c = sq[k]; g = avg(c.get("GRBM_GUI_ACTIVE", [])); wc = avg(c.get("SQ_WAVE_CYCLES", [])) or 1.0
     if g <= 0: continue
-    print("%-36s %8d %10.3f %10.3f %10.3f %10.3f %12.0f" % (k, len(c.get("GRBM_GUI_ACTIVE", [])), avg(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [])) / (1024.0 * g / 8.0),
-          avg(c.get("SQ_WAIT_ANY", [])) / wc, avg(c.get("SQ_WAIT_INST_ANY", [])) / wc, avg(c.get("SQ_ACTIVE_INST_ANY", [])) / wc, avg(c.get("SQ_LDS_BANK_CONFLICT", []))))
+    t = dur.get(k, 0.0)
+    print("%-36s %8d %10.3f %10.3f %10.3f %10.3f %12.0f %10.1f %10.2f" % (k, len(c.get("GRBM_GUI_ACTIVE", [])), avg(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [])) / (1024.0 * g / 8.0),
+          avg(c.get("SQ_WAIT_ANY", [])) / wc, avg(c.get("SQ_WAIT_INST_ANY", [])) / wc, avg(c.get("SQ_ACTIVE_INST_ANY", [])) / wc, avg(c.get("SQ_LDS_BANK_CONFLICT", [])),
+          t / 1e3, (g / 8.0) / t if t > 0 else 0.0))

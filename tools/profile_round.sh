@@ -14,5 +14,4 @@ python $R/tools/prof_summary.py $(find $O/trace -name '*.db' | head -1) > $O/ker
 for p in fetch write sq sq2; do echo "== pass $p"; python $R/tools/pmc_summary.py $(find $O/$p -name '*.db' | head -1) | grep -v columns; done > $O/pmc_summary.txt 2>&1
 cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv 2>/dev/null
 python $R/tools/pmc_table.py $O > $O/pmc_table.txt 2>&1
-python $R/bench.py > $O/bench.json 2> $O/bench.err
-tail -1 $O/bench.json | cut -c1-400
+if [ "$2" != "nobench" ]; then python $R/bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-400; fi

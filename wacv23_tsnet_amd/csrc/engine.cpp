@@ -31,6 +31,7 @@
 
 #include "../../include/tsnet_abi.h"
 #include "kernels.hpp"
+#include "lmfit.hpp"
 #include "flow_warp.hpp"
 #include "head_conv.hpp"
 #include "norm_elementwise.hpp"
@@ -44,7 +45,8 @@ using namespace tsnet;
 namespace {
 
 thread_local std::string g_op_error;
-int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] patch kernels (conv_h2.hpp), [1] general kernel (conv_h2r.hpp), [2] RGB head, [3] unused
+int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] patch kernels (conv_h2.hpp), [1] general kernel (conv_h2r.hpp), [2] RGB head;
+                                               // [3] = tile code (rows * 1000 + width) of the last ResnetBlock-class convolution launch
 std::string g_create_error;
 
 #define HIP_TRY(expr)                                                                               \
@@ -266,6 +268,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
             set_tiles(pr * kPatchCols, bn);
             launch_conv_h2(g, pr, bn, c.nprod, c.abl, c.opt, ctx.stream);
             ++g_launch_counters[0];
+            if (c.tclass == TSNET_T_CONV_RES) g_launch_counters[3] = pr * 1000 + bn;
         } else if (cls == K_H2S) {
             set_tiles(128, 64);
             launch_conv_h2s(g, c.nprod, ctx.stream);
@@ -1386,14 +1389,48 @@ int tsnet_demo_postprocess(const float* rec, int B, int H, int W, const float* g
     OP_END
 }
 
-int tsnet_raster_face(const double* keypoints, int F, int h, int w, int bw, unsigned char* edges, unsigned char* bbox, void* stream) {
+int tsnet_fit_face_curves(const double* keypoints, int F, double* curves) {
     OP_BEGIN
-    if (!keypoints || (!edges && !bbox)) throw ArgError("raster_face: null tensor");
+    if (!keypoints || !curves || F < 1) throw ArgError("fit_face_curves: bad argument");
+    for (int f = 0; f < F; ++f)
+        for (int e = 0; e < kFaceSubEdges; ++e) {
+            double pts[6];
+            const int n = hFaceSubEdgeTable[e][2] < 0 ? 2 : 3;
+            for (int i = 0; i < n; ++i) {
+                const double* k = keypoints + ((size_t)f * kFaceKeypoints + hFaceSubEdgeTable[e][i]) * 2;
+                pts[2 * i] = k[0]; pts[2 * i + 1] = k[1];
+            }
+            lm::fit_piece(pts, n, curves + ((size_t)f * kFaceSubEdges + e) * kCurveRec);
+        }
+    OP_END
+}
+
+int tsnet_fit_pose_curves(const double* pts, int F, int flags, double* curves) {
+    OP_BEGIN
+    if (!pts || !curves || F < 1) throw ArgError("fit_pose_curves: bad argument");
+    for (int f = 0; f < F; ++f) {
+        const double* P = pts + (size_t)f * kPosePts * 2;
+        for (int e = 0; e < kPosePrims; ++e) {
+            double* rec = curves + ((size_t)f * kPosePrims + e) * kCurveRec;
+            for (int i = 0; i < kCurveRec; ++i) rec[i] = 0.0;
+            int ia = 0, ib = 0;
+            if (!pose_primitive_points(e, flags, ia, ib)) continue;
+            const double two[4] = {P[2 * ia], P[2 * ia + 1], P[2 * ib], P[2 * ib + 1]};
+            if (two[0] == 0.0 || two[2] == 0.0) continue;               // `0 not in x` (connect_keypoints): a missing point
+            lm::fit_piece(two, 2, rec);
+        }
+    }
+    OP_END
+}
+
+int tsnet_raster_face(const double* keypoints, const double* curves, int F, int h, int w, int bw, unsigned char* edges, unsigned char* bbox, void* stream) {
+    OP_BEGIN
+    if ((!edges && !bbox) || (edges && !curves) || (bbox && !keypoints)) throw ArgError("raster_face: null tensor");
     if (F < 1 || F > 65535 || h < 1 || w < 1 || bw < 1 || (double)h * w >= 2147483647.0) throw ArgError("raster_face: bad shape");
     hipStream_t s = (hipStream_t)stream;
     if (edges) {
         HIP_TRY(hipMemsetAsync(edges, 0, (size_t)F * h * w, s));
-        hipLaunchKernelGGL(face_edges_kernel, dim3(kFaceSubEdges, F), dim3(64), 0, s, keypoints, edges, h, w, bw);
+        hipLaunchKernelGGL(face_edges_kernel, dim3(kFaceSubEdges, F), dim3(64), 0, s, curves, edges, h, w, bw);
         check_launch("face_edges");
     }
     if (bbox) {
@@ -1403,17 +1440,17 @@ int tsnet_raster_face(const double* keypoints, int F, int h, int w, int bw, unsi
     OP_END
 }
 
-int tsnet_raster_pose(const double* pts, int F, int h, int w, int win_x0, int win_y0, int win_x1, int win_y1, int flags,
+int tsnet_raster_pose(const double* pts, const double* curves, int F, int h, int w, int win_x0, int win_y0, int win_x1, int win_y1, int flags,
                       unsigned char* labels, void* stream) {
     OP_BEGIN
-    if (!pts || !labels) throw ArgError("raster_pose: null tensor");
+    if (!pts || !curves || !labels) throw ArgError("raster_pose: null tensor");
     if (F < 1 || F > 65535 || h < 1 || w < 1 || (double)h * w >= 2147483647.0) throw ArgError("raster_pose: bad shape");
     if (win_x0 < 0 || win_y0 < 0 || win_x1 > w || win_y1 > h || win_x1 <= win_x0 || win_y1 <= win_y0) throw ArgError("raster_pose: window outside the frame");
     if (((uintptr_t)labels & 3) != 0) throw ArgError("raster_pose: labels must be 4-byte aligned (and padded to a multiple of 4 bytes)");
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)F * (win_y1 - win_y0) * (win_x1 - win_x0), n4 = (n + 3) / 4 * 4;
     HIP_TRY(hipMemsetAsync(labels, 0, n4, s));
-    hipLaunchKernelGGL(pose_edges_kernel, dim3(kPosePrims, F), dim3(64), 0, s, pts, labels, h, w, win_x0, win_y0, win_x1, win_y1, flags);
+    hipLaunchKernelGGL(pose_edges_kernel, dim3(kPosePrims, F), dim3(64), 0, s, pts, curves, labels, h, w, win_x0, win_y0, win_x1, win_y1, flags);
     check_launch("pose_edges");
     hipLaunchKernelGGL(pose_order_to_class_kernel, dim3(ew_grid(n)), dim3(256), 0, s, labels, n);
     check_launch("pose_order_to_class");
@@ -1496,7 +1533,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
 }
 
 void tsnet_debug_counters(int64_t out[4], int reset) {
-    for (int i = 0; i < 4; ++i) { if (out) out[i] = g_launch_counters[i]; if (reset) g_launch_counters[i] = 0; }
+    for (int i = 0; i < 4; ++i) { if (out) out[i] = g_launch_counters[i]; if (reset && i < 3) g_launch_counters[i] = 0; }
 }
 
 void tsnet_linspace(int n, float* out) { linspace_pm1(n, out); }

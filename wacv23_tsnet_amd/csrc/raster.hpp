@@ -4,12 +4,11 @@
 //     draw_edge (:298-316)                                               -> face_edges_kernel
 //   * FaceDatasetTest.get_bbox_image (:483-495)                          -> face_bbox_kernel
 //   * utils/misc.py vl2ch (:50-67)                                       -> onehot_kernel
-// interp_points fits every 3-point piece of a face-part polyline with scipy.optimize.curve_fit (Levenberg-Marquardt) -- for three
-// points and three parameters that is the interpolating parabola up to the optimiser's termination error (~1e-9 relative) -- samples it
-// at np.linspace(x0, xn, ceil(xn - x0)) and TRUNCATES to integer pixels.  Here the parabola is the closed form (divided differences,
-// fp64), evaluated in the reference's operation order a*x^2 + b*x + c.  The two differ only where a sample lands within the optimiser's
-// error of an integer (the end points of a piece, whose true ordinates are the integer key points): tests/test_raster.py reports the
-// Hamming distance to the reference's maps on every frame of the demo clips.  Bounding box and one-hot are integer work: bit-exact.
+// interp_points fits every 2- / 3-point piece of a polyline with scipy.optimize.curve_fit (Levenberg-Marquardt), samples the curve at
+// np.linspace(x0, xn, ceil(xn - x0)) and TRUNCATES to integer pixels.  The fit runs on the HOST (lmfit.hpp: MINPACK's lmdif reproduced to
+// the last bit -- 34 fits of microseconds per face frame, 118 per pose frame) and hands the device one record per piece
+// {kind, a, b, c, u_first, u_last}; the kernels sample a*x^2 + b*x + c in the reference's operation order and draw.  Edge maps, bounding
+// boxes and one-hot labels are then EQUAL to the reference's on every frame of its demo clips (tests/test_raster.py, test_raster_pose.py).
 //
 // Pose clips (OpenPose key points -> colour-coded skeleton -> class-index label; dataset/dataset_video_pose.py:489-615):
 //   * utils/keypoint2img_posenorm.py connect_keypoints (:265-311) + draw_edge (:469-487) + interp_points (:490-516, two-point pieces only:
@@ -23,46 +22,31 @@ namespace tsnet {
 
 constexpr int kFaceKeypoints = 68;
 constexpr int kFaceSubEdges = 34;
-// FaceDatasetTest.part_list (:271-280) cut into pieces of three points sharing their end points (:473-477); -1 = two-point piece
-__device__ const signed char kFaceSubEdgeTable[kFaceSubEdges][3] = {
-    {0, 1, 2}, {2, 3, 4}, {4, 5, 6}, {6, 7, 8}, {8, 9, 10}, {10, 11, 12}, {12, 13, 14}, {14, 15, 16},          // face contour
-    {17, 18, 19}, {19, 20, 21}, {22, 23, 24}, {24, 25, 26},                                                  // eyebrows
-    {28, 31, -1}, {31, 32, 33}, {33, 34, 35}, {35, 28, -1},                                                  // nose
-    {36, 37, 38}, {38, 39, -1}, {39, 40, 41}, {41, 36, -1}, {42, 43, 44}, {44, 45, -1}, {45, 46, 47}, {47, 42, -1},   // eyes
-    {48, 49, 50}, {50, 51, 52}, {52, 53, 54}, {54, 55, 56}, {56, 57, 58}, {58, 59, 48},                      // outer mouth
-    {60, 61, 62}, {62, 63, 64}, {64, 65, 66}, {66, 67, 60}};                                                 // inner mouth
+constexpr int kCurveRec = 8;             // doubles per fitted piece: {kind, a, b, c, u_first, u_last, 0, 0} (lmfit.hpp fit_piece)
+// FaceDatasetTest.part_list (:271-280) cut into pieces of three points sharing their end points (:473-477); -1 = two-point piece.
+// (The host fits the pieces, the device draws them: one table, two storage classes.)
+#define TSNET_FACE_SUB_EDGES                                                                                       \
+    {0, 1, 2}, {2, 3, 4}, {4, 5, 6}, {6, 7, 8}, {8, 9, 10}, {10, 11, 12}, {12, 13, 14}, {14, 15, 16},                /* face contour */ \
+    {17, 18, 19}, {19, 20, 21}, {22, 23, 24}, {24, 25, 26},                                                        /* eyebrows */ \
+    {28, 31, -1}, {31, 32, 33}, {33, 34, 35}, {35, 28, -1},                                                        /* nose */ \
+    {36, 37, 38}, {38, 39, -1}, {39, 40, 41}, {41, 36, -1}, {42, 43, 44}, {44, 45, -1}, {45, 46, 47}, {47, 42, -1}, /* eyes */ \
+    {48, 49, 50}, {50, 51, 52}, {52, 53, 54}, {54, 55, 56}, {56, 57, 58}, {58, 59, 48},                            /* outer mouth */ \
+    {60, 61, 62}, {62, 63, 64}, {64, 65, 66}, {66, 67, 60}                                                         /* inner mouth */
+static const signed char hFaceSubEdgeTable[kFaceSubEdges][3] = {TSNET_FACE_SUB_EDGES};
 
-// grid = (kFaceSubEdges, F); kp: (F, 68, 2) cropped key points (x, y) fp64; out: (F, h, w) bytes, zeroed by the caller
-__global__ __launch_bounds__(64) void face_edges_kernel(const double* __restrict__ kp, unsigned char* __restrict__ out, int h, int w, int bw) {
+// grid = (kFaceSubEdges, F); rec: (F, 34, 8) fitted pieces (tsnet_fit_face_curves); out: (F, h, w) bytes, zeroed by the caller
+__global__ __launch_bounds__(64) void face_edges_kernel(const double* __restrict__ rec, unsigned char* __restrict__ out, int h, int w, int bw) {
     const int e = blockIdx.x, f = blockIdx.y;
-    const double* k = kp + (size_t)f * kFaceKeypoints * 2;
-    const int n = kFaceSubEdgeTable[e][2] < 0 ? 2 : 3;
-    double px[3], py[3];
-    for (int i = 0; i < n; ++i) { px[i] = k[kFaceSubEdgeTable[e][i] * 2]; py[i] = k[kFaceSubEdgeTable[e][i] * 2 + 1]; }
-    double mdx = 0, mdy = 0;
-    for (int i = 0; i + 1 < n; ++i) { mdx = fmax(mdx, fabs(px[i] - px[i + 1])); mdy = fmax(mdy, fabs(py[i] - py[i + 1])); }
-    const bool swap = mdx < mdy;                                  // fit along the axis with the larger extent (keypoint2img.py:320-321)
-    double u[3], v[3];
-    for (int i = 0; i < n; ++i) { u[i] = swap ? py[i] : px[i]; v[i] = swap ? px[i] : py[i]; }
-    double a = 0, b, c;
-    if (n == 3) {                                                 // interpolating parabola, divided differences
-        const double d01 = (v[1] - v[0]) / (u[1] - u[0]), d12 = (v[2] - v[1]) / (u[2] - u[1]);
-        a = (d12 - d01) / (u[2] - u[0]);
-        b = d01 - a * (u[0] + u[1]);
-        c = v[0] - (a * u[0] + b) * u[0];
-        if (!(fabs(a) <= 1.0)) return;                            // curvature limit of the reference (:333-334); also drops degenerate pieces
-    } else {
-        b = (v[1] - v[0]) / (u[1] - u[0]);
-        c = v[0] - b * u[0];
-        if (!(fabs(b) <= 1.7e308)) return;                        // coincident abscissae: no line (NaN or infinite slope)
-    }
-    double u0 = u[0], u1 = u[n - 1];
-    if (u0 > u1) { const double t = u0; u0 = u1; u1 = t; }       // the sample range runs upwards (:335-337)
+    const double* r = rec + ((size_t)f * kFaceSubEdges + e) * kCurveRec;
+    const int kind = (int)r[0];
+    if (!(kind & 1)) return;                                      // |a| > 1 (:333-334) or no fit
+    const bool swap = (kind & 2) != 0, quad = (kind & 4) != 0;
+    const double a = r[1], b = r[2], c = r[3], u0 = r[4], u1 = r[5];
     const int num = (int)ceil(u1 - u0);
     const double step = num > 1 ? (u1 - u0) / (double)(num - 1) : 0.0;
     for (int i = threadIdx.x; i < num; i += blockDim.x) {
         const double cu = (i == num - 1 && num > 1) ? u1 : u0 + (double)i * step;     // np.linspace: arange * step + start, last = stop
-        const double cv = n == 3 ? (a * (cu * cu) + b * cu) + c : b * cu + c;
+        const double cv = quad ? (a * (cu * cu) + b * cu) + c : b * cu + c;
         const int iu = (int)cu, iv = (int)cv;                     // astype(int): truncation
         const int x = swap ? iv : iu, y = swap ? iu : iv;
         for (int di = -bw; di < bw; ++di)
@@ -109,16 +93,21 @@ constexpr int kPosePts = 137;            // pose 25 | face 70 | left hand 21 | r
 constexpr int kPoseEdges = 24, kHandSegs = 20, kFacePieces = 54;
 constexpr int kPosePrims = kPoseEdges + 2 * kHandSegs + kFacePieces;
 // pose_edge_list incl. the feet (define_edge_lists, keypoint2img_posenorm.py:396-421); with basic_point_only only the first 18
-__device__ const unsigned char kPoseEdgeTable[kPoseEdges][2] = {
-    {17, 15}, {15, 0}, {0, 16}, {16, 18}, {0, 1}, {1, 8}, {1, 2}, {2, 3}, {3, 4}, {1, 5}, {5, 6}, {6, 7},
-    {8, 9}, {9, 10}, {10, 11}, {8, 12}, {12, 13}, {13, 14}, {11, 24}, {11, 22}, {22, 23}, {14, 21}, {14, 19}, {19, 20}};
+#define TSNET_POSE_EDGES \
+    {17, 15}, {15, 0}, {0, 16}, {16, 18}, {0, 1}, {1, 8}, {1, 2}, {2, 3}, {3, 4}, {1, 5}, {5, 6}, {6, 7}, \
+    {8, 9}, {9, 10}, {10, 11}, {8, 12}, {12, 13}, {13, 14}, {11, 24}, {11, 22}, {22, 23}, {14, 21}, {14, 19}, {19, 20}
+static const unsigned char hPoseEdgeTable[kPoseEdges][2] = {TSNET_POSE_EDGES};
+__device__ const unsigned char kPoseEdgeTable[kPoseEdges][2] = {TSNET_POSE_EDGES};
 // face_list cut into consecutive pairs (edge_len = 2, :296-300)
-__device__ const unsigned char kFacePieceTable[kFacePieces][2] = {
-    {0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {9, 10}, {10, 11}, {11, 12}, {12, 13}, {13, 14}, {14, 15}, {15, 16},
-    {17, 18}, {18, 19}, {19, 20}, {20, 21}, {22, 23}, {23, 24}, {24, 25}, {25, 26},
-    {28, 31}, {31, 32}, {32, 33}, {33, 34}, {34, 35}, {35, 28},
-    {36, 37}, {37, 38}, {38, 39}, {39, 40}, {40, 41}, {41, 36}, {42, 43}, {43, 44}, {44, 45}, {45, 46}, {46, 47}, {47, 42},
-    {48, 49}, {49, 50}, {50, 51}, {51, 52}, {52, 53}, {53, 54}, {54, 55}, {55, 56}, {56, 57}, {57, 58}, {58, 59}, {59, 48}};
+#define TSNET_FACE_PIECES \
+    {0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {9, 10}, {10, 11}, {11, 12}, {12, 13}, {13, 14}, {14, 15}, {15, 16}, \
+    {17, 18}, {18, 19}, {19, 20}, {20, 21}, {22, 23}, {23, 24}, {24, 25}, {25, 26}, \
+    {28, 31}, {31, 32}, {32, 33}, {33, 34}, {34, 35}, {35, 28}, \
+    {36, 37}, {37, 38}, {38, 39}, {39, 40}, {40, 41}, {41, 36}, {42, 43}, {43, 44}, {44, 45}, {45, 46}, {46, 47}, {47, 42}, \
+    {48, 49}, {49, 50}, {50, 51}, {51, 52}, {52, 53}, {53, 54}, {54, 55}, {55, 56}, {56, 57}, {57, 58}, {58, 59}, {59, 48}
+static const unsigned char hFacePieceTable[kFacePieces][2] = {TSNET_FACE_PIECES};
+__device__ const unsigned char kFacePieceTable[kFacePieces][2] = {TSNET_FACE_PIECES};
+
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -138,11 +127,31 @@ __device__ __forceinline__ void raise_byte(unsigned char* base, size_t idx, unsi
     }
 }
 
-// grid = (kPosePrims, F).  pts: (F, 137, 2) fp64 in frame coordinates, invalid points = 0 (extract_valid_keypoints).  The skeleton is drawn on
+// HOST: the two point indices (into the 137-point array) of primitive e, or false when the flags drop it -- the index logic of
+// pose_edges_kernel below, for tsnet_fit_pose_curves
+inline bool pose_primitive_points(int e, int flags, int& ia, int& ib) {
+    if (e < kPoseEdges) {
+        if ((flags & 1) && e >= 18) return false;
+        ia = hPoseEdgeTable[e][0]; ib = hPoseEdgeTable[e][1];
+    } else if (e < kPoseEdges + 2 * kHandSegs) {
+        if (flags & 1) return false;
+        const int k = e - kPoseEdges, hand = k / kHandSegs, seg = k % kHandSegs, finger = seg / 4, j = seg % 4;
+        const int base = 25 + 70 + hand * 21;
+        ia = base + (j == 0 ? 0 : finger * 4 + j); ib = base + finger * 4 + j + 1;
+    } else {
+        if (flags & 3) return false;
+        const int k = e - kPoseEdges - 2 * kHandSegs;
+        ia = 25 + hFacePieceTable[k][0]; ib = 25 + hFacePieceTable[k][1];
+    }
+    return true;
+}
+
+// grid = (kPosePrims, F).  pts: (F, 137, 2) fp64 in frame coordinates, invalid points = 0 (extract_valid_keypoints); rec: (F, kPosePrims, 8)
+// fitted pieces (tsnet_fit_pose_curves: straight lines through two points, fitted as the reference fits them).  The skeleton is drawn on
 // the h x w frame (border clamping of draw_edge against THAT size), but only pixels inside the window [x0, x1) x [y0, y1) are stored:
 // out is (F, y1 - y0, x1 - x0) -- crop_person_region (:538-552) of the drawn frame.  flags: 1 = basic_point_only, 2 = remove_face_labels.
-__global__ __launch_bounds__(64) void pose_edges_kernel(const double* __restrict__ pts, unsigned char* __restrict__ out, int h, int w,
-                                                        int x0, int y0, int x1, int y1, int flags) {
+__global__ __launch_bounds__(64) void pose_edges_kernel(const double* __restrict__ pts, const double* __restrict__ rec, unsigned char* __restrict__ out,
+                                                        int h, int w, int x0, int y0, int x1, int y1, int flags) {
     const int e = blockIdx.x, f = blockIdx.y;
     const double* P = pts + (size_t)f * kPosePts * 2;
     int ia, ib, order, bw;
@@ -167,14 +176,14 @@ __global__ __launch_bounds__(64) void pose_edges_kernel(const double* __restrict
             ia = 25 + kFacePieceTable[k][0]; ib = 25 + kFacePieceTable[k][1]; order = kPoseEdges + 10; bw = bw_small;
         }
     }
-    const double ax = P[2 * ia], ay = P[2 * ia + 1], bx = P[2 * ib], by = P[2 * ib + 1];
-    if (ax == 0.0 || bx == 0.0) return;                           // `0 not in x`
-    const bool swap = fabs(ax - bx) < fabs(ay - by);              // fit along the axis with the larger extent (:491-492)
-    double u0 = swap ? ay : ax, v0 = swap ? ax : ay, u1 = swap ? by : bx, v1 = swap ? bx : by;
-    const double b = (v1 - v0) / (u1 - u0), c = v0 - b * u0;      // the line curve_fit(linear, ..) converges to
-    if (u0 > u1) { const double t = u0; u0 = u1; u1 = t; }
+    (void)ia; (void)ib;
+    const double* r = rec + ((size_t)f * kPosePrims + e) * kCurveRec;
+    const int kind = (int)r[0];
+    if (!(kind & 1)) return;                                      // a missing point (`0 not in x`), or no fit
+    const bool swap = (kind & 2) != 0;                            // fitted along the axis with the larger extent (:491-492)
+    const double b = r[2], c = r[3], u0 = r[4], u1 = r[5];        // the line curve_fit(linear, ..) converged to, sample range upwards
     const int num = (int)ceil(u1 - u0);
-    if (num < 1 || !(fabs(b) <= 1.7e308)) return;
+    if (num < 1) return;
     const double step = num > 1 ? (u1 - u0) / (double)(num - 1) : 0.0;
     const int cw = x1 - x0, ch = y1 - y0;
     const unsigned val = (unsigned)order + 1u;

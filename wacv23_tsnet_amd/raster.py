@@ -63,15 +63,23 @@ class FaceRasteriser:
         h, w = crop[1] - crop[0], crop[3] - crop[2]
         bw = max(1, h // 256)                                      # :295
         F = kp.shape[0]
+        kp = np.ascontiguousarray(kp)
+        # interp_points' Levenberg-Marquardt fits run on the host (34 per frame, microseconds each; csrc/lmfit.hpp reproduces scipy's
+        # curve_fit to the last bit); the device samples and draws the fitted curves
+        curves = np.empty((F, 34, 8), dtype=np.float64)
+        rc = self.lib.tsnet_fit_face_curves(kp.ctypes.data, F, curves.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"tsnet_fit_face_curves failed ({rc}): {self.lib.tsnet_op_last_error().decode()}")
         kd = torch.from_numpy(kp).to(self.device)
+        cd = torch.from_numpy(curves).to(self.device)
         edges = torch.empty((F, h, w), dtype=torch.uint8, device=self.device)
         bbox = torch.empty((F, h, w), dtype=torch.uint8, device=self.device)
         ctx = torch.cuda.device(self.device) if self.device.type == "cuda" else _Null()
         with ctx:
-            rc = self.lib.tsnet_raster_face(kd.data_ptr(), F, h, w, bw, edges.data_ptr(), bbox.data_ptr(), self._stream())
+            rc = self.lib.tsnet_raster_face(kd.data_ptr(), cd.data_ptr(), F, h, w, bw, edges.data_ptr(), bbox.data_ptr(), self._stream())
         if rc != 0:
             raise RuntimeError(f"tsnet_raster_face failed ({rc}): {self.lib.tsnet_op_last_error().decode()}")
-        self._keep = kd
+        self._keep = (kd, cd)
         return edges, bbox, crop, bw
 
     def vl2ch(self, labels: torch.Tensor, num_classes: int) -> torch.Tensor:
@@ -297,13 +305,17 @@ class PoseRasteriser:
         xs, ys, xe, ye = window if window is not None else (0, 0, w, h)
         F = pts.shape[0]
         n = F * (ye - ys) * (xe - xs)
+        pts = np.ascontiguousarray(pts)
+        flags = (1 if basic_point_only else 0) | (2 if remove_face_labels else 0)
+        curves = np.empty((F, 118, 8), dtype=np.float64)              # every stroke's line, fitted on the host as the reference fits it (csrc/lmfit.hpp)
+        self._check(self.lib.tsnet_fit_pose_curves(pts.ctypes.data, F, flags, curves.ctypes.data), "tsnet_fit_pose_curves")
         pd = torch.from_numpy(pts).to(self.device)
+        cd = torch.from_numpy(curves).to(self.device)
         buf = torch.empty((n + 3) // 4 * 4, dtype=torch.uint8, device=self.device)      # whole 32-bit words: the kernel raises bytes with word atomics
         with self._ctx():
-            rc = self.lib.tsnet_raster_pose(pd.data_ptr(), F, h, w, xs, ys, xe, ye, (1 if basic_point_only else 0) | (2 if remove_face_labels else 0),
-                                            buf.data_ptr(), self._stream())
+            rc = self.lib.tsnet_raster_pose(pd.data_ptr(), cd.data_ptr(), F, h, w, xs, ys, xe, ye, flags, buf.data_ptr(), self._stream())
         self._check(rc, "tsnet_raster_pose")
-        self._keep = [pd, buf]
+        self._keep = [pd, cd, buf]
         return buf[:n].view(F, ye - ys, xe - xs)
 
     def bbox(self, labels: torch.Tensor) -> torch.Tensor:
