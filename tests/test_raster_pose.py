@@ -10,6 +10,7 @@ resize + padding to 256 x 256.
     reference's on all 60 frames, on the re-drawn driving frames and on the limb-rescaled ones."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -19,6 +20,9 @@ from PIL import Image
 import helpers as Hh
 from oracle import raster_pose_oracle as PO
 from wacv23_tsnet_amd import raster
+
+sys.path.insert(0, os.path.join(Hh.ROOT, "tools")) if hasattr(Hh, "ROOT") else sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import pose_preprocess as pre        # loader-side preprocessing of a driving clip: a tool outside the product package
 
 
 def _golden():
@@ -71,16 +75,16 @@ def test_pose_preprocessing_host_logic_matches_reference():
     meta, z = _golden()
     for clip, m in meta["clips"].items():
         crop = m["crop"]
-        assert np.array_equal(raster.smooth_clip(z[f"{clip}_pts"]), z[f"{clip}_smooth"])
-        assert np.array_equal(raster.shift_into_crop(z[f"{clip}_fm_pts_in"][0], crop), z[f"{clip}_pts_redraw"][0])
+        assert np.array_equal(pre.smooth_clip(z[f"{clip}_pts"]), z[f"{clip}_smooth"])
+        assert np.array_equal(pre.shift_into_crop(z[f"{clip}_fm_pts_in"][0], crop), z[f"{clip}_pts_redraw"][0])
         for mode in ("fm", "mf"):
             pin, pout = z[f"{clip}_{mode}_pts_in"], z[f"{clip}_{mode}_pts_out"]
             for p, q in zip(pin, pout):
-                got = raster.pose_limb_rescale(raster.shift_into_crop(p, crop), mode, crop[3] - crop[1])
+                got = pre.pose_limb_rescale(pre.shift_into_crop(p, crop), mode, crop[3] - crop[1])
                 assert np.array_equal(got, q), (clip, mode)
-            assert np.abs(pout - np.stack([raster.shift_into_crop(p, crop) for p in pin])).max() > 5      # the re-scaling really moves limbs
+            assert np.abs(pout - np.stack([pre.shift_into_crop(p, crop) for p in pin])).max() > 5      # the re-scaling really moves limbs
     with pytest.raises(ValueError):
-        raster.pose_limb_rescale(z["00110_pts"][0], "ff", 100)
+        pre.pose_limb_rescale(z["00110_pts"][0], "ff", 100)
 
 
 def test_read_smooth_openpose_file(tmp_path):
@@ -91,7 +95,7 @@ def test_read_smooth_openpose_file(tmp_path):
            "hand_right_keypoints_2d": enc(sm[:, 116:]), "name": ["frame%06d" % i for i in range(sm.shape[0])]}
     path = tmp_path / "00164.json"
     path.write_text(json.dumps(doc))
-    assert np.array_equal(raster.read_smooth_openpose(str(path)), sm)
+    assert np.array_equal(pre.read_smooth_openpose(str(path)), sm)
 
 
 def _device_check(lib, dev):
@@ -113,7 +117,7 @@ def _device_check(lib, dev):
         # opposite-sex pairs: the label drawn from the re-scaled points (host) at crop size
         for mode in ("fm", "mf"):
             pin, want_m = z[f"{clip}_{mode}_pts_in"], z[f"{clip}_{mode}_cls"]
-            moved = [raster.pose_limb_rescale(raster.shift_into_crop(p, crop), mode, ch) for p in pin]
+            moved = [pre.pose_limb_rescale(pre.shift_into_crop(p, crop), mode, ch) for p in pin]
             got_m = r.rasterise(moved, (cw, ch)).cpu().numpy()
             report[clip][f"{mode}_differing"] = int((got_m != want_m).sum())
             assert np.array_equal(got_m, want_m), report

@@ -1,7 +1,7 @@
 """GPU box: in-run A/B of the patch-convolution variants (tools build, python -m wacv23_tsnet_amd.build --tools).
 
 Per layer shape, every variant is timed in interleaved rounds inside ONE process (cdna_hip_programming.md rule 24) and the median
-reported.  variant code of tsnet_bench_conv: tile | general kernel << 12 | ablation mask << 16 | experiment mask << 24.
+reported.  variant code of tsnet_bench_conv: tile | general kernel << 12 | ablation mask << 16 | experiment mask << 24 | XCD grid << 28.
   experiment mask (h2_tile OPT): 1 = legacy staging arithmetic (select + scalar converts), 2 = rotating wave priority
   ablation mask  (h2_tile HABL, computes garbage): 1 no patch staging, 2 weights once, 4 A fragments once, 8 no fold, 16 no barrier
 usage: h2_variants.py [rounds]"""
@@ -14,8 +14,10 @@ torch.zeros(1, device="cuda")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 
 
-def code(tile=0, general=False, abl=0, opt=0):
-    return tile | (4096 if general else 0) | (abl << 16) | (opt << 24)
+def code(tile=0, general=False, abl=0, opt=0, xcd=None):
+    """xcd: None = the launcher's choice, 0 = consecutive tiles per XCD, 1 / 2 / 4 / 8 = columns of the XCD grid over the N tiles"""
+    gx = 0 if xcd is None else (1 if xcd == 0 else {1: 2, 2: 3, 4: 4, 8: 5}[xcd])
+    return tile | (4096 if general else 0) | (abl << 16) | (opt << 24) | (gx << 28)
 
 
 def run(name, shape, variants, norms=(0, 1), iters=8):
@@ -37,7 +39,21 @@ def run(name, shape, variants, norms=(0, 1), iters=8):
         print(f"   {vn:28s} {'IN+ReLU' if nrm else 'raw    '}  {med*1e3:8.1f} us  {flops/med/1e9:7.1f} TF   (min {min(t)*1e3:.1f} max {max(t)*1e3:.1f})", flush=True)
 
 
+SEL = sys.argv[2] if len(sys.argv) > 2 else "all"
 RES = (12, 32, 32, 512, 512, 3, 1, 1, 1)
+FUSE = (12, 32, 32, 1024, 1024, 3, 1, 1, 1)
+if SEL in ("all", "xcd"):
+    run("res: XCD grids (4x64)", RES, [("linear", code(64, xcd=0))] + [(f"grid x{g}", code(64, xcd=g)) for g in (1, 2, 4, 8)])
+    run("res: XCD grids (2x128)", RES, [("linear", code(2128, xcd=0))] + [(f"grid x{g}", code(2128, xcd=g)) for g in (1, 2, 4)], norms=(1,))
+    run("fuse_c2: XCD grids (4x128)", FUSE, [("linear", code(128, xcd=0))] + [(f"grid x{g}", code(128, xcd=g)) for g in (1, 2, 4, 8)])
+    run("fuse_c2: XCD grids (4x64)", FUSE, [("linear", code(64, xcd=0))] + [(f"grid x{g}", code(64, xcd=g)) for g in (2, 4, 8)], norms=(1,))
+    run("fuse_c1_src: XCD grids (4x128)", (12, 32, 32, 512, 1024, 3, 1, 1, 1), [("linear", code(128, xcd=0))] + [(f"grid x{g}", code(128, xcd=g)) for g in (2, 4, 8)], norms=(0,))
+    run("dec_up0: XCD grids (4x128)", (4, 64, 64, 512, 256, 3, 1, 1, 1), [("linear", code(128, xcd=0))] + [(f"grid x{g}", code(128, xcd=g)) for g in (1, 2)], norms=(0,))
+    for nm, shp in (("down1 (64->128)", (12, 256, 256, 64, 128, 3, 2, 1, 0)), ("down2 (128->256)", (12, 128, 128, 128, 256, 3, 2, 1, 0)),
+                    ("down3 (256->512)", (12, 64, 64, 256, 512, 3, 2, 1, 0))):
+        run(nm, shp, [("h2d 4 waves x 64", code(64)), ("h2d 8 waves x 128", code(128)), ("general 128", code(128, general=True))], norms=(1,))
+if SEL == "xcd":
+    sys.exit(0)
 run("res (ResnetBlock conv, B=4 K=3)", RES,
     [("4x64", code(64)), ("4x64 legacy-staging", code(64, opt=1)), ("4x64 prio", code(64, opt=2)), ("4x64 legacy+prio", code(64, opt=3)),
      ("4x128", code(128)), ("4x128 legacy-staging", code(128, opt=1)), ("2x128", code(2128)), ("2x128 prio", code(2128, opt=2)), ("4x32", code(32))])

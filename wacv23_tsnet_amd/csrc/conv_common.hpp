@@ -67,6 +67,24 @@ __device__ __forceinline__ int xcd_item(int bid, int nitems) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// block -> (tile_m, tile_n).  Blocks are dealt to the XCDs round-robin (block b runs on XCD b % 8: observed, used for speed only) and every
+// XCD has its own L2.  gn = 0: XCD x takes the x-th run of consecutive tiles (N fastest).  gn > 0: the XCDs form a (8 / gn) x gn grid over
+// the tile matrix -- XCD (mg, ng) takes the M-tiles of block row mg and the N-tiles of block column ng, N fastest inside -- so an XCD
+// streams only 1 / gn of the weights and gn / 8 of the activations through its L2 (weights x 8 / gn + activations x gn cross the fabric
+// instead of weights x 8).  The host passes gn > 0 only when it divides evenly (tiles_n % gn == 0, tiles_m % (8 / gn) == 0).
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int gn, int& tile_m, int& tile_n) {
+    if (gn > 0) {
+        const int xcd = bid & 7, loc = bid >> 3;
+        const int tn = tiles_n / gn, tm = tiles_m / (8 / gn);
+        tile_m = (xcd / gn) * tm + loc / tn;
+        tile_n = (xcd % gn) * tn + loc % tn;
+    } else {
+        const int item = xcd_item(bid, tiles_m * tiles_n);
+        tile_m = item / tiles_n;
+        tile_n = item - tile_m * tiles_n;
+    }
+}
+
 __device__ __forceinline__ unsigned short bf16_rne(float f) {
     const unsigned u = __builtin_bit_cast(unsigned, f);
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);     // finite inputs only (activations / weights)
@@ -107,6 +125,7 @@ struct ConvArgs {
     int Ho, Wo, Cout, Npad;
     int stride, pad, reflect, taps, nchunks, M;      // nchunks in units of 16 k
     int tiles_m, tiles_n, tpi;                       // tpi = tiles per image (an M tile never straddles two images)
+    int xcd_gn;                                      // 0: consecutive tiles per XCD; else the 8 XCDs form a (8 / xcd_gn) x xcd_gn grid over (M, N) tiles
     // optional: the last workgroup to deliver the statistics of an (image, channel tile) finalises them itself
     // (alpha = rstd, beta = -mean*rstd), replacing the in_finalize2 launch; null = off
     float* fin_alpha; float* fin_beta; int* fin_counter; int fin_S; float fin_eps;

@@ -271,9 +271,9 @@ template <int PR, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int 
 __global__ __launch_bounds__(256, (BN / WARPS_N) * (PR / WARPS_M) <= 64 ? 3 : 2)   // wave tile 64 x 32: three workgroups per CU; 64 x 64: two
 void conv_h2_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
-    const int bid = xcd_item(blockIdx.x, a.tiles_m * a.tiles_n);
-    const int tile_m = bid / a.tiles_n;
-    h2_tile<PR, BN, WARPS_M, WARPS_N, NPROD, AFFINE, HABL, OPT>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+    int tile_m, tile_n;
+    tile_of_block(blockIdx.x, a.tiles_m, a.tiles_n, a.xcd_gn, tile_m, tile_n);
+    h2_tile<PR, BN, WARPS_M, WARPS_N, NPROD, AFFINE, HABL, OPT>(a, smem_raw, tile_m, tile_n * BN);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -433,8 +433,8 @@ void conv_h2s_kernel(ConvArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // h2d: the encoders' 3 x 3 / stride-2 / zero-pad-1 downsampling convolutions (TSNet.py:70) as a patch kernel -- h2_tile with the patch
 // geometry of stride 2.  A 4 x 32 output rectangle reads the (2*4+1) x (2*32+1) = 9 x 65 input patch; per 16-channel slab it is fetched once
-// (585 pixels x 64 B), transformed and split like h2_tile's, and written to LDS with its columns DE-INTERLEAVED by parity: row pitch 66
-// slots = 33 even columns, then 32 odd ones.  Output column x under tap column kx reads input column 2x + kx: kx = 0 -> even slot x,
+// (585 pixels x 64 B), transformed and split like h2_tile's, and written to LDS with its columns DE-INTERLEAVED by parity: row pitch 68
+// slots = 33 even columns, then (from slot 36) 32 odd ones.  Output column x under tap column kx reads input column 2x + kx: kx = 0 -> even slot x,
 // kx = 1 -> odd slot x, kx = 2 -> even slot x + 1, so the 32 lanes of a fragment read 32 consecutive 16-byte slots (conflict-free) and
 // row / tap shifts are immediates, exactly as in the stride-1 kernel.  Against the implicit GEMM (conv_h2r) on these layers: half the
 // staged elements (the im2col tile holds every input element 2.25 times), no global A traffic per k-step, one barrier per slab instead of
@@ -454,7 +454,8 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     constexpr int MT = WM / 32, NTL = WN / 32;
     static_assert(MT == 2 && NTL == 1, "wave tile 64 x 32");
     constexpr int PCI = 2 * kPatchCols + 1, PRI = 2 * kPatchRows + 1, PP = PRI * PCI;     // 65 x 9 = 585 patch pixels
-    constexpr int RP = 66;                                           // row pitch in slots: 33 even columns, 32 odd, 1 spare
+    constexpr int RP = 68, ODD0 = 36;                                // row pitch in slots: 33 even columns, pad, 32 odd columns from slot 36 on: the 8 lanes of a
+                                                                     // ds_write_b128 group (4 even + 4 odd pixels) then hit disjoint banks (36 * 16 B = 16 banks mod 32)
     constexpr int REGION = PRI * RP * 16;                            // one octet region: 594 slots x 16 B
     constexpr int PLANE_P = 2 * REGION, PATCH_BYTES = NPL * PLANE_P;
     constexpr int OFF_SINK = 2 * 2 * PLANE_P;                        // 2 KiB sink for pixel slots that do not exist (branch-free staging)
@@ -490,7 +491,7 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     auto slot_of = [&](int r) __attribute__((always_inline)) {       // LDS byte offset of the lane's slot inside an octet region (recomputed, not kept), or -1
         const int pp = (wave + NWV * r) * 32 + (lane & 31);
         const int pr = pp / PCI, pc = pp - pr * PCI;
-        return pp < PP ? (pr * RP + ((pc & 1) ? 33 + (pc >> 1) : (pc >> 1))) * 16 : -1;
+        return pp < PP ? (pr * RP + ((pc & 1) ? ODD0 + (pc >> 1) : (pc >> 1))) * 16 : -1;
     };
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -551,7 +552,7 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
-                af[set][p][i] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + ((2 * i + ky) * RP + (kx == 1 ? 33 : (kx >> 1))) * 16);
+                af[set][p][i] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + ((2 * i + ky) * RP + (kx == 1 ? ODD0 : (kx >> 1))) * 16);
     };
 
     f32x16 acc[MT][NTL], tot[MT][NTL];
@@ -650,7 +651,7 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
                                                  [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
 }
 
-constexpr int kH2dLds = 2 * 2 * 2 * (2 * kPatchRows + 1) * 66 * 16 + 2048;      // two stages x two planes x two octet regions + sink (+ 2 Cin floats x 2 of the table)
+constexpr int kH2dLds = 2 * 2 * 2 * (2 * kPatchRows + 1) * 68 * 16 + 2048;      // two stages x two planes x two octet regions + sink (+ 2 Cin floats x 2 of the table)
 
 template <int BN, int NWV, int NPROD, bool AFFINE>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 3 : 2)             // eight waves: 1.5 workgroups = three waves per SIMD

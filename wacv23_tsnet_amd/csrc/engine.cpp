@@ -177,6 +177,7 @@ struct ConvCall {
     int kernel = 0;             // 0 = the layer's own kernel class, 1 = force the general kernel, 2 = require a patch kernel (op tests)
     int tile = 0;               // 0 = heuristic; else rows * 1000 + width of the patch tile (32, 64, 128 = 4 rows; 2128 = 2 x 128), or 64 / 128 for the others
     int abl = 0, opt = 0;       // tools build: ablation / experiment masks of h2_tile
+    int xcd_gn = -1;            // -1 = the launcher's choice; 0 = consecutive tiles per XCD; 1, 2, 4, 8 = XCD grid columns over the N tiles (tile_of_block)
     int tclass = TSNET_T_CONV;
 };
 
@@ -194,7 +195,8 @@ inline int h2_scale_log2(float bound) {
 // Kernel class of a layer at a frame size.  The patch kernels sum K slab-major, the general one tap-major: the class must depend on the
 // layer and the geometry alone, never on the batch (a sample's result is the same bits in any batch).
 enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3 };
-inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool transform, int rows = kPatchRows) {
+// eligible_only: what the layer CAN run on (an explicit request, op tests / tools); otherwise what the forward runs it on
+inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool transform, int rows = kPatchRows, bool eligible_only = false) {
     const int Ho = (H + 2 * L.pad - L.ks) / L.stride + 1, Wo = (W + 2 * L.pad - L.ks) / L.stride + 1;
     const bool s1 = L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H >= 2 && W >= 2;
     if (two_sources || Ho <= 0 || Wo <= 0 || Wo % kPatchCols) return K_GENERAL;
@@ -202,7 +204,9 @@ inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool t
     if (Ho % kPatchRows) return K_GENERAL;
     if (s1) return K_H2;
     if (L.ks == 7 && L.stride == 1 && L.pad == 3 && L.reflect && L.cin_pad == 8 && !transform && H >= 4 && W >= 4) return K_H2S;
-    if (L.ks == 3 && L.stride == 2 && L.pad == 1 && !L.reflect && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H == 2 * Ho && W == 2 * Wo) return K_H2D;
+    // stride 2: the patch kernel from 128 input channels on (117 / 125 us on the 128 -> 256 / 256 -> 512 layers against 132 / 142 us for the
+    // general kernel); with 64 channels the K loop is four slabs long and the general kernel's smaller per-tile prologue wins (147 vs 157 us)
+    if (L.ks == 3 && L.stride == 2 && L.pad == 1 && !L.reflect && L.cin_pad >= (eligible_only ? 16 : 128) && (L.cin_pad & 15) == 0 && H == 2 * Ho && W == 2 * Wo) return K_H2D;
     return K_GENERAL;
 }
 
@@ -232,7 +236,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         throw ArgError("conv: tensor too large for 32-bit buffer offsets");
     if ((size_t)2 * g.Cin * 4 > 32 * 1024) throw ArgError("conv: too many input channels for the transform table");
     const int hw = g.Ho * g.Wo;
-    const int cls = c.kernel == 1 ? K_GENERAL : conv_class(L, c.H, c.W, c.x2 != nullptr, c.alpha != nullptr, c.tile >= 1000 ? c.tile / 1000 : kPatchRows);
+    const int cls = c.kernel == 1 ? K_GENERAL : conv_class(L, c.H, c.W, c.x2 != nullptr, c.alpha != nullptr, c.tile >= 1000 ? c.tile / 1000 : kPatchRows, c.kernel == 2);
     if (c.kernel == 2 && cls == K_GENERAL) throw ArgError("conv: this layer / frame size has no patch kernel");
     g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f;
     TimeScope ts(ctx, c.tclass);
@@ -266,6 +270,16 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
             if ((pr != 2 && pr != 4) || g.Ho % pr) throw ArgError("conv(h2): the output height must be a multiple of the tile's rows (2 or 4)");
             if (g.Npad % bn) throw ArgError("conv(h2): the tile width must divide the padded output width");
             set_tiles(pr * kPatchCols, bn);
+            {
+                // weight planes far beyond the 4 MiB of an XCD's L2 (FuseNet: 37.7 MB): a 2 x 4 XCD grid streams a quarter of them per XCD
+                // (-2..3 % on the 1024 -> 1024 layer, nothing on the 512 -> 512 ones: profiles/round3_conv_variants.txt)
+                int gn = c.xcd_gn < 0 ? (((double)L.kpad * L.npad * 4 > 16e6) ? 4 : 0) : c.xcd_gn;
+                if (gn && ((gn != 1 && gn != 2 && gn != 4 && gn != 8) || g.tiles_n % gn || g.tiles_m % (8 / gn))) {
+                    if (c.xcd_gn >= 0) throw ArgError("conv(h2): the XCD grid does not divide the tile matrix");
+                    gn = 0;
+                }
+                g.xcd_gn = gn;
+            }
             launch_conv_h2(g, pr, bn, c.nprod, c.abl, c.opt, ctx.stream);
             ++g_launch_counters[0];
             if (c.tclass == TSNET_T_CONV_RES) g_launch_counters[3] = pr * 1000 + bn;
@@ -1514,7 +1528,8 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     {
         OpLayer op(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s);
         ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = norm ? 64.f : 1.f; c.nprod = nprod;
-        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : 0; c.abl = (v >> 16) & 255; c.opt = (v >> 24) & 255;
+        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : 0; c.abl = (v >> 16) & 255; c.opt = (v >> 24) & 15;
+        { const int gx = (v >> 28) & 7; c.xcd_gn = gx == 0 ? -1 : (gx == 1 ? 0 : 1 << (gx - 2)); }          // bits 28-30: 0 default, 1 linear, 2..5 grid with 1, 2, 4, 8 columns
         if (norm) { c.alpha = al; c.beta = be; c.relu = 1; }
         for (int i = 0; i < 2; ++i) run_conv(ctx, op.L, c);
         hipEvent_t e0, e1;
