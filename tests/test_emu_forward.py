@@ -125,9 +125,10 @@ def test_patch_kernel_schedule(emu_lib):
     rec, flows = Hh.run_engine(eng, inp, "cpu")
     cnt = (C.c_int64 * 4)()
     emu_lib.tsnet_debug_counters(cnt, 1)
-    # patch kernels: 2 stems + 2 x 3 downsampling + 2 (encoder block) + 2 (halves of fuse conv1) + 1 (fuse conv2) + 2 (decoder block)
-    # + 3 (decoder up-convolutions) = 18; general kernel: fuse_net.conv and dec.map_conv
-    assert cnt[0] == 18 and cnt[1] == 2 and cnt[2] == 1
+    # patch kernels: 2 stems + 2 (the 128-channel downsampling layer of each encoder) + 2 (encoder block) + 2 (halves of fuse conv1)
+    # + 1 (fuse conv2) + 2 (decoder block) + 3 (decoder up-convolutions) = 14; general kernel: the 32- and 64-channel downsampling layers
+    # (2 x 2), fuse_net.conv and dec.map_conv
+    assert cnt[0] == 14 and cnt[1] == 6 and cnt[2] == 1
     assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
     rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, 1, "cpu")
     assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4
@@ -170,7 +171,7 @@ def test_bf16_operand_mode(emu_lib):
     rec, flows = Hh.run_engine(eng, inp, "cpu")
     cnt = (C.c_int64 * 4)()
     emu_lib.tsnet_debug_counters(cnt, 1)
-    assert cnt[0] == 18 and cnt[1] == 2
+    assert cnt[0] == 14 and cnt[1] == 6
     r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, 1, "cpu")
     print("[bf16 mode] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
     assert r["src_fea"] < 5e-2 and r["tar_fea"] < 2e-2 and r["sg"] < 8e-2          # bf16 flip noise on a +-18 range
