@@ -63,6 +63,7 @@ f32x16_t mfma_f16_32x32x16(const void* a16, const void* b16, f32x16_t c);
 // dynamic LDS: HIP's own HIP_DYNAMIC_SHARED macro (amd_device_functions.h) is what the kernels use
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<unsigned char*>(emu::g_dyn_smem);
 static inline void __syncthreads() { emu::syncthreads(); }
+#define TSNET_FAST_EXP(x) expf(x)     // device: __expf = v_exp_f32 of x * log2 e; the emulator evaluates it exactly
 static inline float __shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }
 static inline double __shfl_xor(double v, int mask) {
     union { double d; float f[2]; } u, r; u.d = v;

@@ -60,6 +60,13 @@ def test_conv_h2_tile_shapes_and_scales(emu_lib):
     # every tile shape runs the same chains per output element
     ys = [oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 48, 128, True, norm=True, tile_n=t, return_output=True) for t in (32, 64, 128, 2128)]
     assert all(torch.equal(ys[0], y) for y in ys[1:])
+    # two K groups (20032 / 20064: single-frame launches; eight waves, group g folds the chains of slabs g, g + 2, ...; total = P0 + P1, weight
+    # fragments eight steps ahead): the same bits in both tile
+    # shapes, fp32-class accuracy, NOT the bits of the one-group tiles (another association of the same chains)
+    zs = [oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 64, 128, True, norm=True, tile_n=t, return_output=True) for t in (64, 20032, 20064)]
+    assert torch.equal(zs[1], zs[2]) and not torch.equal(zs[0], zs[1]) and (zs[0] - zs[1]).abs().max().item() < 1e-5 * zs[0].abs().max().item()
+    assert oc.conv_h2_case(emu_lib, "cpu", 2, 8, 32, 32, 64, False, tile_n=20064) < REL
+    assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 64, 96, 96, True, norm=True, tile_n=20032) < REL       # six slabs: three per group (odd local count)
     # operands far from 1: the power-of-two scales keep the fp16 planes in range (results relative to max|ref|)
     assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=300.0) < REL
     assert oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True, scale=1e-4) < REL
@@ -125,8 +132,10 @@ def test_flow_ragged_positions_and_spike(emu_lib):
 
 
 def test_flow_many_tiles(emu_lib):
-    df, dw = oc.flow_case(emu_lib, "cpu", 1, 16, 16, 16, "ones", spike=True)   # 8 source tiles: 2 per wave
+    df, dw = oc.flow_case(emu_lib, "cpu", 1, 16, 16, 16, "ones", spike=True)   # 4 pairs of 32-source blocks: waves 0..3 sweep one each
     assert df < 5e-5 and dw < 4e-3   # dw = flow error x feature gradient
+    df, dw = oc.flow_case(emu_lib, "cpu", 1, 24, 24, 16, "bernoulli", spike=True)   # 9 pairs: wave 0 sweeps two; 9 workgroups of 64 targets
+    assert df < 5e-5 and dw < 4e-3
 
 
 def test_warp_out_of_range(emu_lib):

@@ -112,6 +112,31 @@ def test_cfg0_batch_items_independent(cfg0):
     assert torch.equal(r, rec[sl])
 
 
+def test_single_frame_forward(cfg0):
+    """B = 1, the reference demo's own call (demo_face.py:185-192): launches of at most one tile per CU run the two-K-group tiles (eight
+    waves, total = P0 + P1).  Same parity bar against the reference golden as the batched forward; against the same frame inside the
+    batch only agreement to fp32 rounding (amplified by the network) -- another association of the same chains -- which is measured and
+    bounded here; run-to-run the single-frame forward is bit-identical."""
+    import ctypes
+    from wacv23_tsnet_amd import _lib
+    eng, inputs, rec, z = cfg0["eng"], cfg0["inputs"], cfg0["rec"], cfg0["z"]
+    sl = slice(0, 1)
+    sub = ([x[sl] for x in inputs[0]], [x[sl] for x in inputs[1]], [x[sl] for x in inputs[2]], inputs[3][sl], inputs[4][sl])
+    r1, f1 = Hh.run_engine(eng, sub, DEV)
+    cnt = (ctypes.c_int64 * 4)()
+    _lib.load().tsnet_debug_counters(cnt, 0)
+    assert cnt[3] == 24064, cnt[3]                  # the ResnetBlock layers of one frame: 4 x 64 tiles, two K groups
+    r2, _ = Hh.run_engine(eng, sub, DEV)
+    assert torch.equal(r1, r2)
+    d_crop = np.abs(r1[:, :, 96:128, 96:128].numpy() - z["rec_crop"][sl]).max()
+    d_flow = max(np.abs(f1[i].numpy() - z[f"flow{i}"][sl]).max() for i in range(3))
+    d_batch = (r1 - rec[sl]).abs().max().item()
+    print(f"[cfg0, B=1] d_crop={d_crop:.2e} d_flow={d_flow:.2e} vs the same frame in the batch of 4: {d_batch:.2e}")
+    assert d_crop <= TOL_REC and d_flow <= TOL_FLOW
+    assert 0 < d_batch <= 5e-4
+    Hh.run_engine(eng, inputs, DEV)                 # leave the engine as the other tests expect it (last_B = 4)
+
+
 def test_model_shell_matches_engine(cfg0):
     """The reference-surface Python object (TSNet / set_test_input / forward) drives the same path."""
     from wacv23_tsnet_amd.model import TSNet

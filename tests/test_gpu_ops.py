@@ -113,6 +113,20 @@ def test_conv_h2_tile_shapes_bitwise(lib):
     assert all(torch.equal(ys[0], y) for y in ys[1:])
 
 
+def test_conv_h2_two_k_groups(lib):
+    """single-frame launches (at most one 64-wide tile per CU) run the tile as eight waves: two K groups, each folding the chains of every other
+    slab, total = P0 + P1.  Both tile shapes give the same bits; against the one-group tiles the association differs (agreement to fp32
+    rounding, asserted as such); accuracy stays fp32-class.  The operator's default (tile = 0) is a one-group tile; the ENGINE picks the
+    two-group form when it runs a forward of one frame (test_gpu_forward.py::test_single_frame_forward)."""
+    import torch
+    assert oc.conv_h2_case(lib, DEV, 3, 32, 32, 512, 512, True, norm=True, tile_n=20064) < REL
+    assert oc.conv_h2_case(lib, DEV, 1, 32, 32, 512, 512, True, norm=True, tile_n=20032) < REL
+    assert oc.conv_h2_case(lib, DEV, 1, 64, 64, 512, 256, True, tile_n=20032) < REL
+    zs = [oc.conv_h2_case(lib, DEV, 1, 32, 32, 512, 512, True, norm=True, tile_n=t, return_output=True) for t in (64, 20032, 20064, 0)]
+    assert torch.equal(zs[1], zs[2]) and torch.equal(zs[0], zs[3]) and not torch.equal(zs[0], zs[1])
+    assert (zs[0] - zs[1]).abs().max().item() < 1e-5 * zs[0].abs().max().item()
+
+
 def test_conv_h2d_downsampling_layers(lib):
     """the encoder's three stride-2 layers at their real shapes on the patch kernel (conv_h2.hpp h2d), explicitly selected (kernel = 2): the
     four-wave / 64-column and the eight-wave / 128-column workgroups, which are bit-identical to each other.  Against the general kernel on

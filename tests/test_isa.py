@@ -1,0 +1,25 @@
+"""CPU tier: the hot patch-convolution kernels must not spill inside their main loop.  They sit exactly at their register limits (168 VGPRs =
+three workgroups per CU, 256 = two): a source change that looks neutral can make the allocator spill there -- this round an `& 3` on the wave
+index cost 11 scratch operations per two slabs and 3 % of the headline before the ISA was looked at.  tools/isa_check.py compiles the
+translation unit for gfx950 with -save-temps (hipcc cross-compiles without a GPU) and counts scratch operations in each kernel's loop."""
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
+def test_hot_kernels_do_not_spill_in_their_loops():
+    spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
+    ic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ic)
+    rows = {r["name"]: r for r in ic.analyse(ic.compile_asm(), "conv_h2_kernel")}
+    for name, limit in ic.HOT:
+        hit = [r for n, r in rows.items() if name in n]
+        assert hit, f"{name} is not in the product library"
+        r = hit[0]
+        assert r["scratch"] <= limit, f"{name}: {r['scratch']} scratch operations in the main loop (limit {limit}), {r['vgpr']} VGPRs"
+        assert r["vgpr"] <= (256 if ("4, 128" in name or ", 24>" in name) else 168), (name, r["vgpr"])

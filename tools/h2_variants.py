@@ -17,7 +17,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 def code(tile=0, general=False, abl=0, opt=0, xcd=None):
     """xcd: None = the launcher's choice, 0 = consecutive tiles per XCD, 1 / 2 / 4 / 8 = columns of the XCD grid over the N tiles"""
     gx = 0 if xcd is None else (1 if xcd == 0 else {1: 2, 2: 3, 4: 4, 8: 5}[xcd])
-    return tile | (4096 if general else 0) | (abl << 16) | (opt << 24) | (gx << 28)
+    return tile | (4096 if general else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | (gx << 28)
 
 
 def run(name, shape, variants, norms=(0, 1), iters=8):
@@ -41,6 +41,30 @@ def run(name, shape, variants, norms=(0, 1), iters=8):
 
 SEL = sys.argv[2] if len(sys.argv) > 2 else "all"
 RES = (12, 32, 32, 512, 512, 3, 1, 1, 1)
+if SEL == "kg":         # two K groups per tile (eight waves, one workgroup per CU) against the co-resident four-wave workgroups
+    for nm, n in (("res B=4 (12 images)", 12), ("res B=2 (6 images)", 6), ("res B=1 (3 images)", 3), ("res clip (1 image)", 1), ("res B=8 (24 images)", 24)):
+        run(nm, (n, 32, 32, 512, 512, 3, 1, 1, 1), [("4x64", code(64)), ("4x64 deep", code(64, opt=8)), ("4x64 deep kg2", code(64, opt=24)), ("4x32 deep kg2", code(32, opt=24)), ("4x64 kg2", code(64, opt=16))])
+    run("fuse_c2 (12 images)", (12, 32, 32, 1024, 1024, 3, 1, 1, 1), [("4x128", code(128)), ("4x64 deep kg2", code(64, opt=24)), ("4x128 kg2", code(128, opt=16))])
+    run("fuse_c2 (3 images)", (3, 32, 32, 1024, 1024, 3, 1, 1, 1), [("4x128", code(128)), ("4x64 deep kg2", code(64, opt=24)), ("4x128 kg2", code(128, opt=16))])
+    run("fuse_c1_src (12 images)", (12, 32, 32, 512, 1024, 3, 1, 1, 1), [("4x128", code(128)), ("4x64 deep kg2", code(64, opt=24))], norms=(0,))
+    run("dec_up0 (B=4)", (4, 64, 64, 512, 256, 3, 1, 1, 1), [("4x128", code(128)), ("4x64", code(64)), ("4x64 deep kg2", code(64, opt=24))], norms=(0,))
+    run("dec_up0 (B=1)", (1, 64, 64, 512, 256, 3, 1, 1, 1), [("4x64 deep", code(64, opt=8)), ("4x64 deep kg2", code(64, opt=24)), ("4x32 deep kg2", code(32, opt=24))], norms=(0,))
+    run("dec_up1 (B=4)", (4, 128, 128, 256, 128, 3, 1, 1, 1), [("4x128", code(128)), ("4x64", code(64)), ("4x64 deep kg2", code(64, opt=24))], norms=(0,))
+    run("dec_up1 (B=1)", (1, 128, 128, 256, 128, 3, 1, 1, 1), [("4x64 deep", code(64, opt=8)), ("4x64 deep kg2", code(64, opt=24))], norms=(0,))
+    sys.exit(0)
+if SEL == "small":      # one driving frame: launches of at most one workgroup per CU
+    for nm, n in (("res B=1 (3 images)", 3), ("res clip (1 image)", 1), ("res B=2 (6 images)", 6)):
+        run(nm, (n, 32, 32, 512, 512, 3, 1, 1, 1), [("4x32", code(32)), ("4x64", code(64)), ("4x32 deep", code(32, opt=8)), ("4x64 deep", code(64, opt=8)), ("2x128", code(2128))])
+    run("fuse_c2 B=1 (3 images)", (3, 32, 32, 1024, 1024, 3, 1, 1, 1), [("4x128", code(128)), ("4x64", code(64)), ("4x64 deep", code(64, opt=8)), ("4x32 deep", code(32, opt=8))])
+    run("fuse_c1_tar B=1 (1 image)", (1, 32, 32, 512, 1024, 3, 1, 1, 1), [("4x128", code(128)), ("4x64", code(64)), ("4x64 deep", code(64, opt=8)), ("4x32 deep", code(32, opt=8))], norms=(0,))
+    run("dec_up0 B=1", (1, 64, 64, 512, 256, 3, 1, 1, 1), [("4x32", code(32)), ("4x64", code(64)), ("4x32 deep", code(32, opt=8)), ("4x64 deep", code(64, opt=8))], norms=(0,))
+    run("dec_up1 B=1", (1, 128, 128, 256, 128, 3, 1, 1, 1), [("4x64", code(64)), ("4x32 deep", code(32, opt=8)), ("4x64 deep", code(64, opt=8))], norms=(0,))
+    run("dec_up2 B=1", (1, 256, 256, 128, 64, 3, 1, 1, 1), [("4x64", code(64)), ("4x32", code(32)), ("4x64 deep", code(64, opt=8))], norms=(0,))
+    for nm, shp in (("down1 B=1 src", (3, 256, 256, 64, 128, 3, 2, 1, 0)), ("down2 B=1 src", (3, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 B=1 src", (3, 64, 64, 256, 512, 3, 2, 1, 0)),
+                    ("down2 1 image", (1, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 1 image", (1, 64, 64, 256, 512, 3, 2, 1, 0))):
+        run(nm, shp, [("h2d 4 waves x 64", code(64)), ("h2d 8 waves x 128", code(128)), ("general 64", code(64, general=True)), ("general 128", code(128, general=True))], norms=(1,))
+    run("1x1 (1024->512) 1 image", (1, 32, 32, 1024, 512, 1, 1, 0, 0), [("general 64", code(64))], norms=(0,))
+    sys.exit(0)
 FUSE = (12, 32, 32, 1024, 1024, 3, 1, 1, 1)
 if SEL in ("all", "xcd"):
     run("res: XCD grids (4x64)", RES, [("linear", code(64, xcd=0))] + [(f"grid x{g}", code(64, xcd=g)) for g in (1, 2, 4, 8)])

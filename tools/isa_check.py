@@ -1,0 +1,87 @@
+"""Compile the patch-convolution kernels for gfx950 with -save-temps and report, per kernel, the VGPR count and -- inside the main loop
+(the backward branch spanning the most MFMAs) -- the MFMA / total instruction counts, scratch (spill) operations and how the compiler
+interleaved MFMAs with the rest.  The 168-VGPR (three workgroups per CU) and 256-VGPR tiles sit at their register limit: a harmless-looking
+source change can push the allocator into spilling inside the loop (-3 % of the headline for 11 scratch ops), and only the ISA shows it.
+    python tools/isa_check.py [substring of the demangled kernel name] [--tools]
+Exit status 1 if a kernel on the forward's hot path spills in its loop (tests/test_isa.py)."""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# (kernel-name substring, scratch operations tolerated in the loop): the ResnetBlock / decoder / FuseNet tiles of the headline forward
+HOT = [("conv_h2_kernel<4, 64, 2, 2, 3, true, 0, 0>", 0), ("conv_h2_kernel<4, 64, 2, 2, 3, false, 0, 0>", 0),
+       ("conv_h2_kernel<4, 128, 2, 2, 3, false, 0, 0>", 0), ("conv_h2_kernel<4, 128, 2, 2, 3, true, 0, 0>", 4),
+       ("conv_h2_kernel<4, 64, 2, 2, 1, true, 0, 0>", 0), ("conv_h2_kernel<4, 64, 2, 2, 1, false, 0, 0>", 0),
+       ("conv_h2_kernel<4, 64, 2, 2, 3, true, 0, 24>", 0), ("conv_h2_kernel<4, 32, 4, 1, 3, true, 0, 24>", 0)]
+
+
+def loops_of(body):
+    L = body.split("\n")
+    labels = {m.group(1): k for k, l in enumerate(L) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    out = []
+    for k, l in enumerate(L):
+        m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < k:
+            b = L[labels[m.group(1)]:k + 1]
+            out.append((sum("v_mfma" in x for x in b), b))
+    return sorted(out, key=lambda t: -t[0])
+
+
+def analyse(asm_path, pattern=""):
+    s = open(asm_path).read()
+    rows = []
+    for m in re.finditer(r"^(_ZN5tsnet\w+):\s*;", s, re.M):
+        nm = m.group(1)
+        d = subprocess.run(["c++filt", nm], capture_output=True, text=True).stdout.strip()
+        d = d.replace("tsnet::", "").replace("(ConvArgs)", "").replace("(tsnet::ConvArgs)", "").replace("void ", "")
+        if pattern not in d:
+            continue
+        body = s[m.start():s.index(".Lfunc_end", m.start())]
+        lp = loops_of(body)
+        if not lp or not lp[0][0]:
+            continue
+        n, b = lp[0]
+        ins = [x.split()[0] for x in b if x.strip() and not x.strip().startswith((";", "."))]
+        runs, cur, cnt = [], None, 0
+        for x in ins:
+            t = "M" if x.startswith("v_mfma") else "o"
+            if t == cur:
+                cnt += 1
+            else:
+                if cur:
+                    runs.append((cur, cnt))
+                cur, cnt = t, 1
+        runs.append((cur, cnt))
+        mr = [c for t, c in runs if t == "M"]
+        orr = [c for t, c in runs if t == "o"] or [0]
+        vg = re.search(re.escape(nm) + r"\.num_vgpr, (\d+)", s)
+        rows.append(dict(name=d, vgpr=int(vg.group(1)) if vg else -1, mfma=n, total=len(ins), scratch=sum(x.startswith("scratch_") for x in ins),
+                         mfma_run_max=max(mr), other_run_max=max(orr)))
+    return rows
+
+
+def compile_asm(tools=False):
+    tmp = tempfile.mkdtemp(prefix="tsnet_isa_")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps", "-I" + os.path.join(ROOT, "include")]
+    if tools:
+        cmd.append("-DTSNET_TOOLS")
+    cmd += ["-c", os.path.join(ROOT, "wacv23_tsnet_amd", "csrc", "conv_h2_launch.cpp"), "-o", os.path.join(tmp, "x.o")]
+    subprocess.run(cmd, cwd=tmp, check=True, capture_output=True)
+    return os.path.join(tmp, "conv_h2_launch-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rows = analyse(compile_asm("--tools" in sys.argv), args[0] if args else "")
+    bad = 0
+    for r in sorted(rows, key=lambda r: r["name"]):
+        lim = [l for n, l in HOT if n in r["name"]]
+        flag = ""
+        if lim and r["scratch"] > lim[0]:
+            flag = "   <-- spills in the loop of a hot kernel"; bad += 1
+        print(f"{r['name']:62s} vgpr={r['vgpr']:3d} loop: mfma={r['mfma']:3d} instr={r['total']:4d} scratch={r['scratch']:2d} "
+              f"longest mfma run={r['mfma_run_max']:2d} longest other run={r['other_run_max']:3d}{flag}")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

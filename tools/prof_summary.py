@@ -14,12 +14,12 @@ tot = sum(v[1] for v in agg.values())
 print("%-36s %8s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-36s %8d %12.1f %10.2f %6.2f" % (k, v[0], v[1] / 1e3, v[1] / 1e3 / v[0], 100 * v[1] / tot))
-# last forward: find the last pack_input_kernel(img) (grid largest) -> end
-idx = [i for i, r in enumerate(rows) if "pack_input" in r[0]]
+# last forward = the dispatches after the second-to-last head kernel up to the last one (every forward ends with the head)
+ALL = "--all" in sys.argv
+idx = [i for i, r in enumerate(rows) if "head_conv" in r[0] and "pack" not in r[0]]
 if len(idx) >= 2:
-    start = idx[-2]
-    fw = rows[start:]
+    fw = rows[idx[-2] + 1: idx[-1] + 1]
     print("\nlast forward: %d dispatches, span %.3f ms, busy %.3f ms" % (len(fw), (fw[-1][2] - fw[0][1]) / 1e6, sum(r[3] for r in fw) / 1e6))
     for r in fw:
-        if "conv_" in r[0] and "pack" not in r[0]:
-            print("  %-34s grid=%6d wg=%d lds=%d vgpr=%d agpr=%d  %9.1f us" % (short(r[0]), r[4] // r[5], r[5], r[6], r[7], r[8], r[3] / 1e3))
+        if ALL or ("conv_" in r[0] and "pack" not in r[0]):
+            print("  t=%8.1f  %-34s grid=%6d wg=%d lds=%d vgpr=%d agpr=%d  %9.1f us" % ((r[1] - fw[0][1]) / 1e3, short(r[0]), r[4] // r[5], r[5], r[6], r[7], r[8], r[3] / 1e3))

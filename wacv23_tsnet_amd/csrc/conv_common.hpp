@@ -57,6 +57,9 @@ typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
         asm("s_nop 0\n\tv_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw) : "v"(b), "v"(hw));           \
     } while (0)
 #endif
+#ifndef TSNET_FAST_EXP
+#define TSNET_FAST_EXP(x) __expf(x)
+#endif
 #ifndef TSNET_SETPRIO
 #define TSNET_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
@@ -202,7 +205,7 @@ __device__ __forceinline__ void transform_octet(const F4 (&sx)[2], const float* 
 // m_of(l) maps the local row l of the tile to the output position m (or -1: a row past the end of the image).
 template <int BN, int WARPS_M, int WARPS_N, int MT, int NTL, typename MOf>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[MT][NTL], unsigned char* smem_raw, int tid, int wave, int n0,
-                                              size_t stat_tile, MOf m_of) {
+                                              size_t stat_tile, MOf m_of, const bool active = true) {
     constexpr int WM = MT * 32, WN = NTL * 32;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / WARPS_N) * WM, wn0 = (wave % WARPS_N) * WN;
@@ -221,7 +224,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m_of(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
-                const bool mok = m >= 0;
+                const bool mok = active && m >= 0;
                 float v = tot[i][j][r] + bv;
                 if (a.addend && nok && mok) {
                     const int img = m / hw;
@@ -242,7 +245,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
         for (int j = 0; j < NTL; ++j) {
             const double s2 = csum[j] + __shfl_xor(csum[j], 32);
             const double q2 = csq[j] + __shfl_xor(csq[j], 32);
-            if (lh == 0) {
+            if (lh == 0 && active) {
                 double* o = red + ((size_t)(wave / WARPS_N) * BN + wn0 + j * 32 + li) * 2;
                 o[0] = s2; o[1] = q2;
             }

@@ -13,6 +13,9 @@
 //     256 consecutive bytes -- conflict-free without a swizzle -- and one address register serves all (row, tap) combinations;
 //   * weight fragments (fragment order, contiguous per wave: pack_weights_kernel) go straight into registers two steps ahead (three
 //     register sets); A fragments one step ahead (two sets; the slab loop is unrolled by two because nine taps flip the parity);
+//   * DEEP (OPT bit 3; launches of at most one workgroup per CU -- a single driving frame): nothing else on the CU hides a load's
+//     latency, so weight fragments are fetched EIGHT steps ahead (nine register sets, one per tap) and both staging rounds of the next
+//     slab are in flight for five / six steps; same K order, chains and fold points, hence the same bits;
 //   * one __syncthreads per slab; every load is compiler-visible (the only inline asm is the three-instruction split).
 // K order is slab-major (slab, tap); chains = taps 0..3 and 4..8 of a slab, folded into the running total.  Every tile shape runs the
 // same chains per output element: bit-identical convolution results (tested).
@@ -27,8 +30,8 @@ namespace tsnet {
 //   4 x 128 (2 x 2, 64 x 64)   half the LDS / L1 bytes per MFMA, two workgroups per CU (FuseNet, decoder)
 //   4 x 32  (4 x 1, 32 x 32)   launches with few tiles (one driving frame)
 //   2 x 128 (1 x 4, 64 x 32)   the patch is staged once per 128 instead of 64 output channels (0.67 x the staging work per MFMA)
-// OPT (tools build: tools/h2_variants.py): bit 0 legacy staging arithmetic (select / scalar converts; for the A/B), bit 1 rotating wave
-// priority, bit 2 interleave hints.  HABL (tools/x3_ablate.py h2; non-zero computes garbage): bit0 no patch staging in the loop, bit1
+// OPT: bit 3 = DEEP prefetch (product).  Tools build only (tools/h2_variants.py): bit 0 legacy staging arithmetic (select / scalar
+// converts; for the A/B), bit 1 rotating wave priority.  HABL (tools/x3_ablate.py h2; non-zero computes garbage): bit0 no patch staging in the loop, bit1
 // weight fragments loaded once, bit2 A fragments read once, bit3 no fold, bit4 no slab barrier.
 template <int PR, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int HABL = 0, int OPT = 0>
 __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_raw, const int tile_m, const int n0) {
@@ -37,6 +40,9 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     static_assert(NW == 4, "four waves: patch blocks are dealt w, w+4");
     static_assert(NPROD == 1 || NPROD == 3 || NPROD == 4, "one (bf16 operands), three or four products");
     constexpr int NPL = NPROD == 1 ? 1 : 2;                          // operand planes
+    constexpr bool DEEP = (OPT & 8) != 0;
+    constexpr int BD = DEEP ? 9 : 3;                                 // weight register sets: fragments are fetched BD - 1 steps ahead
+    constexpr int KG = (OPT & 16) ? 2 : 1;                           // K groups: 4 KG waves, group g runs the slabs g, g + KG, ... of the tile
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 32, NTL = WN / 32;
     static_assert(WARPS_M * MT == PR, "a wave covers MT whole patch rows");
@@ -46,11 +52,17 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     constexpr int REGION = PBLK * 512;                               // one octet region: 32 PBLK slots x 16 B
     constexpr int PLANE_P = 2 * REGION, PATCH_BYTES = NPL * PLANE_P;
     constexpr int OFF_SINK = 2 * 2 * PLANE_P;                        // 2 KiB sink for a wave whose second pixel block does not exist (branch-free staging)
-    constexpr int OFF_TAB = OFF_SINK + 2048;                         // (alpha*s, beta*s) table of the image: 2 x Cin floats (fixed offset in both modes)
+    constexpr int GROUP_BYTES = OFF_SINK + 2048;                     // stages + sink of one K group
+    constexpr int OFF_TAB = KG * GROUP_BYTES;                        // (alpha*s, beta*s) table of the image: 2 x Cin floats (fixed offset in both modes)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = TSNET_UNIFORM(tid >> 6);
+    const int wave_all = TSNET_UNIFORM(tid >> 6);
+    const int kg = KG == 1 ? 0 : wave_all >> 2;                      // this wave's K group
+    // ... and its place in the group's 2 x 2 / 4 x 1 / 1 x 4 wave grid.  (One group: no mask -- "& 3" hides from the compiler that the
+    // readfirstlane value IS the wave index and costs the 168-VGPR tiles 11 scratch operations per two slabs: tools/isa_check.py.)
+    const int wave = KG == 1 ? wave_all : (wave_all & 3);
+    unsigned char* const gbase = smem_raw + kg * GROUP_BYTES;        // the group's own patch stages
     const int wrow = wave / WARPS_N;
     const int wn0 = (wave % WARPS_N) * WN;
     const int li = lane & 31, lh = lane >> 5;
@@ -93,22 +105,24 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     }
     float* tab = reinterpret_cast<float*>(smem_raw + OFF_TAB);       // [Cin] alpha*s, then [Cin] beta*s
     if (AFFINE) {
-        for (int c = tid; c < a.Cin; c += 256) {
+        for (int c = tid; c < a.Cin; c += 256 * KG) {
             tab[c] = a.in_alpha[(size_t)img * a.Cin + c] * in_scale;
             tab[a.Cin + c] = a.in_beta[(size_t)img * a.Cin + c] * in_scale;
         }
         __syncthreads();
     }
     const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();    // branch-free ReLU switch
-    F4 sx[2];                                                        // staging registers: one round of x
+    // slab indices below are LOCAL to the K group (stage parity, loop counter); slab_of() is the channel slab they stand for
+    auto slab_of = [&](int lc) __attribute__((always_inline)) { return lc * KG + kg; };
+    F4 sx[2][2];                                                     // staging registers [round][half octet] (DEEP: both rounds live at once)
     auto stage_load_x = [&](int cn, int r) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) sx[q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(cn * 64 + q * 16));
+        for (int q = 0; q < 2; ++q) sx[r][q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(slab_of(cn) * 64 + q * 16));
     };
     auto stage_store = [&](int cn, int r) __attribute__((always_inline)) {
         const int b = wave + 4 * r;
         F4 t[2];
-        const float* ta = tab + (cn < ncc ? cn * 16 : 0) + oct * 8;         // past the last slab: any valid entry (result unused)
+        const float* ta = tab + (slab_of(cn) < ncc ? slab_of(cn) * 16 : 0) + oct * 8;   // past the last slab: any valid entry (result unused)
         if (OPT & 1) {
             if (AFFINE) {
 #pragma unroll
@@ -116,7 +130,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
                     const F4 al = *reinterpret_cast<const F4*>(ta + q * 4), be = *reinterpret_cast<const F4*>(ta + a.Cin + q * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = __builtin_fmaf(sx[q].v[e], al.v[e], be.v[e]);
+                        float v = __builtin_fmaf(sx[r][q].v[e], al.v[e], be.v[e]);
                         v = v > relu_floor ? v : relu_floor;
                         t[q].v[e] = v * vM[r];
                     }
@@ -126,15 +140,15 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = sx[q].v[e] * in_scale;
+                        float v = sx[r][q].v[e] * in_scale;
                         t[q].v[e] = v > relu_floor ? v : relu_floor;
                     }
             }
         } else {
-            transform_octet<AFFINE>(sx, ta, a.Cin, in_scale, relu_floor, vM[r], t);
+            transform_octet<AFFINE>(sx[r], ta, a.Cin, in_scale, relu_floor, vM[r], t);
         }
         // a block past the patch does not exist: its wave writes into the sink (wave-uniform select, no branch)
-        unsigned char* dst = smem_raw + (b < PBLK ? (cn & 1) * PATCH_BYTES + oct * REGION + b * 512 : OFF_SINK + oct * 512) + (lane & 31) * 16;
+        unsigned char* dst = gbase + (b < PBLK ? (cn & 1) * PATCH_BYTES + oct * REGION + b * 512 : OFF_SINK + oct * 512) + (lane & 31) * 16;
         F4 Hh, Ll;
         if (NPROD == 1) {
             bf16_octet(t[0], t[1], Hh);
@@ -159,15 +173,15 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
 
     // ---- fragments.  Weights: lane (li, lh) takes the 16 bytes of column wn0 + j*32 + li, logical octet lh
     const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
-    F4 af[2][NPL][MT], bf[3][NPL][NTL];                              // [register set][plane][tile]
+    F4 af[2][NPL][MT], bf[BD][NPL][NTL];                             // [register set][plane][tile]
     auto load_b = [&](int set, int cc, int t) __attribute__((always_inline)) {     // past the end of K the descriptor returns zeros
-        const int kc = t * ncc + cc;
+        const int kc = t * ncc + slab_of(cc);
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0 + j * 32) * 32));
     };
-    const unsigned char* abase = smem_raw + lh * REGION + (wrow * MT * PC + li) * 16;
+    const unsigned char* abase = gbase + lh * REGION + (wrow * MT * PC + li) * 16;
     auto load_a = [&](int set, int cc, int t) __attribute__((always_inline)) {
         const int ky = t / 3, kx = t - ky * 3;
         const unsigned char* pbase = abase + (cc & 1) * PATCH_BYTES;
@@ -199,17 +213,18 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
                 else acc[i][j] = TSNET_MFMA_F16(af[sa][pa][i], bf[sb][pb][j], c);
             }
     };
-    // step (cc, t): A(cc,t) in set SA, B(cc,t) in set t%3; issues A(cc,t+1) and B of two steps ahead first
+    // step (cc, t): A(cc,t) in set SA, B(cc,t) in set t % BD; issues A(cc,t+1) and B of BD - 1 steps ahead first
     auto step = [&](int cc, int t, int SA) __attribute__((always_inline)) {
         const bool fresh = t == 0 || t == 4;                         // chains: taps 0..3 and 4..8 of the slab
-        const int t2 = (t + 2) % 9;
-        if (!(HABL & 2)) load_b(t2 % 3, cc + (t + 2 >= 9 ? 1 : 0), t2);
+        const int t2 = (t + BD - 1) % 9;
+        if (!(HABL & 2)) load_b(t2 % BD, cc + (t + BD - 1 >= 9 ? 1 : 0), t2);
         if (t < 8 && !(HABL & 4)) load_a(SA ^ 1, cc, t + 1);
-        // staging of slab cc+1: round 0 fetched at tap 0 and written at tap 2, round 1 fetched at tap 3 and written at tap 5
-        // (past the last slab the loads run into the next pixel's channels or return zeros: written to the idle stage, never read)
+        // staging of slab cc+1: round 0 fetched at tap 0 and written at tap 2, round 1 fetched at tap 3 and written at tap 5 (DEEP: fetched
+        // at taps 0 and 1, written at taps 5 and 7).  Past the last slab the loads run into the next pixel's channels or return zeros:
+        // written to the idle stage, never read.
         if (t == 0 && !(HABL & 1)) stage_load_x(cc + 1, 0);
-        if (t == 3 && !(HABL & 1)) stage_load_x(cc + 1, 1);
-        const int SB = t % 3;
+        if (t == (DEEP ? 1 : 3) && !(HABL & 1)) stage_load_x(cc + 1, 1);
+        const int SB = t % BD;
         if (NPROD == 1) {
             product(SA, SB, 0, 0, fresh);                            // bf16 * bf16
         } else {
@@ -218,8 +233,8 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
             product(SA, SB, 0, NPL - 1, false);                      // hi * lo
             product(SA, SB, 0, 0, false);                            // hi * hi
         }
-        if (t == 2 && !(HABL & 1)) stage_store(cc + 1, 0);
-        if (t == 5 && !(HABL & 1)) stage_store(cc + 1, 1);
+        if (t == (DEEP ? 5 : 2) && !(HABL & 1)) stage_store(cc + 1, 0);
+        if (t == (DEEP ? 7 : 5) && !(HABL & 1)) stage_store(cc + 1, 1);
         if ((t == 3 || t == 8) && !(HABL & 8)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -240,17 +255,41 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
         step(cc, 6, S0); step(cc, 7, S0 ^ 1); step(cc, 8, S0);
     };
 
-    // prologue: patch of slab 0, weight fragments of steps (0,0) and (0,1)
-    stage_load_x(0, 0); stage_store(0, 0);
-    stage_load_x(0, 1); stage_store(0, 1);
-    load_b(0, 0, 0);
-    load_b(1, 0, 1);
+    // prologue: patch of slab 0, weight fragments of the first BD - 1 steps
+    stage_load_x(0, 0); stage_load_x(0, 1);
+#pragma unroll
+    for (int i = 0; i < BD - 1; ++i) load_b(i, 0, i);
+    stage_store(0, 0); stage_store(0, 1);
     if (HABL & 2) load_b(2, 0, 2);
     if (HABL & 4) { __syncthreads(); load_a(0, 0, 0); load_a(1, 0, 1); }
+    const int nloc = ncc / KG;                                       // the launcher passes KG = 2 only for an even slab count
     int cc = 0;
-    for (; cc + 2 <= ncc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
-    if (cc < ncc) slab(cc, 0);
+    for (; cc + 2 <= nloc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
+    if (cc < nloc) slab(cc, 0);
     if (OPT & 2) TSNET_SETPRIO(0);
+    if (KG == 2) {
+        // total = P0 + P1 (the groups' partial totals, each a sequential fold of its own chains): group 1 hands its registers over through
+        // LDS in lane order (conflict-free), group 0 adds them and runs the epilogue; group 1 only keeps the barriers company
+        __syncthreads();                                             // every stage has been read
+        float* fold = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (MT * NTL * 16 * 64) + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) fold[((i * NTL + j) * 16 + r) * 64] = tot[i][j][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[i][j][r] += fold[((i * NTL + j) * 16 + r) * 64];
+        }
+    }
 
     const float unscale = a.w_unscale ? in_unscale * a.w_unscale[0] : in_unscale;
 #pragma unroll
@@ -261,14 +300,14 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
             for (int r = 0; r < 16; ++r) tot[i][j][r] *= unscale;    // exact: power of two
     const int m_img = img * a.Ho * a.Wo;
     conv_epilogue<BN, WARPS_M, WARPS_N, MT, NTL>(a, tot, smem_raw, tid, wave, n0, (size_t)img * tper + tin,
-                                                 [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
+                                                 [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); }, kg == 0);
 }
 
 // LDS bytes of an h2 tile: two stages x two planes x two octet regions + the sink + the transform table (two-plane offsets in every mode)
-constexpr int h2_lds_bytes(int PR, int Cin) { return 2 * 2 * 2 * (((PR + 2) * (kPatchCols + 2) + 31) / 32) * 512 + 2048 + 2 * Cin * 4; }
+constexpr int h2_lds_bytes(int PR, int Cin, int KG = 1) { return KG * (2 * 2 * 2 * (((PR + 2) * (kPatchCols + 2) + 31) / 32) * 512 + 2048) + 2 * Cin * 4; }
 
 template <int PR, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int HABL = 0, int OPT = 0>
-__global__ __launch_bounds__(256, (BN / WARPS_N) * (PR / WARPS_M) <= 64 ? 3 : 2)   // wave tile 64 x 32: three workgroups per CU; 64 x 64: two
+__global__ __launch_bounds__((OPT & 16) ? 512 : 256, (OPT & 16) ? 1 : ((BN / WARPS_N) * (PR / WARPS_M) * ((OPT & 8) ? 2 : 1) <= 64 ? 3 : 2))   // wave tile 64 x 32: three workgroups per CU; 64 x 64 or DEEP 64 x 32: two; two K groups: one
 void conv_h2_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     int tile_m, tile_n;

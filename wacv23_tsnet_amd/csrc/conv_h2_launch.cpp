@@ -28,13 +28,15 @@ namespace {
 
 template <int PR, int BN, int WM, int WN, int NPROD, int HABL = 0, int OPT = 0>
 void go_h2(const ConvArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)h2_lds_bytes(PR, a.Cin);
+    constexpr int KG = (OPT & 16) ? 2 : 1;
+    if ((a.Cin >> 4) % KG) throw std::invalid_argument("conv(h2): two K groups need an even number of 16-channel slabs");
+    const size_t lds = (size_t)h2_lds_bytes(PR, a.Cin, KG);
     if (a.in_alpha) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2_kernel<PR, BN, WM, WN, NPROD, true, HABL, OPT>), lds);
-        hipLaunchKernelGGL((conv_h2_kernel<PR, BN, WM, WN, NPROD, true, HABL, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((conv_h2_kernel<PR, BN, WM, WN, NPROD, true, HABL, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(256 * KG), lds, s, a);
     } else {
         ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2_kernel<PR, BN, WM, WN, NPROD, false, HABL, OPT>), lds);
-        hipLaunchKernelGGL((conv_h2_kernel<PR, BN, WM, WN, NPROD, false, HABL, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((conv_h2_kernel<PR, BN, WM, WN, NPROD, false, HABL, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(256 * KG), lds, s, a);
     }
 }
 
@@ -62,12 +64,20 @@ void go_h2d(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int opt, hipStream_t s) {
+    if (!abl && opt == 24) {           // single-frame launches: deep prefetch + two K groups, eight waves (conv_h2.hpp)
+        if (nprod != 1 && nprod != 3) throw std::invalid_argument("conv(h2): the two-group tiles run 1 or 3 products");
+        if (pr == 4 && bn == 32) { if (nprod == 3) go_h2<4, 32, 4, 1, 3, 0, 24>(a, s); else go_h2<4, 32, 4, 1, 1, 0, 24>(a, s); }
+        else if (pr == 4 && bn == 64) { if (nprod == 3) go_h2<4, 64, 2, 2, 3, 0, 24>(a, s); else go_h2<4, 64, 2, 2, 1, 0, 24>(a, s); }
+        else throw std::invalid_argument("conv(h2): the two-group tiles are 4x32 and 4x64");
+        return;
+    }
     if (abl || opt) {
 #ifdef TSNET_TOOLS
         // experiment / ablation instantiations (tools/h2_variants.py, tools/x3_ablate.py): 3 products, raw or transformed input
         if (nprod != 3) throw std::invalid_argument("conv(h2): experiment variants are built for three products");
 #define TSNET_H2_VAR(PR_, BN_, WM_, WN_, A_, O_) if (pr == PR_ && bn == BN_ && abl == A_ && opt == O_) { go_h2<PR_, BN_, WM_, WN_, 3, A_, O_>(a, s); return; }
-        TSNET_H2_VAR(4, 64, 2, 2, 0, 1) TSNET_H2_VAR(4, 64, 2, 2, 0, 2) TSNET_H2_VAR(4, 64, 2, 2, 0, 3)
+        TSNET_H2_VAR(4, 64, 2, 2, 0, 1) TSNET_H2_VAR(4, 64, 2, 2, 0, 2) TSNET_H2_VAR(4, 64, 2, 2, 0, 3) TSNET_H2_VAR(4, 64, 2, 2, 0, 16) TSNET_H2_VAR(4, 128, 2, 2, 0, 16)
+        TSNET_H2_VAR(4, 64, 2, 2, 0, 8) TSNET_H2_VAR(4, 32, 4, 1, 0, 8)
         TSNET_H2_VAR(4, 128, 2, 2, 0, 1) TSNET_H2_VAR(2, 128, 1, 4, 0, 2)
         TSNET_H2_VAR(4, 64, 2, 2, 1, 0) TSNET_H2_VAR(4, 64, 2, 2, 2, 0) TSNET_H2_VAR(4, 64, 2, 2, 4, 0) TSNET_H2_VAR(4, 64, 2, 2, 7, 0)
         TSNET_H2_VAR(4, 64, 2, 2, 8, 0) TSNET_H2_VAR(4, 64, 2, 2, 16, 0) TSNET_H2_VAR(4, 64, 2, 2, 15, 0) TSNET_H2_VAR(4, 64, 2, 2, 31, 0)

@@ -46,7 +46,7 @@ namespace {
 
 thread_local std::string g_op_error;
 int64_t g_launch_counters[4] = {0, 0, 0, 0};   // conv launches: [0] patch kernels (conv_h2.hpp), [1] general kernel (conv_h2r.hpp), [2] RGB head;
-                                               // [3] = tile code (rows * 1000 + width) of the last ResnetBlock-class convolution launch
+                                               // [3] = tile code (rows * 1000 + width, + 20000 two K groups) of the last ResnetBlock-class convolution launch
 std::string g_create_error;
 
 #define HIP_TRY(expr)                                                                               \
@@ -175,8 +175,10 @@ struct ConvCall {
     unsigned* amax_out = nullptr;   // publish max |y| per image (operand scale of a consumer without an a-priori bound)
     int nprod = 3;              // products per k-group: 3 (4 adds lo*lo), or 1 = bf16 operands
     int kernel = 0;             // 0 = the layer's own kernel class, 1 = force the general kernel, 2 = require a patch kernel (op tests)
-    int tile = 0;               // 0 = heuristic; else rows * 1000 + width of the patch tile (32, 64, 128 = 4 rows; 2128 = 2 x 128), or 64 / 128 for the others
+    int tile = 0;               // 0 = heuristic; else rows * 1000 + width of the patch tile (32, 64, 128 = 4 rows; 2128 = 2 x 128; + 20000 = its
+                                // two-K-group form, 4 x 32 and 4 x 64 only), or 64 / 128 for the others
     int abl = 0, opt = 0;       // tools build: ablation / experiment masks of h2_tile
+    bool single_frame = false;  // the forward runs ONE frame (B = 1): launches of at most a tile per CU take the two-K-group tiles
     int xcd_gn = -1;            // -1 = the launcher's choice; 0 = consecutive tiles per XCD; 1, 2, 4, 8 = XCD grid columns over the N tiles (tile_of_block)
     int tclass = TSNET_T_CONV;
 };
@@ -236,7 +238,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         throw ArgError("conv: tensor too large for 32-bit buffer offsets");
     if ((size_t)2 * g.Cin * 4 > 32 * 1024) throw ArgError("conv: too many input channels for the transform table");
     const int hw = g.Ho * g.Wo;
-    const int cls = c.kernel == 1 ? K_GENERAL : conv_class(L, c.H, c.W, c.x2 != nullptr, c.alpha != nullptr, c.tile >= 1000 ? c.tile / 1000 : kPatchRows, c.kernel == 2);
+    const int cls = c.kernel == 1 ? K_GENERAL : conv_class(L, c.H, c.W, c.x2 != nullptr, c.alpha != nullptr, c.tile % 10000 >= 1000 ? c.tile % 10000 / 1000 : kPatchRows, c.kernel == 2);
     if (c.kernel == 2 && cls == K_GENERAL) throw ArgError("conv: this layer / frame size has no patch kernel");
     g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f;
     TimeScope ts(ctx, c.tclass);
@@ -256,16 +258,26 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
     };
     try {
         if (cls == K_H2) {
-            int pr = 4, bn = 0;
-            if (c.tile) { pr = c.tile >= 1000 ? c.tile / 1000 : 4; bn = c.tile % 1000; }
+            int pr = 4, bn = 0, opt = c.opt;
+            if (c.tile) {
+                const int tc = c.tile % 10000, mode = c.tile / 10000;          // mode 2: deep prefetch + two K groups; 1 / 3: one of the two (tools build)
+                pr = tc >= 1000 ? tc / 1000 : 4; bn = tc % 1000;
+                opt |= mode == 1 ? 8 : (mode == 2 ? 24 : (mode == 3 ? 16 : 0));
+            }
             if (bn == 0) {
                 // 128-wide tiles (wave tile 64 x 64) move half the LDS / L1 bytes per MFMA: measured 1.07-1.15x per unit area without the
                 // fused transform, 1.03x with it; the 384-tile ResnetBlock layers at batch 4 are the case where 768 64-wide tiles = exactly
                 // three per CU win.  Small M (one driving frame: the decoder's ResnetBlocks are 64 tiles of 128 x 64 on 256 CUs): 32-wide
                 // tiles double the number of workgroups; each stages the same patch but runs half the MFMA chain.
-                const long tm = (long)c.N * (hw / 128);
+                const long tm = (long)c.N * (hw / 128), t64 = tm * ((g.Cout + 63) / 64);
                 bn = wide_pays(tm, c.alpha ? 1.03 : 1.10) ? 128 : 64;
-                if (bn == 64 && tm * ((g.Cout + 63) / 64) <= 192 && c.nprod != 4) bn = 32;
+                // A forward of ONE frame (B = 1), launches of at most one 64-wide tile per CU: no co-resident workgroup hides a load.  The
+                // tile then runs as eight waves -- two K groups of four, each folding the chains of every other slab, weights eight steps
+                // ahead -- and, up to 128 tiles, in its 32-wide shape, which doubles the workgroups: 67 -> 54 us on the 192-tile ResnetBlock
+                // layers, 60 -> 38 us on the decoder's ResnetBlocks of one frame (profiles/round3_small_batch.txt).  total = P0 + P1 is
+                // another association of the same chains: results agree with the one-group tiles to fp32 rounding, not bit for bit -- a
+                // frame run alone and the same frame inside a batch differ in the last bits; any two batches of >= 2 frames do not.
+                if (c.single_frame && t64 <= 256 && c.nprod != 4 && !c.abl && !opt && (L.cin_pad >> 4) % 2 == 0) { opt = 24; bn = t64 <= 128 ? 32 : 64; }
             }
             if ((pr != 2 && pr != 4) || g.Ho % pr) throw ArgError("conv(h2): the output height must be a multiple of the tile's rows (2 or 4)");
             if (g.Npad % bn) throw ArgError("conv(h2): the tile width must divide the padded output width");
@@ -280,15 +292,18 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
                 }
                 g.xcd_gn = gn;
             }
-            launch_conv_h2(g, pr, bn, c.nprod, c.abl, c.opt, ctx.stream);
+            launch_conv_h2(g, pr, bn, c.nprod, c.abl, opt, ctx.stream);
             ++g_launch_counters[0];
-            if (c.tclass == TSNET_T_CONV_RES) g_launch_counters[3] = pr * 1000 + bn;
+            if (c.tclass == TSNET_T_CONV_RES) g_launch_counters[3] = pr * 1000 + bn + ((opt & 16) ? 20000 : 0);
         } else if (cls == K_H2S) {
             set_tiles(128, 64);
             launch_conv_h2s(g, c.nprod, ctx.stream);
             ++g_launch_counters[0];
         } else if (cls == K_H2D) {
-            int bn = c.tile ? c.tile : ((g.Npad % 128 == 0 && g.Cout > 64) ? 128 : 64);
+            // eight waves x 128 columns from 128 such tiles on; below that the four-wave x 64 shape has twice the workgroups (one frame:
+            // 24 vs 32 us on 128 -> 256, 47 vs 58 us on 256 -> 512; bit-identical shapes)
+            const long t128 = (long)c.N * (hw / 128) * ((g.Cout + 127) / 128);
+            int bn = c.tile ? c.tile : ((g.Npad % 128 == 0 && g.Cout > 64 && t128 >= 128) ? 128 : 64);
             if (g.Npad % bn) throw ArgError("conv(h2d): the tile width must divide the padded output width");
             set_tiles(128, bn);
             launch_conv_h2d(g, bn, c.nprod, ctx.stream);
@@ -389,19 +404,31 @@ void launch_head(const HeadArgs& ha, int hh, int ww, int B, hipStream_t s) {
     ++g_launch_counters[2];
 }
 
-void run_l2norm(Ctx& ctx, const float* x, float* y, int rows, int C) {
+// F.normalize over channels of N images of P positions -> the flow kernel's fp16 (hi, lo) operand planes (flow_plane_halves(N, P, C) halves)
+void run_l2norm_split(Ctx& ctx, const float* x, unsigned short* q, int N, int P, int C) {
+    if (C & 7) throw ArgError("l2norm: C must be a multiple of 8");
     TimeScope ts(ctx, TSNET_T_ELEMWISE);
-    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, ctx.stream, x, y, rows, C);
-    check_launch("l2norm");
+    const int Ppad = flow_ppad(P);
+    hipLaunchKernelGGL(l2norm_split_kernel, dim3((unsigned)(((size_t)N * Ppad + 3) / 4)), dim3(256), 0, ctx.stream, x, q, N, P, Ppad, C, flow_ksteps(C));
+    check_launch("l2norm_split");
 }
 
 void run_flow(Ctx& ctx, FlowArgs a, int NB) {
     if (a.C & 7) throw ArgError("flow: C must be a multiple of 8");
     TimeScope ts(ctx, TSNET_T_FLOW);
-    const size_t lds = ((size_t)32 * (a.C + 4) + ((a.P + 3) & ~3) + 2 * kFlowWaves * 32 * 4) * sizeof(float);
-    if (lds > 160 * 1024) throw ArgError("flow: feature width / position count exceed the LDS budget");
-    ensure_dynamic_lds(reinterpret_cast<const void*>(flow_kernel), lds);
-    hipLaunchKernelGGL(flow_kernel, dim3((a.P + 31) / 32, NB), dim3(64 * kFlowWaves), lds, ctx.stream, a);
+    // 64 target positions per workgroup while their planes fit in LDS beside the mask row (C <= 512 at P <= 4096), else 32
+    const size_t budget = 160 * 1024;
+    const int NT = flow_lds_bytes(2, a.h, a.w, a.C) <= budget ? 2 : 1;
+    const size_t lds = flow_lds_bytes(NT, a.h, a.w, a.C);
+    if (lds > budget) throw ArgError("flow: feature width / position count exceed the LDS budget");
+    const dim3 grid(flow_ppad(a.P) / (32 * NT) * NB);
+    if (NT == 2) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(flow_kernel<2>), lds);
+        hipLaunchKernelGGL(flow_kernel<2>, grid, dim3(64 * kFlowWaves), lds, ctx.stream, a);
+    } else {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(flow_kernel<1>), lds);
+        hipLaunchKernelGGL(flow_kernel<1>, grid, dim3(64 * kFlowWaves), lds, ctx.stream, a);
+    }
     check_launch("flow");
 }
 
@@ -487,7 +514,7 @@ struct tsnet_engine {
     float *x_img = nullptr, *x_lbl = nullptr;
     std::vector<float*> raw_img, raw_lbl;
     float *X = nullptr, *Y1 = nullptr, *Y2 = nullptr;
-    float *tar_fea = nullptr, *that = nullptr, *shat = nullptr, *flow = nullptr, *pg = nullptr;
+    float *tar_fea = nullptr, *that = nullptr, *shat = nullptr, *flow = nullptr, *pg = nullptr;   // that / shat: fp16 operand planes of the flow kernel
     float *F1 = nullptr, *F2 = nullptr, *zbar = nullptr, *sg = nullptr;
     float* F1s = nullptr;                 // per-source half of FuseNet's first convolution (+ bias): computed by set_sources, cached in clip mode
     float* FT = nullptr;                  // (B,P,2C) target half of it, computed once per driving frame
@@ -508,6 +535,7 @@ struct tsnet_engine {
     int cached_B = 0;
     float* bbox_copy = nullptr;     // (K, Bmax, H, W) device copies of the source bboxes
     int last_B = 0;
+    int cur_B = 0;                        // batch of the forward being enqueued
     float src_div[TSNET_MAX_SOURCES];  // per-source image divisor (255; 1 for use_prev sources), tsnet_set_source_divisors
 
     Timing timing;
@@ -535,7 +563,7 @@ struct tsnet_engine {
     }
     float enc_bound() const { return (float)(cfg.enc_blocks + 1) * std::sqrt((float)P); }  // bound of the source features: |relu(IN)| <= sqrt(P), + one IN output per block
     // every convolution of the forward goes through here: the engine's operand mode, the lane's statistics scratch, the finalize
-    void conv(Ctx& ctx, const ConvLayer& L, ConvCall& c) { c.nprod = np; run_conv(ctx, L, c); }
+    void conv(Ctx& ctx, const ConvLayer& L, ConvCall& c) { c.nprod = np; c.single_frame = cur_B == 1; run_conv(ctx, L, c); }
     void conv_stats(Ctx& ctx, const ConvLayer& L, ConvCall& c, int N, int HW, float* alpha, float* beta) {
         double* pt = ctx.lane ? part_side : part;
         c.stat_part = pt;
@@ -704,7 +732,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     }
     const size_t fe = (size_t)P * C;
     want(&X, NB * fe); want(&Y1, NB * fe); want(&Y2, NB * fe);
-    want(&tar_fea, B * fe); want(&that, B * fe); want(&shat, NB * fe); want(&flow, NB * P * 2); want(&pg, B * fe);
+    want(&tar_fea, B * fe); want(&that, (flow_plane_halves((int)B, P, C) + 1) / 2); want(&shat, (flow_plane_halves((int)NB, P, C) + 1) / 2); want(&flow, NB * P * 2); want(&pg, B * fe);
     want(&F1, NB * fe * 2); want(&F2, NB * fe * 2); want(&F1s, NB * fe * 2); want(&zbar, B * fe * 2); want(&sg, B * fe); want(&FT, B * fe * 2);
     want(&D, B * fe); want(&DY1, B * fe); want(&DY2, B * fe);
     U.assign(cfg.n_downsampling, nullptr); R.assign(cfg.n_downsampling, nullptr);
@@ -788,6 +816,7 @@ void tsnet_engine::encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin,
 }
 
 void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B) {
+    cur_B = B;
     const int H = cfg.height, W = cfg.width;
     {
         TimeScope ts(ctx, TSNET_T_PACK);
@@ -803,7 +832,7 @@ void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const floa
             HIP_TRY(hipMemcpyAsync(bbox_copy + (size_t)s * Bmax * H * W, src_bbox[s], (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
     }
     encode(ctx, img_enc, x_img, amax_src(), K * B, raw_img, X, cfg.enc_blocks);
-    run_l2norm(ctx, X, shat, K * B * P, C);
+    run_l2norm_split(ctx, X, reinterpret_cast<unsigned short*>(shat), K * B, P, C);
     // the per-source half of FuseNet's first convolution (conv(cat(src, tar)) = conv_src(src) + conv_tar(tar), TSNet.py:195-197)
     // depends on the sources only: computed here, so a driving frame of a clip does not pay for it
     ConvCall a; a.x = X; a.bound = enc_bound(); a.N = K * B; a.H = h; a.W = w; a.y = F1s;
@@ -814,6 +843,7 @@ void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const floa
 // Everything that depends on the driving frame only: label encoder, its L2-normalised features and the target half of
 // FuseNet's first convolution.  Independent of the source encoder, so a full forward runs it on the side stream.
 void tsnet_engine::target_chain(Ctx& ctx, const float* tar_lbl, int B) {
+    cur_B = B;
     const int H = cfg.height, W = cfg.width;
     {
         TimeScope ts(ctx, TSNET_T_PACK);
@@ -821,18 +851,20 @@ void tsnet_engine::target_chain(Ctx& ctx, const float* tar_lbl, int B) {
         p.img[0] = nullptr; p.lbl[0] = tar_lbl;
         p.coords = cfg.addcoords ? d_coords : nullptr;
         p.out = x_lbl; p.S = 1; p.B = B; p.H = H; p.W = W; p.L = cfg.label_nc; p.nimg = 0; p.Cp = cp_lbl;
-        HIP_TRY(hipMemsetAsync(amax_tar(), 0, (size_t)B * sizeof(unsigned), ctx.stream));
+        // one reset for the three per-image maxima of this forward (target input, sg, decoder stream: contiguous)
+        HIP_TRY(hipMemsetAsync(amax_tar(), 0, (size_t)3 * Bmax * sizeof(unsigned), ctx.stream));
         p.amax_out = amax_tar();
         hipLaunchKernelGGL(pack_input_kernel, dim3(pack_grid(H * W), B), dim3(256), 0, ctx.stream, p);
         check_launch("pack_input(lbl)");
     }
     encode(ctx, lbl_enc, x_lbl, amax_tar(), B, raw_lbl, tar_fea, 0);
-    run_l2norm(ctx, tar_fea, that, B * P, C);
+    run_l2norm_split(ctx, tar_fea, reinterpret_cast<unsigned short*>(that), B, P, C);
     ConvCall t; t.x = tar_fea; t.bound = std::sqrt((float)P); t.N = B; t.H = h; t.W = w; t.y = FT;      // shared target half of fuse conv1
     conv(ctx, fuse_c1_tar, t);
 }
 
 void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
+    cur_B = B;
     const int H = cfg.height, W = cfg.width, NB = K * B;
     // ---- transformation branch.  Its result (pg) is first needed by the decoder, and its kernels are latency-bound (384 workgroups):
     // with the side stream available it runs there, concurrently with the MFMA-bound synthesis branch below, and joins before dec_map.
@@ -845,7 +877,7 @@ void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb,
         HIP_TRY(hipStreamWaitEvent(side_stream, ev_fork2, 0));
     }
     FlowArgs fa{};
-    fa.that = that; fa.shat = shat; fa.tar_bbox = tar_bbox;
+    fa.tq = reinterpret_cast<const unsigned short*>(that); fa.sq = reinterpret_cast<const unsigned short*>(shat); fa.tar_bbox = tar_bbox;
     for (int s = 0; s < K; ++s) fa.src_bbox[s] = bbox_copy + (size_t)s * Bmax * H * W;
     fa.gx = d_gx; fa.gy = d_gy; fa.flow = flow;
     fa.B = B; fa.P = P; fa.C = C; fa.h = h; fa.w = w; fa.H = H; fa.W = W; fa.sy = H / h; fa.sx = W / w;
@@ -874,7 +906,6 @@ void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb,
         // zbar = mean over sources of cat(src_fea, tar_fea) + IN(.): bounded by enc_bound + sqrt(P).  fuse_net.conv has no norm behind it:
         // it publishes max |sg| per image for dec.map_conv's operand scale
         ConvCall c; c.x = zbar; c.bound = enc_bound() + sqP; c.N = B; c.H = h; c.W = w; c.y = sg;
-        HIP_TRY(hipMemsetAsync(amax_sg(), 0, (size_t)B * sizeof(unsigned), ctx.stream));
         c.amax_out = amax_sg();
         conv(ctx, fuse_out, c);
     }
@@ -889,7 +920,6 @@ void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb,
     {
         ConvCall a; a.x = pg; a.x2 = sg; a.csplit = C; a.x2_nmod = B; a.N = B; a.H = h; a.W = w; a.y = D;
         a.in_amax = amax_sg(); a.bound_add = enc_bound();
-        HIP_TRY(hipMemsetAsync(amax_dec(), 0, (size_t)B * sizeof(unsigned), ctx.stream));
         a.amax_out = amax_dec();
         conv(ctx, dec_map, a);
     }
@@ -1352,19 +1382,20 @@ int tsnet_op_flow(const float* tar_fea, const float* src_fea, const float* tar_b
     if (H % h || W % w) throw ArgError("flow op: bbox size must be a multiple of the feature size");
     Ctx ctx; ctx.stream = (hipStream_t)stream;
     const int P = h * w;
-    float *that = nullptr, *shat = nullptr, *gx = nullptr, *gy = nullptr;
-    HIP_TRY(hipMalloc((void**)&that, (size_t)B * P * C * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&shat, (size_t)B * P * C * sizeof(float)));
+    unsigned short *that = nullptr, *shat = nullptr;
+    float *gx = nullptr, *gy = nullptr;
+    HIP_TRY(hipMalloc((void**)&that, flow_plane_halves(B, P, C) * 2));
+    HIP_TRY(hipMalloc((void**)&shat, flow_plane_halves(B, P, C) * 2));
     HIP_TRY(hipMalloc((void**)&gx, w * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&gy, h * sizeof(float)));
     std::vector<float> hx(w), hy(h);
     linspace_pm1(w, hx.data()); linspace_pm1(h, hy.data());
     HIP_TRY(hipMemcpy(gx, hx.data(), w * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(gy, hy.data(), h * sizeof(float), hipMemcpyHostToDevice));
-    run_l2norm(ctx, tar_fea, that, B * P, C);
-    run_l2norm(ctx, src_fea, shat, B * P, C);
+    run_l2norm_split(ctx, tar_fea, that, B, P, C);
+    run_l2norm_split(ctx, src_fea, shat, B, P, C);
     FlowArgs fa{};
-    fa.that = that; fa.shat = shat; fa.tar_bbox = tar_bbox; fa.src_bbox[0] = src_bbox; fa.gx = gx; fa.gy = gy; fa.flow = flow;
+    fa.tq = that; fa.sq = shat; fa.tar_bbox = tar_bbox; fa.src_bbox[0] = src_bbox; fa.gx = gx; fa.gy = gy; fa.flow = flow;
     fa.B = B; fa.P = P; fa.C = C; fa.h = h; fa.w = w; fa.H = H; fa.W = W; fa.sy = H / h; fa.sx = W / w;
     run_flow(ctx, fa, B);
     HIP_TRY(hipStreamSynchronize(ctx.stream));
@@ -1508,7 +1539,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     hipStream_t s = (hipStream_t)stream;
     Ctx ctx; ctx.stream = s;
     // variant (-1 = the layer's own kernel and tile): bits 0-11 tile code (ConvCall::tile), bit 12 general kernel, bit 13 bf16 operands,
-    // bits 16-23 ablation mask, bits 24-31 experiment mask (tools build)
+    // bits 16-22 ablation mask, bit 23 two K groups, bits 24-27 experiment mask (8 = deep prefetch; the rest tools build), bits 28-30 XCD grid
     const int v = variant < 0 ? 0 : variant;
     const int nprod = (v & 8192) ? 1 : 3;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -1528,7 +1559,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     {
         OpLayer op(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s);
         ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = norm ? 64.f : 1.f; c.nprod = nprod;
-        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : 0; c.abl = (v >> 16) & 255; c.opt = (v >> 24) & 15;
+        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : 0; c.abl = (v >> 16) & 127; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0);
         { const int gx = (v >> 28) & 7; c.xcd_gn = gx == 0 ? -1 : (gx == 1 ? 0 : 1 << (gx - 2)); }          // bits 28-30: 0 default, 1 linear, 2..5 grid with 1, 2, 4, 8 columns
         if (norm) { c.alpha = al; c.beta = be; c.relu = 1; }
         for (int i = 0; i < 2; ++i) run_conv(ctx, op.L, c);

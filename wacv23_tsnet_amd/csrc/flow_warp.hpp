@@ -1,13 +1,22 @@
 // flow_warp.hpp -- the transformation branch: mask-aware correlation -> softmax(100*) ->
 // soft-argmax flow -> bilinear warp + mean over sources.
 //
-// Replaces (model/TSNet.py): the two masked torch.bmm (:350-358), F.softmax(100*., dim=2) (:359),
-// get_grid + torch.matmul (:299-307, :362-365), F.grid_sample (:366) and the stack().mean() over
-// sources (:392).  The reference materialises three B x P x P tensors per source; here the
-// P x P matrix never exists: each workgroup owns 32 target positions, its 4 waves sweep disjoint
-// 32-source tiles with the exact-fp32 MFMA (A = normalised source rows, B = normalised target
-// rows, so a lane owns ONE target column and the softmax reduction over sources is in-lane),
-// keep an online softmax state whose "value" is the 2-vector grid coordinate, and merge at the end.
+// Replaces (model/TSNet.py): F.normalize (:319,339), the two masked torch.bmm (:350-358), F.softmax(100*., dim=2) (:359),
+// get_grid + torch.matmul (:299-307, :362-365), F.grid_sample (:366) and the stack().mean() over sources (:392).  The reference
+// materialises three B x P x P tensors per source; here the P x P matrix never exists.
+//
+//   l2norm_split_kernel   one wave per position: x / max(|x|, 1e-12) as before, then the row is scaled by 2^14 and written as two fp16
+//                         planes (hi = rne(v), lo = rne(v - hi): conv_common.hpp) in MFMA FRAGMENT ORDER
+//                         [image][32-position block][16-channel step][plane][lane = half * 32 + position][8 channels]:
+//                         a wave's operand fragment is one contiguous, coalesced KiB.  Positions are padded to 64 and channels to 32 with zeros.
+//   flow_kernel<NT>       a workgroup (eight waves) owns NT * 32 target positions of one (source, batch) image pair.  Their planes
+//                         (64 x 512 channels x 2 planes = 128 KiB) are copied to LDS once; each wave then sweeps its own pairs of
+//                         32-source blocks: source fragments come straight from global memory into registers (two 16-channel steps
+//                         ahead), target fragments from LDS, 3 exact fp16 products per (source block, target block, step) on
+//                         v_mfma_f32_32x32x16_f16 (lo*hi, hi*lo, hi*hi -- the convolution kernels' fp16 x 2 arithmetic: the dropped
+//                         lo*lo term is <= 2^-22 |s||t|).  A = sources, B = targets: a lane owns target COLUMNS, so the softmax reduction
+//                         over sources is in-lane; it keeps an online-softmax state per column whose "value" is the 2-vector grid
+//                         coordinate, and the 16 partial states of a column (8 waves x 2 half-waves) are merged in a fixed order.
 //
 // Masks: corr = (T.S) * (mt*ms + (1-mt)*(1-ms)), which equals the reference's sum of two masked
 // products exactly for 0/1 masks and to rounding for soft masks; masked pairs stay at logit 0
@@ -18,9 +27,58 @@
 
 namespace tsnet {
 
+constexpr int kFlowWaves = 8;
+constexpr float kFlowScale = 16384.0f;                       // 2^14: |v| <= 1 -> |hi| <= 2^14, lo keeps 11 more bits down to |v| ~ 2e-5
+constexpr float kFlowUnscale = 1.0f / (16384.0f * 16384.0f);
+inline int flow_ppad(int P) { return (P + 63) / 64 * 64; }
+inline int flow_ksteps(int C) { return (C + 31) / 32 * 2; }  // 16-channel steps, padded to an even count
+inline size_t flow_plane_halves(int N, int P, int C) { return (size_t)N * flow_ppad(P) * flow_ksteps(C) * 16 * 2; }
+// LDS bytes of flow_kernel<NT>: max(target planes, merge buffer) + the source-mask row
+inline size_t flow_lds_bytes(int NT, int P, int C) {
+    const size_t t = (size_t)NT * flow_ksteps(C) * 2048, r = (size_t)2 * kFlowWaves * NT * 32 * 16;
+    return (t > r ? t : r) + (size_t)flow_ppad(P) * 4;
+}
+inline size_t flow_lds_bytes(int NT, int h, int w, int C) { return flow_lds_bytes(NT, h * w, C) + (size_t)(((w + 3) & ~3) + ((h + 3) & ~3)) * 4; }
+
+// F.normalize(p=2, dim=channel, eps=1e-12) on NHWC rows -> fp16 (hi, lo) planes in fragment order.  grid = N * Ppad / 4 blocks of 4 waves.
+__global__ __launch_bounds__(256) void l2norm_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ q, int N, int P, int Ppad, int C, int KC) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = row / Ppad, p = row - n * Ppad;
+    if (n >= N) return;
+    const bool valid = p < P;
+    const float* px = x + ((size_t)n * P + (valid ? p : 0)) * C;
+    float ss = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(px + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    float nrm = sqrtf(ss);
+    if (nrm < 1e-12f) nrm = 1e-12f;
+    unsigned short* dst = q + ((size_t)(n * (Ppad >> 5) + (p >> 5)) * KC) * 1024 + (p & 31) * 8;
+    for (int o = lane; o < KC * 2; o += 64) {                // channel octets, zero past C (and for the padded positions)
+        F4 t0, t1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t0.v[e] = 0.f; t1.v[e] = 0.f; }
+        if (valid && o * 8 < C) {
+            t0 = *reinterpret_cast<const F4*>(px + o * 8);
+            t1 = *reinterpret_cast<const F4*>(px + o * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { t0.v[e] = t0.v[e] / nrm * kFlowScale; t1.v[e] = t1.v[e] / nrm * kFlowScale; }
+        }
+        F4 Hh, Ll;
+        split_h2_octet(t0, t1, Hh, Ll);
+        unsigned short* d = dst + (o >> 1) * 1024 + (o & 1) * 256;
+        *reinterpret_cast<F4*>(d) = Hh;
+        *reinterpret_cast<F4*>(d + 512) = Ll;
+    }
+}
+
 struct FlowArgs {
-    const float* that;        // (B, P, C)   L2-normalised target features
-    const float* shat;        // (NB, P, C)  L2-normalised source features, n = s*B + b
+    const unsigned short* tq; // target planes of B images (l2norm_split_kernel)
+    const unsigned short* sq; // source planes of NB images, n = s*B + b
     const float* tar_bbox;    // (B, H, W)
     const float* src_bbox[8]; // per source (B, H, W)
     const float* gx;          // (w) linspace(-1,1,w)
@@ -29,111 +87,193 @@ struct FlowArgs {
     int B, P, C, h, w, H, W, sy, sx;
 };
 
-// grid = (ceil(P/32), NB), block = 64 * kFlowWaves.  dyn LDS: T tile [32][C+4] floats + ms[P] + merge[2*waves][32][4].
-// Eight waves per workgroup: the grid is only 384 workgroups at cfg0 (12 images x 32 target tiles), and every wave
-// streams its own source rows from global memory -- with four waves that was 1.5 waves per SIMD to hide the loads.
-constexpr int kFlowWaves = 8;
+// grid = Ppad / (32 NT) * NB (1-D), block = 512.  dyn LDS: target planes NT * KC * 2 KiB, then ms[Ppad], gx[w], gy[h]; the merge buffer
+// [16][NT * 32][4] floats aliases the target planes after the sweep.
+template <int NT>
 __global__ __launch_bounds__(64 * kFlowWaves) void flow_kernel(FlowArgs a) {
-    constexpr int NT = 64 * kFlowWaves;
+    constexpr int NTH = 64 * kFlowWaves;
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
-    const int LDT = a.C + 4;
-    float* sT = reinterpret_cast<float*>(smem_raw);     // [32][LDT]
-    float* sMs = sT + 32 * LDT;                          // [P]
-    float* sRed = sMs + ((a.P + 3) & ~3);                // [2 * kFlowWaves][32][4]
+    const int Ppad = (a.P + 63) / 64 * 64, KC = (a.C + 31) / 32 * 2;
+    const int TBYTES = NT * KC * 2048, RBYTES = 2 * kFlowWaves * NT * 32 * 16;
+    float* sMs = reinterpret_cast<float*>(smem_raw + (TBYTES > RBYTES ? TBYTES : RBYTES));   // [Ppad]
+    float* sGx = sMs + Ppad;                                             // [w] linspace(-1, 1, w)
+    float* sGy = sGx + ((a.w + 3) & ~3);                                 // [h]
+    float* sRed = reinterpret_cast<float*>(smem_raw);                    // [2 * kFlowWaves][NT * 32][4] (after the sweep)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = TSNET_UNIFORM(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int n = blockIdx.y;
+    // 1-D grid, XCD-aware: consecutive (image, target tile) items run on one XCD, whose L2 then fetches an image's source planes once
+    const int tiles = Ppad / (32 * NT);
+    const int item = xcd_item(blockIdx.x, (int)gridDim.x);
+    const int n = item / tiles;
     const int s_idx = n / a.B, b = n - s_idx * a.B;
-    const int t0 = blockIdx.x * 32;
+    const int tb0 = (item - n * tiles) * NT;
 
-    // stage the target tile (rows beyond P are zero) and the source mask row
-    const int c4n = a.C >> 2;
-    for (int i = tid; i < 32 * c4n; i += NT) {
-        const int r = i / c4n, c = (i - r * c4n) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t0 + r < a.P) v = *reinterpret_cast<const float4*>(a.that + ((size_t)b * a.P + t0 + r) * a.C + c);
-        *reinterpret_cast<float4*>(sT + r * LDT + c) = v;
+    // the workgroup's target fragments: one contiguous region of the plane buffer
+    {
+        const F4* g = reinterpret_cast<const F4*>(a.tq + ((size_t)(b * (Ppad >> 5) + tb0) * KC) * 1024);
+        F4* d = reinterpret_cast<F4*>(smem_raw);
+        const int cnt = TBYTES / 16;                                     // a multiple of 256 (KC is even)
+        for (int i0 = 0; i0 < cnt; i0 += 8 * NTH) {                      // eight loads in flight per thread
+            F4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * NTH + tid; v[u] = g[i < cnt ? i : tid]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * NTH + tid; if (i < cnt) d[i] = v[u]; }
+        }
     }
     const float* sb = a.src_bbox[s_idx] + (size_t)b * a.H * a.W;
-    for (int p = tid; p < a.P; p += NT) {
-        const int py = p / a.w, px = p - py * a.w;
-        sMs[p] = sb[(size_t)(py * a.sy) * a.W + px * a.sx];   // F.interpolate(nearest): src = dst*scale
+    for (int p = tid; p < Ppad; p += NTH) {
+        float v = 0.f;
+        if (p < a.P) {
+            const int py = p / a.w, px = p - py * a.w;
+            v = sb[(size_t)(py * a.sy) * a.W + px * a.sx];               // F.interpolate(nearest): src = dst*scale
+        }
+        sMs[p] = v;
     }
+    for (int p = tid; p < a.w; p += NTH) sGx[p] = a.gx[p];
+    for (int p = tid; p < a.h; p += NTH) sGy[p] = a.gy[p];
     __syncthreads();
 
-    const int t = t0 + li;                                  // this lane's target column
-    float mt = 0.f;
-    if (t < a.P) {
-        const int ty = t / a.w, tx = t - ty * a.w;
-        mt = a.tar_bbox[(size_t)b * a.H * a.W + (size_t)(ty * a.sy) * a.W + tx * a.sx];
-    }
-
-    float m_run = -3.0e38f, l_run = 0.f, ax = 0.f, ay = 0.f;
-    const int ntile = (a.P + 31) >> 5;
-    const float* srow_base = a.shat + (size_t)n * a.P * a.C;
-    for (int st = wave; st < ntile; st += kFlowWaves) {
-        const int s0 = st * 32;
-        const int srow = s0 + li < a.P ? s0 + li : a.P - 1;     // clamp (masked below)
-        const float* ap = srow_base + (size_t)srow * a.C + lh * 4;
-        const float* bp = sT + li * LDT + lh * 4;
-        f32x16 acc;
+    float mt[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int k = 0; k < a.C; k += 8) {
-            const F4 av = *reinterpret_cast<const F4*>(ap + k);
-            const F4 bv = *reinterpret_cast<const F4*>(bp + k);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.v[e], bv.v[e], acc, 0, 0, 0);
+    for (int j = 0; j < NT; ++j) {
+        const int t = (tb0 + j) * 32 + li;                                // this lane's target column of block j
+        mt[j] = 0.f;
+        if (t < a.P) {
+            const int ty = t / a.w, tx = t - ty * a.w;
+            mt[j] = a.tar_bbox[(size_t)b * a.H * a.W + (size_t)(ty * a.sy) * a.W + tx * a.sx];
         }
-        // D[row = source][col = target]: lane owns target li, source rows (r&3)+8*(r>>2)+4*lh
-        float logit[16];
-        float mx = -3.0e38f;
+    }
+    const float inv_w = 1.0f / (float)a.w;
+
+    float m_run[NT], l_run[NT], ax[NT], ay[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float lg = -3.0e38f;
-            if (s < a.P) {
+    for (int j = 0; j < NT; ++j) { m_run[j] = -3.0e38f; l_run[j] = 0.f; ax[j] = 0.f; ay[j] = 0.f; }
+    const unsigned char* sbase = reinterpret_cast<const unsigned char*>(a.sq) + ((size_t)n * (Ppad >> 5) * KC) * 2048 + lane * 16;
+    const unsigned char* tbase = smem_raw + lane * 16;
+    const int npair = Ppad >> 6;
+    for (int sp = wave; sp < npair; sp += kFlowWaves) {
+        const unsigned char* ap = sbase + (size_t)(sp * 2) * KC * 2048;  // source blocks 2 sp, 2 sp + 1: KC * 2 KiB each
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        F4 af[3][2][2][2];                                               // [set][step of the group][source block][plane]
+        F4 bf[2][NT][2];                                                 // [set][target block][plane]
+        auto load_a = [&](int set, int g) __attribute__((always_inline)) {       // the two steps of group g
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        af[set][u][i][pl] = *reinterpret_cast<const F4*>(ap + ((size_t)(i * KC + g * 2 + u) * 2 + pl) * 1024);
+        };
+        auto load_b = [&](int set, int kc) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) bf[set][j][pl] = *reinterpret_cast<const F4*>(tbase + ((j * KC + kc) * 2 + pl) * 1024);
+        };
+        auto mfmas = [&](int sa, int u, int sbt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = TSNET_MFMA_F16(af[sa][u][i][1], bf[sbt][j][0], acc[i][j]);      // lo * hi
+                    acc[i][j] = TSNET_MFMA_F16(af[sa][u][i][0], bf[sbt][j][1], acc[i][j]);      // hi * lo
+                    acc[i][j] = TSNET_MFMA_F16(af[sa][u][i][0], bf[sbt][j][0], acc[i][j]);      // hi * hi
+                }
+        };
+        // groups of two steps; source fragments two groups ahead (three register sets: a load has ~48 MFMAs = 1500 cycles to land)
+        const int ngrp = KC >> 1;
+        load_a(0, 0);
+        load_a(1, ngrp > 1 ? 1 : 0);
+        load_b(0, 0);
+        auto group = [&](int g, int S) __attribute__((always_inline)) {          // S = register set of group g = g % 3
+            load_a((S + 2) % 3, g + 2 < ngrp ? g + 2 : g);               // past the end: re-reads a valid group (unused)
+            load_b(1, 2 * g + 1);
+            mfmas(S, 0, 0);
+            load_b(0, 2 * g + 2 < KC ? 2 * g + 2 : 0);
+            mfmas(S, 1, 1);
+        };
+        int g = 0;
+        for (; g + 3 <= ngrp; g += 3) { group(g, 0); group(g + 1, 1); group(g + 2, 2); }
+        if (g < ngrp) group(g, 0);
+        if (g + 1 < ngrp) group(g + 1, 1);
+
+        // D[row = source][col = target]: lane owns target li of each block, source rows i*32 + (r&3) + 8*(r>>2) + 4*lh.  Branch-free:
+        // a source past P gets logit -3e38 and weight 0 (select); every table it indexes is padded.
+        const int s0 = sp * 64 + 4 * lh;
+        float mx[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mx[j] = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int s = s0 + i * 32 + (r & 3) + 8 * (r >> 2);
                 const float ms = sMs[s];
-                const float mf = mt * ms + (1.0f - mt) * (1.0f - ms);
-                lg = 100.0f * (acc[r] * mf);
-            }
-            logit[r] = lg;
-            mx = lg > mx ? lg : mx;
-        }
-        const float m_new = mx > m_run ? mx : m_run;
-        const float sc = expf(m_run - m_new);
-        l_run *= sc; ax *= sc; ay *= sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (s < a.P) {
-                const float e = expf(logit[r] - m_new);
-                const int py = s / a.w, px = s - py * a.w;
-                l_run += e;
-                ax = __builtin_fmaf(e, a.gx[px], ax);
-                ay = __builtin_fmaf(e, a.gy[py], ay);
+                for (int j = 0; j < NT; ++j) {
+                    const float mf = mt[j] * ms + (1.0f - mt[j]) * (1.0f - ms);
+                    float lg = 100.0f * ((acc[i][j][r] * kFlowUnscale) * mf);
+                    lg = s < a.P ? lg : -3.0e38f;
+                    acc[i][j][r] = lg;
+                    mx[j] = lg > mx[j] ? lg : mx[j];
+                }
             }
+        float m_new[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            m_new[j] = mx[j] > m_run[j] ? mx[j] : m_run[j];
+            const float sc = expf(m_run[j] - m_new[j]);
+            l_run[j] *= sc; ax[j] *= sc; ay[j] *= sc;
+            m_run[j] = m_new[j];
         }
-        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int s = s0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                const int sc = s < a.P ? s : a.P - 1;
+                const int py = (int)(((float)sc + 0.5f) * inv_w), px = sc - py * a.w;          // exact for s < 2^20
+                const float gxv = sGx[px], gyv = sGy[py];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float e = TSNET_FAST_EXP(acc[i][j][r] - m_new[j]);      // v_exp_f32((lg - m) * log2 e): relative error <= 6e-8 * |lg - m| * 1.44 (+ 1 ulp) -- weights that matter have small |lg - m|
+                    e = s < a.P ? e : 0.f;
+                    l_run[j] += e;
+                    ax[j] = __builtin_fmaf(e, gxv, ax[j]);
+                    ay[j] = __builtin_fmaf(e, gyv, ay[j]);
+                }
+            }
     }
-    // merge the partial states (waves x 2 half-waves) of each target column
-    float* o = sRed + ((wave * 2 + lh) * 32 + li) * 4;
-    o[0] = m_run; o[1] = l_run; o[2] = ax; o[3] = ay;
+    // merge the partial states (waves x 2 half-waves) of each target column, in a fixed order
+    __syncthreads();                                                     // every wave is done with the target planes
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        float* o = sRed + (((wave * 2 + lh) * NT + j) * 32 + li) * 4;
+        o[0] = m_run[j]; o[1] = l_run[j]; o[2] = ax[j]; o[3] = ay[j];
+    }
     __syncthreads();
-    if (tid < 32 && t0 + tid < a.P) {
+    if (tid < NT * 32 && tb0 * 32 + tid < a.P) {
         float M = -3.0e38f;
-        for (int q = 0; q < 2 * kFlowWaves; ++q) { const float v = sRed[(q * 32 + tid) * 4]; M = v > M ? v : M; }
+        for (int qd = 0; qd < 2 * kFlowWaves; ++qd) { const float v = sRed[(qd * NT * 32 + tid) * 4]; M = v > M ? v : M; }
         float L = 0.f, X = 0.f, Y = 0.f;
-        for (int q = 0; q < 2 * kFlowWaves; ++q) {
-            const float* p = sRed + (q * 32 + tid) * 4;
-            if (p[1] > 0.f) {
-                const float sc = expf(p[0] - M);
-                L += p[1] * sc; X += p[2] * sc; Y += p[3] * sc;
+        for (int qd = 0; qd < 2 * kFlowWaves; ++qd) {
+            const float* pr = sRed + (qd * NT * 32 + tid) * 4;
+            if (pr[1] > 0.f) {
+                const float sc = expf(pr[0] - M);
+                L += pr[1] * sc; X += pr[2] * sc; Y += pr[3] * sc;
             }
         }
-        float* f = a.flow + ((size_t)n * a.P + t0 + tid) * 2;
+        float* f = a.flow + ((size_t)n * a.P + tb0 * 32 + tid) * 2;
         f[0] = X / L;
         f[1] = Y / L;
     }

@@ -8,7 +8,6 @@
 //   * FuseNet residual + the mean over sources (TSNet.py:195-200, :400)  -> fuse_resid_mean_kernel
 //   * nn.Upsample(x2, bilinear, align_corners=False) (TSNet.py:145)      -> upsample2x_kernel
 //   * set_test_input's /255 + torch.cat + coord_conv (TSNet.py:286,312,107-125) -> pack_input_kernel
-//   * F.normalize(p=2, dim=1) (TSNet.py:319,339)                         -> l2norm_kernel
 // All reductions use a fixed order (no float atomics): results are run-to-run deterministic.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -374,30 +373,6 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
         }
     }
     if (a.amax_out) tsnet_publish_amax(a.amax_out + n, vmax);      // per image; block-uniform branch: every thread of the workgroup arrives
-}
-
-// ---------------------------------------------------------------------------------------------
-// F.normalize(p=2, dim=channel, eps=1e-12) on NHWC rows: one wave per position.
-__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int C) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* p = x + (size_t)row * C;
-    float ss = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(p + c);
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    float nrm = sqrtf(ss);
-    if (nrm < 1e-12f) nrm = 1e-12f;
-    float* q = y + (size_t)row * C;
-    for (int c = lane * 4; c < C; c += 256) {
-        float4 v = *reinterpret_cast<const float4*>(p + c);
-        v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
-        *reinterpret_cast<float4*>(q + c) = v;
-    }
 }
 
 }  // namespace tsnet
