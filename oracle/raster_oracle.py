@@ -16,8 +16,8 @@ Follows, function by function:
 The arithmetic that decides pixels lives in scipy.optimize.curve_fit (Levenberg-Marquardt from p0 = ones): this restatement calls
 it exactly as the reference does, so it reproduces the reference bit for bit (pinned by tests/golden/g7_raster_face.npz, captured
 by oracle/capture_raster_goldens.py from the imported reference).  The step after these functions in the reference's data loader,
-skimage.transform.resize + img_as_bool to 256 x 256 (:316-317), is not restated: skimage is absent from this image, so there is
-nothing to pin it against."""
+skimage.transform.resize + img_as_bool to 256 x 256 (:316-317), is restated in oracle/skimage_resize.py -- PARITY UNPINNED: skimage is
+absent from this image, so there is nothing to pin that one against."""
 from __future__ import annotations
 
 import math

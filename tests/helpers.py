@@ -77,6 +77,8 @@ def bf16_mode_report(eng, cfg, sd, inp, rec, B, dev):
     out = dict(src_fea=max(rep[k] for k in rep if k.startswith("src_fea")), tar_fea=rep["tar_fea"], sg=rep["sg"], pg=rep["pg"],
                decoder_on_engine_features=(rec - dec).abs().max().item(),
                end_to_end_vs_bf16_oracle=(rec - ref16["rec_tar_img"]).abs().max().item(),
+               end_to_end_vs_bf16_oracle_mean=(rec - ref16["rec_tar_img"]).abs().mean().item(),
+               decoder_on_engine_features_mean=(rec - dec).abs().mean().item(),
                end_to_end_vs_fp32_oracle=(rec - ref32["rec_tar_img"]).abs().max().item(),
                end_to_end_vs_fp32_oracle_mean=(rec - ref32["rec_tar_img"]).abs().mean().item(),
                oracle_bf16_vs_fp32=(ref16["rec_tar_img"] - ref32["rec_tar_img"]).abs().max().item())

@@ -29,7 +29,7 @@ def test_clip_harness_equals_one_shot_forward(tmp_path):
     kp = demo_clip.synthetic_face_keypoints(K + F)
     rs = raster.FaceRasteriser(dev)
     edges, bbox, crop, bw = rs.rasterise(list(kp))
-    lbl, box = rs.vl2ch(demo.resize_nearest(edges), 2), demo.resize_nearest(bbox)
+    lbl, box = rs.vl2ch(demo.resize_label(edges), 2), demo.resize_label(bbox)
     assert lbl.shape == (K + F, 2, 256, 256) and torch.equal(lbl.sum(dim=1), torch.ones_like(lbl[:, 0])) and lbl[:, 1].sum() > 1000
     g = torch.Generator().manual_seed(1)
     src_img = [(torch.rand((1, 3, 256, 256), generator=g) * 255.0 - torch.from_numpy(demo.IMG_MEAN).view(1, 3, 1, 1)) for _ in range(K)]
@@ -44,6 +44,13 @@ def test_clip_harness_equals_one_shot_forward(tmp_path):
     model.forward()
     want = runner.post(model.rec_tar_img)[0].cpu().numpy()
     assert np.array_equal(frames[1], want)
+    # the runner owns its engine: a later forward at a larger batch re-creates the model's shared engine (and a training-style call leaves
+    # per-source divisors on it); the clip goes on and reproduces its frames
+    model.set_test_input([x.repeat(2, 1, 1, 1) for x in src_img], [lbl[i:i + 1].repeat(2, 1, 1, 1) for i in range(K)],
+                         [box[i:i + 1].repeat(2, 1, 1) for i in range(K)], lbl[K:K + 2], box[K:K + 2])
+    model.forward()
+    assert np.array_equal(runner.frame(lbl[K + 1:K + 2], box[K + 1:K + 2]).cpu().numpy(), frames[1])
+    runner.close()
 
 
 def test_pose_clip_harness_equals_one_shot_forward(tmp_path):

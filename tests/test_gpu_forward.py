@@ -262,18 +262,30 @@ def _bf16_case(cfg, B, H, W, wseed, iseed, mask="box"):
     return r
 
 
-def test_cfg2_bf16_face_checkpoint_shape_b8():
-    """configs[2]: face-checkpoint shape (n_blocks=4), bs=8, bf16 operands on one MI355X.  Gates: the smooth stages within bf16
-    rounding-flip noise of the oracle that rounds the same operands; end-to-end distances reported (helpers.bf16_mode_report)."""
-    r = _bf16_case(O.TSNetConfig(label_nc=2, n_blocks=4, n_source=3), 8, 256, 256, 21, 22)
-    print("[cfg2 bf16] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
-    assert r["src_fea"] < 0.15 and r["tar_fea"] < 0.05 and r["sg"] < 0.15
-    assert r["decoder_on_engine_features"] < 0.05
+# Gates of the bf16-operand mode: 1.25 x the worst value measured over the three (weight seed, input seed) pairs of each configuration
+# (profiles/round3_bf16_seed_sweep.txt).  max |d| of the smooth stages against the oracle that rounds the same operands, and the
+# end-to-end MEAN |d| against that oracle: the maximum is chaotic (softmax(100 corr) turns a 1e-2 feature difference into another flow at
+# a few positions), the mean is not.
+BF16_GATES = {
+    "cfg2": dict(src_fea=0.175, tar_fea=0.0095, sg=0.0553, decoder_on_engine_features=0.0315, end_to_end_vs_bf16_oracle_mean=0.128, decoder_on_engine_features_mean=0.0032),
+    "cfg4": dict(src_fea=0.173, tar_fea=0.0088, sg=0.0426, decoder_on_engine_features=0.0068, end_to_end_vs_bf16_oracle_mean=0.1415, decoder_on_engine_features_mean=0.00023),
+}
 
 
-def test_cfg4_bf16_512_k5():
-    """configs[4] per-GPU shard: 512 x 512, n_source=5, bf16 operands (P = 4096 positions)."""
-    r = _bf16_case(O.TSNetConfig(label_nc=2, n_blocks=0, n_source=5), 1, 512, 512, 25, 26, mask="bernoulli")
-    print("[cfg4 bf16] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
-    assert r["src_fea"] < 0.15 and r["tar_fea"] < 0.05 and r["sg"] < 0.15
-    assert r["decoder_on_engine_features"] < 0.05
+def _gate(tag, r):
+    print(f"[{tag} bf16] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
+    for k, lim in BF16_GATES[tag].items():
+        assert r[k] <= lim, (tag, k, r[k], lim)
+
+
+@pytest.mark.parametrize("wseed,iseed", [(21, 22), (31, 32), (41, 42)])
+def test_cfg2_bf16_face_checkpoint_shape_b8(wseed, iseed):
+    """configs[2]: face-checkpoint shape (n_blocks=4), bs=8, bf16 operands on one MI355X, three (weights, inputs) draws.  Gates: BF16_GATES;
+    the end-to-end maxima are reported, not gated (helpers.bf16_mode_report)."""
+    _gate("cfg2", _bf16_case(O.TSNetConfig(label_nc=2, n_blocks=4, n_source=3), 8, 256, 256, wseed, iseed))
+
+
+@pytest.mark.parametrize("wseed,iseed", [(25, 26), (35, 36), (45, 46)])
+def test_cfg4_bf16_512_k5(wseed, iseed):
+    """configs[4] per-GPU shard: 512 x 512, n_source=5, bf16 operands (P = 4096 positions), three (weights, inputs) draws."""
+    _gate("cfg4", _bf16_case(O.TSNetConfig(label_nc=2, n_blocks=0, n_source=5), 1, 512, 512, wseed, iseed, mask="bernoulli"))

@@ -42,6 +42,8 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     constexpr int NPL = NPROD == 1 ? 1 : 2;                          // operand planes
     constexpr bool DEEP = (OPT & 8) != 0;
     constexpr int BD = DEEP ? 9 : 3;                                 // weight register sets: fragments are fetched BD - 1 steps ahead
+    constexpr bool ONE_LEVEL = NPROD == 1;                            // bf16 operands (2^-9 each): one fp32 chain over all of K -- the second
+                                                                     // level buys nothing below the operand rounding and costs 16 VGPRs per tile
     constexpr int KG = (OPT & 16) ? 2 : 1;                           // K groups: 4 KG waves, group g runs the slabs g, g + KG, ... of the tile
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 32, NTL = WN / 32;
@@ -215,7 +217,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     };
     // step (cc, t): A(cc,t) in set SA, B(cc,t) in set t % BD; issues A(cc,t+1) and B of BD - 1 steps ahead first
     auto step = [&](int cc, int t, int SA) __attribute__((always_inline)) {
-        const bool fresh = t == 0 || t == 4;                         // chains: taps 0..3 and 4..8 of the slab
+        const bool fresh = !ONE_LEVEL && (t == 0 || t == 4);         // chains: taps 0..3 and 4..8 of the slab
         const int t2 = (t + BD - 1) % 9;
         if (!(HABL & 2)) load_b(t2 % BD, cc + (t + BD - 1 >= 9 ? 1 : 0), t2);
         if (t < 8 && !(HABL & 4)) load_a(SA ^ 1, cc, t + 1);
@@ -235,7 +237,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
         }
         if (t == (DEEP ? 5 : 2) && !(HABL & 1)) stage_store(cc + 1, 0);
         if (t == (DEEP ? 7 : 5) && !(HABL & 1)) stage_store(cc + 1, 1);
-        if ((t == 3 || t == 8) && !(HABL & 8)) {
+        if (!ONE_LEVEL && (t == 3 || t == 8) && !(HABL & 8)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -267,6 +269,12 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     for (; cc + 2 <= nloc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
     if (cc < nloc) slab(cc, 0);
     if (OPT & 2) TSNET_SETPRIO(0);
+    if (ONE_LEVEL) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) tot[i][j] = acc[i][j];
+    }
     if (KG == 2) {
         // total = P0 + P1 (the groups' partial totals, each a sequential fold of its own chains): group 1 hands its registers over through
         // LDS in lane order (conflict-free), group 0 adds them and runs the epilogue; group 1 only keeps the barriers company
@@ -307,7 +315,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
 constexpr int h2_lds_bytes(int PR, int Cin, int KG = 1) { return KG * (2 * 2 * 2 * (((PR + 2) * (kPatchCols + 2) + 31) / 32) * 512 + 2048) + 2 * Cin * 4; }
 
 template <int PR, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int HABL = 0, int OPT = 0>
-__global__ __launch_bounds__((OPT & 16) ? 512 : 256, (OPT & 16) ? 1 : ((BN / WARPS_N) * (PR / WARPS_M) * ((OPT & 8) ? 2 : 1) <= 64 ? 3 : 2))   // wave tile 64 x 32: three workgroups per CU; 64 x 64 or DEEP 64 x 32: two; two K groups: one
+__global__ __launch_bounds__((OPT & 16) ? 512 : 256, (OPT & 16) ? 1 : ((BN / WARPS_N) * (PR / WARPS_M) * ((OPT & 8) ? 2 : 1) <= (NPROD == 1 ? 128 : 64) ? 3 : 2))   // wave tile 64 x 32 (bf16 operands: also 64 x 64, no second accumulator level): three workgroups per CU; 64 x 64 or DEEP 64 x 32: two; two K groups: one
 void conv_h2_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     int tile_m, tile_n;

@@ -86,14 +86,55 @@ def save_gif(frames: Sequence[np.ndarray], path: str, duration_ms: int = 100):
 
 # ----------------------------------------------------------------------------------------------------------------------
 # Clip harness: what demo/demo_face.py:108-236 does around the model, with the per-frame work on the device.
-def resize_nearest(x: torch.Tensor, size=(256, 256)) -> torch.Tensor:
-    """(F,h,w) byte maps -> (F,H,W) {0,1} floats by nearest-neighbour sampling.  STAND-IN, not parity-pinned: the reference resizes
-    its label maps with skimage.transform.resize + img_as_bool (dataset_video_face.py:316-317), which this image cannot run."""
+RESIZE_NOTE = ("label maps resized by a restatement of skimage.transform.resize + img_as_bool (scikit-image 0.18.3, dataset_video_face.py:316-317): "
+               "PARITY UNPINNED -- scikit-image is absent from this image, nothing to check the restatement against")
+
+
+def _mirror_index(i: torch.Tensor, n: int) -> torch.Tensor:
+    if n == 1:
+        return torch.zeros_like(i)
+    i = i.abs()
+    q, r = torch.div(i, n - 1, rounding_mode="floor"), torch.remainder(i, n - 1)
+    return torch.where(q % 2 == 1, (n - 1) - r, r)
+
+
+def resize_label(x: torch.Tensor, size=(256, 256)) -> torch.Tensor:
+    """(F,h,w) byte maps (0 / 255) -> (F,H,W) {0,1} floats: np.asarray(img_as_bool(resize(x, size))) of the reference's loaders
+    (dataset_video_face.py:104-106, 316-317, 397-398), restated from the published algorithm of scikit-image 0.18.3 -- anti-aliasing Gaussian
+    on the uint8 image (sigma = (in / out - 1) / 2, truncating cast, identity for crops below 320 pixels), bilinear sampling at
+    f (o + 0.5) - 0.5 with mirrored borders in float64, threshold 0.5.  PARITY UNPINNED (RESIZE_NOTE): the arithmetic mirrors
+    oracle/skimage_resize.py, which tests/test_resize.py holds it equal to, but neither can be run against scikit-image here."""
     F_, h, w = x.shape
     H, W = size
-    yi = (torch.arange(H, device=x.device) * h) // H
-    xi = (torch.arange(W, device=x.device) * w) // W
-    return (x[:, yi][:, :, xi] > 0).to(torch.float32)
+    dev = x.device
+    work = x.to(torch.uint8)
+    for axis, (n_in, n_out) in ((1, (h, H)), (2, (w, W))):
+        sigma = max(0.0, (n_in / n_out - 1.0) / 2.0)
+        if sigma <= 1e-15:
+            continue
+        lw = int(4.0 * sigma + 0.5)
+        k = torch.arange(-lw, lw + 1, dtype=torch.float64)
+        wts = torch.exp(-0.5 / (sigma * sigma) * k * k)
+        wts = (wts / wts.sum()).to(dev)
+        src = work.to(torch.float64)
+        idx = torch.arange(n_in, device=dev)
+        acc = src * wts[lw]
+        for j in range(1, lw + 1):
+            acc = acc + (src.index_select(axis, _mirror_index(idx + j, n_in)) + src.index_select(axis, _mirror_index(idx - j, n_in))) * wts[lw + j]
+        work = acc.trunc().to(torch.uint8)
+    im = work.to(torch.float64) / 255.0
+    r = (h / H) * (torch.arange(H, dtype=torch.float64, device=dev) + 0.5) - 0.5
+    c = (w / W) * (torch.arange(W, dtype=torch.float64, device=dev) + 0.5) - 0.5
+    r0, c0, r1, c1 = r.floor(), c.floor(), r.ceil(), c.ceil()
+    dr, dc = (r - r0).view(1, H, 1), (c - c0).view(1, 1, W)
+    ir0, ir1 = _mirror_index(r0.long(), h), _mirror_index(r1.long(), h)
+    ic0, ic1 = _mirror_index(c0.long(), w), _mirror_index(c1.long(), w)
+    top = (1 - dc) * im[:, ir0][:, :, ic0] + dc * im[:, ir0][:, :, ic1]
+    bot = (1 - dc) * im[:, ir1][:, :, ic0] + dc * im[:, ir1][:, :, ic1]
+    out = (1 - dr) * top + dr * bot
+    lo, hi = im.amin(dim=(1, 2), keepdim=True), im.amax(dim=(1, 2), keepdim=True)
+    out = torch.minimum(torch.maximum(out, lo), hi)
+    return (out > 0.5).to(torch.float32)
 
 
 class ClipRunner:
@@ -106,13 +147,26 @@ class ClipRunner:
 
     def __init__(self, model, src_img: Sequence[torch.Tensor], src_lbl: Sequence[torch.Tensor], src_bbox: Sequence[torch.Tensor]):
         self.model = model
-        self.eng = model._get_engine(1)
+        # its OWN engine (batch 1, the model's weights at this moment, default /255 source divisors): the model's shared engine is
+        # re-created when a later forward() needs a larger batch or new weights, and carries the divisors of the last set_train_input
+        self.eng = model._new_engine(1)
         K = model.n_source
         dev = model._device()
         mv = lambda t: t.to(dev, dtype=torch.float32).contiguous()
         self.src_img = [mv(x) for x in src_img[:K]]
         self.eng.set_sources(self.src_img, [mv(x) for x in src_lbl[:K]], [mv(x) for x in src_bbox[:K]])
         self.post = DemoPostprocessor(self.src_img[0])              # ref_img_list[0] (:180)
+
+    def close(self):
+        if self.eng is not None:
+            self.eng.close()
+            self.eng = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def frame(self, tar_lbl: torch.Tensor, tar_bbox: torch.Tensor) -> torch.Tensor:
         """one driving frame (1,L,H,W), (1,H,W) -> (H,W,3) uint8 RGB on the device"""

@@ -225,23 +225,30 @@ class TSNet(nn.Module):
     def _weights_version(self):
         return tuple(p._version for p in self.parameters()) + (str(self._device()),)
 
+    def _new_engine(self, max_batch: int) -> TSNetEngine:
+        """a finalized engine with this model's current weights (the caller owns it and closes it)"""
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("TSNet.forward() runs on an MI355X only: move the model with .cuda() first "
+                               "(there is no CPU execution path)")
+        eng = TSNetEngine(label_nc=self.label_nc, n_blocks=self.n_blocks, n_downsampling=self.n_downsampling,
+                          n_source=self.n_source, ngf=self.ngf, addcoords=self.addcoords,
+                          pose_composite=self._pose and getattr(self, "use_mask", False),
+                          pose_mean=getattr(self, "mean", POSE_MEAN), height=self.height, width=self.width,
+                          max_batch=max_batch, operands=self.operands)
+        eng.load_state_dict(self.generator_state_dict())
+        eng.finalize(dev)
+        return eng
+
     def _get_engine(self, B: int) -> TSNetEngine:
         key = (self.n_source, self._weights_version())
         if self._engine is None or self._engine_key != key or B > self._engine.cfg.max_batch:
-            dev = self._device()
-            if dev.type != "cuda":
+            if self._device().type != "cuda":
                 raise RuntimeError("TSNet.forward() runs on an MI355X only: move the model with .cuda() first "
                                    "(there is no CPU execution path)")
             if self._engine is not None:
                 self._engine.close()
-            eng = TSNetEngine(label_nc=self.label_nc, n_blocks=self.n_blocks, n_downsampling=self.n_downsampling,
-                              n_source=self.n_source, ngf=self.ngf, addcoords=self.addcoords,
-                              pose_composite=self._pose and getattr(self, "use_mask", False),
-                              pose_mean=getattr(self, "mean", POSE_MEAN), height=self.height, width=self.width,
-                              max_batch=max(B, self.max_batch or 0), operands=self.operands)
-            eng.load_state_dict(self.generator_state_dict())
-            eng.finalize(dev)
-            self._engine, self._engine_key = eng, key
+            self._engine, self._engine_key = self._new_engine(max(B, self.max_batch or 0)), key
         return self._engine
 
 
