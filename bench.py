@@ -162,7 +162,8 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
             import ctypes
             cnt = (ctypes.c_int64 * 4)()
             eng.lib.tsnet_debug_counters(cnt, 0)
-            pr, bn = int(cnt[3]) // 1000, int(cnt[3]) % 1000
+            code = int(cnt[3]) % 10000               # + 20000: the two-K-group tiles of single-frame forwards (not this workload)
+            pr, bn = code // 1000, code % 1000
             flop_per_launch = 2.0 * (K * batch * P) * C * (9 * C)
             avg_ms = res_ms / res_launches
             achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12

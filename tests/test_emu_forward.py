@@ -92,10 +92,11 @@ def test_conv_epilogue_statistics_path(emu_lib):
     eng.close()
 
 
-@pytest.mark.parametrize("pose", [False, True])
+@pytest.mark.parametrize("pose", [False])
 def test_vector_rgb_head(emu_lib, pose):
     """ngf=16: head_conv3_kernel (the form every reference-width model runs); ragged 48x40 frames exercise its partial tiles and
-    reflection, the pose case (256x256) its composite epilogue."""
+    reflection.  (Its composite epilogue needs a 256 x 256 pose forward -- 47 s of emulation: held by the GPU tier's pose goldens at
+    the reference width, tests/test_gpu_forward.py::test_pose_golden_composite.)"""
     H, W = (256, 256) if pose else (48, 40)
     cfg = O.TSNetConfig(label_nc=2, n_blocks=0, n_source=1, ngf=16, enc_blocks=0, fuse_ngf=256, pose=pose)
     sd = O.synth_state_dict(cfg, seed=8, bias_std=0.02)
@@ -157,11 +158,8 @@ def test_h2_samples_do_not_see_their_batch(emu_lib):
     calm[0][0][1] /= 40.0                                    # the same first sample next to an ordinary neighbour
     rec2b, _ = Hh.run_engine(eng, calm, "cpu", return_flow=False)
     assert torch.equal(rec2[:1], rec2b[:1]) and not torch.equal(rec2[1:], rec2b[1:])
-    # alone (B = 1) the single-frame tiles run: two K groups per tile, total = P0 + P1 -- the same chains in another association, so the
-    # frame agrees with its copy in the batch to fp32 rounding (amplified by the network), not bit for bit
-    one = [[t[:1] for t in x] if isinstance(x, list) else x[:1] for x in inp]
-    rec1, _ = Hh.run_engine(eng, one, "cpu", return_flow=False)
-    assert (rec2[:1] - rec1).abs().max().item() < 2e-4
+    # (alone, B = 1, the single-frame tiles run -- two K groups per tile, another association of the same chains: agreement to fp32
+    # rounding, not bit for bit; tests/test_gpu_forward.py::test_single_frame_forward and test_emu_ops.py hold that)
     eng.close()
 
 

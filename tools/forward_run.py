@@ -12,12 +12,14 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--n-blocks", type=int, default=0)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--clip", action="store_true")
+ap.add_argument("--size", type=int, default=256, help="frame height = width (512: BASELINE.json configs[4])")
+ap.add_argument("--n-source", type=int, default=3)
 ap.add_argument("--bf16", action="store_true", help="tsnet_cfg.operand_mode = 1 (bf16 convolution operands)")
 a = ap.parse_args()
-H = W = 256
-eng = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=3, height=H, width=W, max_batch=a.batch, operands="bf16" if a.bf16 else "fp32")
+H = W = a.size
+eng = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=a.n_source, height=H, width=W, max_batch=a.batch, operands="bf16" if a.bf16 else "fp32")
 eng.load_state_dict(synth.state_dict(eng.param_shapes(), seed=0)); eng.finalize("cuda")
-inp = synth.inputs(3, 2, a.batch, H, W, seed=1)
+inp = synth.inputs(a.n_source, 2, a.batch, H, W, seed=1)
 si, sl, sb, tl, tb = [[t.cuda() for t in x] if isinstance(x, list) else x.cuda() for x in inp]
 if a.clip:
     eng.set_sources(si, sl, sb)
@@ -28,4 +30,4 @@ for _ in range(5): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.iters): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
-print(json.dumps({"batch": a.batch, "n_blocks": a.n_blocks, "clip": a.clip, "bf16": a.bf16, "ms": round(dt * 1e3, 3), "frames_per_s": round(a.batch / dt, 1)}))
+print(json.dumps({"batch": a.batch, "n_blocks": a.n_blocks, "clip": a.clip, "bf16": a.bf16, "size": a.size, "n_source": a.n_source, "ms": round(dt * 1e3, 3), "frames_per_s": round(a.batch / dt, 1)}))

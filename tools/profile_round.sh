@@ -2,7 +2,7 @@
 # GPU box: the round's committed evidence -- kernel-trace stats of `bench.py`, plus two PMC passes
 # (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over the same command.  Outputs under gpurun_out/.
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$1; mkdir -p $O
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
+CMD="${TSNET_PROF_CMD:-python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary}"     # TSNET_PROF_CMD: profile another command (tools/forward_run.py ...)
 rocprofv3 --kernel-trace --stats -f csv rocpd -d $O/trace -o t -- $CMD > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p -- $CMD > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p -- $CMD > $O/write.log 2>&1

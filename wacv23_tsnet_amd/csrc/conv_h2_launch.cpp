@@ -73,7 +73,7 @@ void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int o
     }
     if (abl || opt) {
 #ifdef TSNET_TOOLS
-        // experiment / ablation instantiations (tools/h2_variants.py, tools/x3_ablate.py): 3 products, raw or transformed input
+        // experiment / ablation instantiations (tools/h2_variants.py): 3 products, raw or transformed input
         if (nprod != 3) throw std::invalid_argument("conv(h2): experiment variants are built for three products");
 #define TSNET_H2_VAR(PR_, BN_, WM_, WN_, A_, O_) if (pr == PR_ && bn == BN_ && abl == A_ && opt == O_) { go_h2<PR_, BN_, WM_, WN_, 3, A_, O_>(a, s); return; }
         TSNET_H2_VAR(4, 64, 2, 2, 0, 1) TSNET_H2_VAR(4, 64, 2, 2, 0, 2) TSNET_H2_VAR(4, 64, 2, 2, 0, 3) TSNET_H2_VAR(4, 64, 2, 2, 0, 16) TSNET_H2_VAR(4, 128, 2, 2, 0, 16)

@@ -271,6 +271,10 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
                 // tiles double the number of workgroups; each stages the same patch but runs half the MFMA chain.
                 const long tm = (long)c.N * (hw / 128), t64 = tm * ((g.Cout + 63) / 64);
                 bn = wide_pays(tm, c.alpha ? 1.03 : 1.10) ? 128 : 64;
+                // bf16 operands: one product per step -- the 64-wide tile is latency-bound (mfma_util 0.19, 81 % of the wave cycles
+                // waiting at configs[4]); the 128-wide one runs three workgroups per CU as well (no second accumulator level) and wins
+                // whenever it still fills the chip
+                if (bf16 && g.Npad % 128 == 0 && g.Cout > 64 && tm * ((g.Cout + 127) / 128) >= 256) bn = 128;
                 // A forward of ONE frame (B = 1), launches of at most one 64-wide tile per CU: no co-resident workgroup hides a load.  The
                 // tile then runs as eight waves -- two K groups of four, each folding the chains of every other slab, weights eight steps
                 // ahead -- and, up to 128 tiles, in its 32-wide shape, which doubles the workgroups: 67 -> 54 us on the 192-tile ResnetBlock
