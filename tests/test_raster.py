@@ -82,6 +82,56 @@ def test_host_fit_equals_curve_fit_bit_for_bit(emu_lib):
     assert n_fits == 34 * 78
 
 
+def test_degenerate_pieces_follow_the_reference(emu_lib):
+    """Integer landmarks make pieces whose points share an abscissa along the fitting axis, repeat, or collapse to one point (a
+    closed-form parabola gives NaN there).  The host fit runs the reference's optimiser on them too: same `popt` bits as scipy's curve_fit
+    (or the same decision to drop the piece), and the maps the device draws from them equal the oracle's."""
+    import warnings
+    from scipy.optimize import curve_fit
+    g = np.random.default_rng(7)
+    kps = g.integers(30, 260, size=(6, 68, 2)).astype(np.float64)
+    subs = RO.sub_edges()
+    for f in range(6):                                   # force the degenerate shapes into every frame
+        for e in g.choice(len(subs), size=8, replace=False):
+            se = subs[e]
+            mode = g.integers(0, 4)
+            if mode == 0:
+                kps[f, se[1]] = kps[f, se[0]]                              # repeated point
+            elif mode == 1:
+                kps[f, se[1], 0] = kps[f, se[0], 0]; kps[f, se[1], 1] = kps[f, se[0], 1] + 40     # same x, far apart in y
+            elif mode == 2:
+                kps[f, se, :] = kps[f, se[0]]                              # the whole piece is one point
+            else:
+                kps[f, se[-1], 1] = kps[f, se[0], 1]; kps[f, se[-1], 0] = kps[f, se[0], 0] + 1
+    kps = np.ascontiguousarray(kps)
+    rec = np.full((6, 34, 8), np.nan)
+    assert emu_lib.tsnet_fit_face_curves(kps.ctypes.data, 6, rec.ctypes.data) == 0
+    checked = 0
+    for f in range(6):
+        for e, se in enumerate(subs):
+            x, y = kps[f][se, 0], kps[f][se, 1]
+            swap = abs(x[:-1] - x[1:]).max() < abs(y[:-1] - y[1:]).max()
+            if swap:
+                x, y = y, x
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                popt, _ = curve_fit(RO._linear if len(x) < 3 else RO._quadratic, x, y)
+            if len(x) == 3 and abs(popt[0]) > 1:
+                assert rec[f, e, 0] == 0
+                continue
+            want = [0.0, popt[0], popt[1]] if len(x) < 3 else list(popt)
+            got = [float(v) for v in rec[f, e, 1:4]]
+            assert all((a == b) or (np.isnan(a) and np.isnan(b)) for a, b in zip(got, [float(v) for v in want])), (f, e, x, y, got, want)
+            checked += 1
+    assert checked > 150
+    r = raster.FaceRasteriser("cpu", lib=emu_lib)
+    crop = (0, 292, 0, 292)
+    edges, bbox, _, bw = r.rasterise(list(kps), crop)
+    for f in range(6):
+        want = RO.face_edge_map(kps[f], (292, 292), bw)
+        assert np.array_equal(edges[f].numpy(), want), f
+
+
 def _device_check(lib, dev):
     meta, z = _golden()
     r = raster.FaceRasteriser(dev, lib=lib)
