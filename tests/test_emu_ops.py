@@ -136,6 +136,8 @@ def test_flow_many_tiles(emu_lib):
     assert df < 5e-5 and dw < 4e-3   # dw = flow error x feature gradient
     df, dw = oc.flow_case(emu_lib, "cpu", 1, 24, 24, 16, "bernoulli", spike=True)   # 9 pairs: wave 0 sweeps two; 9 workgroups of 64 targets
     assert df < 5e-5 and dw < 4e-3
+    df, dw = oc.flow_case(emu_lib, "cpu", 1, 8, 10, 1024, "bernoulli", spike=True)  # 1024 channels: 64 targets' planes exceed the LDS -> 32 per workgroup (flow_kernel<1>)
+    assert df < 5e-5 and dw < 4e-3
 
 
 def test_warp_out_of_range(emu_lib):

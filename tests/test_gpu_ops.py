@@ -82,6 +82,14 @@ def test_flow_ragged_positions(lib):
     assert df < 5e-5 and dw < 4e-3   # dw = flow error x feature gradient
 
 
+def test_flow_wide_features_and_large_maps(lib):
+    """1024 channels (64 targets' planes exceed the LDS: 32 targets per workgroup, flow_kernel<1>) and BASELINE.json configs[4]'s 64 x 64 positions"""
+    df, dw = oc.flow_case(lib, DEV, 1, 16, 16, 1024, "bernoulli", spike=True)
+    assert df < 5e-5 and dw < 4e-3
+    df, dw = oc.flow_case(lib, DEV, 1, 64, 64, 512, "box")
+    assert df < 5e-5 and dw < 4e-3
+
+
 def test_warp_out_of_range(lib):
     assert oc.warp_case(lib, DEV, 2, 16, 12, 128) < TOL
 

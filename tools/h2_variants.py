@@ -41,6 +41,10 @@ def run(name, shape, variants, norms=(0, 1), iters=8):
 
 SEL = sys.argv[2] if len(sys.argv) > 2 else "all"
 RES = (12, 32, 32, 512, 512, 3, 1, 1, 1)
+if SEL == "chain":      # one accumulation chain per slab (27 MFMAs) instead of two (12 + 15): half the folds
+    run("res", RES, [("4x64", code(64)), ("4x64 slab-chain", code(64, opt=4)), ("4x128", code(128)), ("4x128 slab-chain", code(128, opt=4))])
+    run("fuse_c2", (12, 32, 32, 1024, 1024, 3, 1, 1, 1), [("4x128", code(128)), ("4x128 slab-chain", code(128, opt=4))])
+    sys.exit(0)
 if SEL == "kg":         # two K groups per tile (eight waves, one workgroup per CU) against the co-resident four-wave workgroups
     for nm, n in (("res B=4 (12 images)", 12), ("res B=2 (6 images)", 6), ("res B=1 (3 images)", 3), ("res clip (1 image)", 1), ("res B=8 (24 images)", 24)):
         run(nm, (n, 32, 32, 512, 512, 3, 1, 1, 1), [("4x64", code(64)), ("4x64 deep", code(64, opt=8)), ("4x64 deep kg2", code(64, opt=24)), ("4x32 deep kg2", code(32, opt=24)), ("4x64 kg2", code(64, opt=16))])

@@ -217,7 +217,8 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     };
     // step (cc, t): A(cc,t) in set SA, B(cc,t) in set t % BD; issues A(cc,t+1) and B of BD - 1 steps ahead first
     auto step = [&](int cc, int t, int SA) __attribute__((always_inline)) {
-        const bool fresh = !ONE_LEVEL && (t == 0 || t == 4);         // chains: taps 0..3 and 4..8 of the slab
+        constexpr bool SLAB_CHAIN = (OPT & 4) != 0;                  // experiment (tools build): one chain per slab instead of two
+        const bool fresh = !ONE_LEVEL && (t == 0 || (!SLAB_CHAIN && t == 4));   // chains: taps 0..3 and 4..8 of the slab
         const int t2 = (t + BD - 1) % 9;
         if (!(HABL & 2)) load_b(t2 % BD, cc + (t + BD - 1 >= 9 ? 1 : 0), t2);
         if (t < 8 && !(HABL & 4)) load_a(SA ^ 1, cc, t + 1);
@@ -237,7 +238,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
         }
         if (t == (DEEP ? 5 : 2) && !(HABL & 1)) stage_store(cc + 1, 0);
         if (t == (DEEP ? 7 : 5) && !(HABL & 1)) stage_store(cc + 1, 1);
-        if (!ONE_LEVEL && (t == 3 || t == 8) && !(HABL & 8)) {
+        if (!ONE_LEVEL && ((!SLAB_CHAIN && t == 3) || t == 8) && !(HABL & 8)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll

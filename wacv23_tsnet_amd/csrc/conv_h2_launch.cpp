@@ -77,7 +77,7 @@ void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int o
         if (nprod != 3) throw std::invalid_argument("conv(h2): experiment variants are built for three products");
 #define TSNET_H2_VAR(PR_, BN_, WM_, WN_, A_, O_) if (pr == PR_ && bn == BN_ && abl == A_ && opt == O_) { go_h2<PR_, BN_, WM_, WN_, 3, A_, O_>(a, s); return; }
         TSNET_H2_VAR(4, 64, 2, 2, 0, 1) TSNET_H2_VAR(4, 64, 2, 2, 0, 2) TSNET_H2_VAR(4, 64, 2, 2, 0, 3) TSNET_H2_VAR(4, 64, 2, 2, 0, 16) TSNET_H2_VAR(4, 128, 2, 2, 0, 16)
-        TSNET_H2_VAR(4, 64, 2, 2, 0, 8) TSNET_H2_VAR(4, 32, 4, 1, 0, 8)
+        TSNET_H2_VAR(4, 64, 2, 2, 0, 8) TSNET_H2_VAR(4, 32, 4, 1, 0, 8) TSNET_H2_VAR(4, 64, 2, 2, 0, 4) TSNET_H2_VAR(4, 128, 2, 2, 0, 4)
         TSNET_H2_VAR(4, 128, 2, 2, 0, 1) TSNET_H2_VAR(2, 128, 1, 4, 0, 2)
         TSNET_H2_VAR(4, 64, 2, 2, 1, 0) TSNET_H2_VAR(4, 64, 2, 2, 2, 0) TSNET_H2_VAR(4, 64, 2, 2, 4, 0) TSNET_H2_VAR(4, 64, 2, 2, 7, 0)
         TSNET_H2_VAR(4, 64, 2, 2, 8, 0) TSNET_H2_VAR(4, 64, 2, 2, 16, 0) TSNET_H2_VAR(4, 64, 2, 2, 15, 0) TSNET_H2_VAR(4, 64, 2, 2, 31, 0)
