@@ -15,6 +15,7 @@ import torch
 import helpers as Hh
 from oracle import tsnet_oracle as O
 
+SINGLES = 2                      # batch items also run alone (B = 1) per pair
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 torch.set_num_threads(min(16, max(1, len(os.sched_getaffinity(0)))))
@@ -36,7 +37,15 @@ for i in range(n):
     i64 = [[t.double() for t in x] if isinstance(x, list) else x.double() for x in inp]
     o64 = O.tsnet_forward(sd64, cfg, *i64)
     r32, r64 = o32["rec_tar_img"], o64["rec_tar_img"]
-    row = dict(wseed=wseed, iseed=iseed, mask=mask,
+    # the same frames one at a time: a forward of ONE frame runs the two-K-group tiles -- same gate, other association
+    one_vs_o32 = one_vs_o64 = one_vs_batch = 0.0
+    for b in range(SINGLES):
+        sub = [[t[b:b + 1] for t in x] if isinstance(x, list) else x[b:b + 1] for x in inp]
+        r1, _ = Hh.run_engine(eng, sub, "cuda")
+        one_vs_o32 = max(one_vs_o32, (r1 - r32[b:b + 1]).abs().max().item())
+        one_vs_o64 = max(one_vs_o64, (r1.double() - r64[b:b + 1]).abs().max().item())
+        one_vs_batch = max(one_vs_batch, (r1 - rec[b:b + 1]).abs().max().item())
+    row = dict(wseed=wseed, iseed=iseed, mask=mask, single_frame_vs_o32=one_vs_o32, single_frame_vs_o64=one_vs_o64, single_frame_vs_same_frame_in_batch=one_vs_batch,
                gpu_vs_o32=(rec - r32).abs().max().item(), gpu_vs_o64=(rec.double() - r64).abs().max().item(),
                o32_vs_o64=(r32.double() - r64).abs().max().item(),
                gpu_vs_o64_mean=(rec.double() - r64).abs().mean().item(), o32_vs_o64_mean=(r32.double() - r64).abs().mean().item(),
@@ -47,7 +56,9 @@ summary = dict(pairs=n,
                max_gpu_vs_o32=max(r["gpu_vs_o32"] for r in rows), max_gpu_vs_o64=max(r["gpu_vs_o64"] for r in rows),
                max_o32_vs_o64=max(r["o32_vs_o64"] for r in rows), max_flow=max(r["flow"] for r in rows),
                pairs_where_gpu_is_closer_to_fp64_than_the_fp32_oracle=sum(r["gpu_vs_o64"] < r["o32_vs_o64"] for r in rows),
-               pairs_over_1e_3_vs_o32=sum(r["gpu_vs_o32"] > 1e-3 for r in rows))
+               pairs_over_1e_3_vs_o32=sum(r["gpu_vs_o32"] > 1e-3 for r in rows),
+               max_single_frame_vs_o32=max(r["single_frame_vs_o32"] for r in rows), max_single_frame_vs_o64=max(r["single_frame_vs_o64"] for r in rows),
+               max_single_frame_vs_same_frame_in_batch=max(r["single_frame_vs_same_frame_in_batch"] for r in rows))
 print(json.dumps(summary))
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out")
 if os.path.isdir(out):

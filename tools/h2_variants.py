@@ -2,9 +2,10 @@
 
 Per layer shape, every variant is timed in interleaved rounds inside ONE process (cdna_hip_programming.md rule 24) and the median
 reported.  variant code of tsnet_bench_conv: tile | general kernel << 12 | ablation mask << 16 | experiment mask << 24 | XCD grid << 28.
-  experiment mask (h2_tile OPT): 1 = legacy staging arithmetic (select + scalar converts), 2 = rotating wave priority
+  experiment mask (h2_tile OPT): 1 = legacy staging arithmetic (select + scalar converts), 2 = rotating wave priority, 4 = one accumulation
+    chain per slab, 8 = deep weight prefetch, 16 = two K groups per tile (24 = the product's single-frame tiles)
   ablation mask  (h2_tile HABL, computes garbage): 1 no patch staging, 2 weights once, 4 A fragments once, 8 no fold, 16 no barrier
-usage: h2_variants.py [rounds]"""
+usage: h2_variants.py [rounds] [all | xcd | small | kg | chain]"""
 import ctypes as C, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -30,8 +30,9 @@ namespace tsnet {
 //   4 x 128 (2 x 2, 64 x 64)   half the LDS / L1 bytes per MFMA, two workgroups per CU (FuseNet, decoder)
 //   4 x 32  (4 x 1, 32 x 32)   launches with few tiles (one driving frame)
 //   2 x 128 (1 x 4, 64 x 32)   the patch is staged once per 128 instead of 64 output channels (0.67 x the staging work per MFMA)
-// OPT: bit 3 = DEEP prefetch (product).  Tools build only (tools/h2_variants.py): bit 0 legacy staging arithmetic (select / scalar
-// converts; for the A/B), bit 1 rotating wave priority.  HABL (tools/h2_variants.py; non-zero computes garbage): bit0 no patch staging in the loop, bit1
+// OPT: bits 3 + 4 = DEEP prefetch with two K groups (24: the single-frame tiles of the product).  Tools build only (tools/h2_variants.py):
+// bit 0 legacy staging arithmetic (select / scalar converts; for the A/B), bit 1 rotating wave priority, bit 2 one accumulation chain
+// per slab instead of two, bits 3 / 4 alone.  HABL (tools/h2_variants.py; non-zero computes garbage): bit0 no patch staging in the loop, bit1
 // weight fragments loaded once, bit2 A fragments read once, bit3 no fold, bit4 no slab barrier.
 template <int PR, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int HABL = 0, int OPT = 0>
 __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_raw, const int tile_m, const int n0) {
