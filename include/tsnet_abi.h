@@ -229,6 +229,14 @@ int tsnet_vl2ch(const float* labels, int B, int HW, int num_classes, float* out,
  * tsnet_resize_pad  <- Image.resize(size, NEAREST) + resize_square (:425-432, :471-477): out[f, pad_top+y, pad_left+x] = in[f, ytab[y], xtab[x]],
  *                      zero elsewhere; out (F,OH,OW) floats (binarise: != 0 -> 1, the `bbox != 0` of :441, :448).  ytab / xtab: device ints, the
  *                      source row / column of every output row / column (wacv23_tsnet_amd/raster.py computes them in PIL's order). */
+/* tsnet_resize_label <- np.asarray(img_as_bool(skimage.transform.resize(map, (OH, OW)))) of the face loader (dataset/dataset_video_face.py:104-106,
+ *                      316-317, 397-398; scikit-image 0.18.3): in (F,h,w) device bytes (0 / 255), out (F,OH,OW) device floats 0 / 1.  Restated from
+ *                      the published algorithm of that version (oracle/skimage_resize.py) -- PARITY UNPINNED: scikit-image is not available to
+ *                      check it against.  wts_rows / wts_cols: HOST doubles, the anti-aliasing Gaussian of an axis that shrinks, centre first:
+ *                      w[j] = exp(-0.5 j^2 / sigma^2) / sum, j = 0..lw, sigma = (in / out - 1) / 2, lw = int(4 sigma + 0.5)
+ *                      (scipy.ndimage.gaussian_filter1d); lw = -1 (or sigma = 0): no pass along that axis.  Synchronises the stream. */
+int tsnet_resize_label(const unsigned char* in, int F, int h, int w, int OH, int OW, const double* wts_rows, int lw_rows,
+                       const double* wts_cols, int lw_cols, float* out, void* stream);
 int tsnet_fit_pose_curves(const double* pts, int F, int flags, double* curves);
 int tsnet_raster_pose(const double* pts, const double* curves, int F, int h, int w, int win_x0, int win_y0, int win_x1, int win_y1, int flags,
                       unsigned char* labels, void* stream);

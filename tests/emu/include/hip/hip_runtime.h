@@ -112,6 +112,8 @@ template <class T> static inline T emu_fetch_add(T* p, T v) { T o = *p; *p = o +
 #define __hip_atomic_fetch_add(p, v, order, scope) emu_fetch_add((p), (v))
 template <class T> static inline T emu_fetch_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 #define __hip_atomic_fetch_max(p, v, order, scope) emu_fetch_max((p), (v))
+template <class T> static inline T emu_fetch_min(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+#define __hip_atomic_fetch_min(p, v, order, scope) emu_fetch_min((p), (v))
 static inline unsigned atomicCAS(unsigned* p, unsigned cmp, unsigned v) { const unsigned o = *p; if (o == cmp) *p = v; return o; }   // raster.hpp raise_byte
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

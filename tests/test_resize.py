@@ -1,6 +1,6 @@
 """CPU tier: the 256 x 256 resize of the reference's loaders (skimage.transform.resize + img_as_bool, dataset_video_face.py:316-317).
 PARITY UNPINNED: scikit-image 0.18.3 cannot be run here, so these tests hold only what can be held -- the product-side helper
-(wacv23_tsnet_amd.demo.resize_label) equals the oracle restatement (oracle/skimage_resize.py) bit for bit, the restatement has the
+(wacv23_tsnet_amd.demo.resize_label -> tsnet_resize_label, HIP kernels run here through the emulation build) equals the oracle restatement (oracle/skimage_resize.py) bit for bit, the restatement has the
 properties the published algorithm implies, and in the interior it equals torch's bilinear resampling, which uses the same
 (o + 0.5) f - 0.5 sampling grid."""
 import numpy as np
@@ -23,13 +23,14 @@ def edge_map(h, w, seed):
     return img
 
 
-@pytest.mark.parametrize("h,w", [(292, 292), (256, 256), (300, 281), (512, 512), (640, 400), (200, 230)])
-def test_product_helper_equals_the_restatement(h, w):
-    for seed in range(2):
-        img = edge_map(h, w, seed)
-        want = SR.resize_bool(img)
-        got = demo.resize_label(torch.from_numpy(img)[None]).numpy()[0]
-        assert got.shape == (256, 256) and np.array_equal(got, want.astype(np.float32))
+@pytest.mark.parametrize("h,w", [(292, 292), (256, 256), (300, 281), (512, 512), (640, 400), (200, 230), (1100, 900)])
+def test_product_kernels_equal_the_restatement(emu_lib, h, w):
+    """tsnet_resize_label (the emulation build runs the same kernels) against oracle/skimage_resize.py, two frames per call"""
+    imgs = np.stack([edge_map(h, w, seed) for seed in range(2)])
+    got = demo.resize_label(torch.from_numpy(imgs), lib=emu_lib).numpy()
+    assert got.shape == (2, 256, 256)
+    for f in range(2):
+        assert np.array_equal(got[f], SR.resize_bool(imgs[f]).astype(np.float32)), f
 
 
 def test_identity_and_small_crops_do_not_blur():
@@ -53,3 +54,13 @@ def test_mirrored_borders():
     img = np.zeros((300, 300), np.uint8); img[0, :] = 255; img[:, -1] = 255
     out = SR.resize_float(img)
     assert out[0].min() > 0.4 and out[:, -1].min() > 0.4 and out[5:-5, 5:-5].max() == 0
+
+
+@pytest.mark.gpu
+def test_product_kernels_on_the_gpu():
+    """the same comparison through the HIP library on cuda:0 (three crop sizes: no filter, a 5-tap and a 15-tap Gaussian)"""
+    for h, w in ((292, 292), (512, 640), (1100, 900)):
+        imgs = np.stack([edge_map(h, w, seed) for seed in range(3)])
+        got = demo.resize_label(torch.from_numpy(imgs).cuda()).cpu().numpy()
+        for f in range(3):
+            assert np.array_equal(got[f], SR.resize_bool(imgs[f]).astype(np.float32)), (h, w, f)

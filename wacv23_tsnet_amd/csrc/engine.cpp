@@ -1527,6 +1527,45 @@ int tsnet_resize_pad(const unsigned char* in, int F, int h, int w, const int* yt
     OP_END
 }
 
+int tsnet_resize_label(const unsigned char* in, int F, int h, int w, int OH, int OW, const double* wts_rows, int lw_rows,
+                       const double* wts_cols, int lw_cols, float* out, void* stream) {
+    OP_BEGIN
+    if (!in || !out) throw ArgError("resize_label: null tensor");
+    if (F < 1 || h < 1 || w < 1 || OH < 1 || OW < 1) throw ArgError("resize_label: bad shape");
+    if (lw_rows < -1 || lw_cols < -1 || lw_rows > 63 || lw_cols > 63 || (lw_rows >= 0 && !wts_rows) || (lw_cols >= 0 && !wts_cols))
+        throw ArgError("resize_label: bad Gaussian kernel");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)F * h * w;
+    unsigned char *t0 = nullptr, *t1 = nullptr;
+    double* dw = nullptr;
+    int* mm = nullptr;
+    struct Guard { unsigned char*& a; unsigned char*& b; double*& c; int*& d; ~Guard() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); } } guard{t0, t1, dw, mm};
+    const unsigned char* cur = in;
+    // anti-aliasing passes: one per axis that shrinks (lw >= 0); the caller supplies the kernel halves (centre first) it computed in fp64
+    for (int axis = 0; axis < 2; ++axis) {
+        const int lw = axis ? lw_cols : lw_rows;
+        const double* wts = axis ? wts_cols : wts_rows;
+        if (lw < 0) continue;
+        unsigned char*& dst = (cur == t0) ? t1 : t0;
+        if (!dst) HIP_TRY(hipMalloc((void**)&dst, n));
+        if (!dw) HIP_TRY(hipMalloc((void**)&dw, 2 * 64 * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(dw + axis * 64, wts, (lw + 1) * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(gauss1d_u8_kernel, dim3(ew_grid(n)), dim3(256), 0, s, cur, dst, F, h, w, axis, dw + axis * 64, lw);
+        check_launch("gauss1d_u8");
+        cur = dst;
+    }
+    HIP_TRY(hipMalloc((void**)&mm, (size_t)2 * F * sizeof(int)));
+    std::vector<int> init(2 * F);
+    for (int f = 0; f < F; ++f) { init[2 * f] = 255; init[2 * f + 1] = 0; }
+    HIP_TRY(hipMemcpyAsync(mm, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(u8_minmax_kernel, dim3(std::min(64, (h * w + 255) / 256), F), dim3(256), 0, s, cur, F, h * w, mm);
+    check_launch("u8_minmax");
+    hipLaunchKernelGGL(resize_label_kernel, dim3(ew_grid((size_t)F * OH * OW)), dim3(256), 0, s, cur, F, h, w, OH, OW, mm, out);
+    check_launch("resize_label");
+    HIP_TRY(hipStreamSynchronize(s));                                  // host temporaries (init, the caller's kernels) and device scratch end here
+    OP_END
+}
+
 int tsnet_vl2ch(const float* labels, int B, int HW, int num_classes, float* out, void* stream) {
     OP_BEGIN
     if (!labels || !out) throw ArgError("vl2ch: null tensor");

@@ -15,6 +15,8 @@
 //     a straight line) + utils/misc.py im2vl (:27-47, colour -> class index)                  -> pose_edges_kernel + pose_order_to_class_kernel
 //   * PoseDatasetTestVideo.get_bbox_image (:590-607)                                          -> label_bbox_kernel
 //   * Image.resize(.., NEAREST) + resize_square (:425-432, :471-477)                          -> gather_pad_kernel (index tables from the host)
+//   * skimage.transform.resize + img_as_bool of the face loader (dataset_video_face.py:316-317)    -> gauss1d_u8 / u8_minmax / resize_label kernels
+//     (restated from the published algorithm, PARITY UNPINNED: see there)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -273,6 +275,74 @@ __global__ __launch_bounds__(256) void gather_pad_kernel(const unsigned char* __
             v = binarise ? (s != 0 ? 1.f : 0.f) : (float)s;
         }
         out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The face loader's 256 x 256 resize: np.asarray(img_as_bool(skimage.transform.resize(map, (256, 256)))) (dataset_video_face.py:104-106,
+// 316-317, 397-398; scikit-image 0.18.3).  PARITY UNPINNED: scikit-image cannot be run in this image; the kernels below follow
+// oracle/skimage_resize.py, the restatement of that version's published algorithm, operation for operation (fp64, no contraction).
+//   1. anti-aliasing Gaussian on the uint8 image, one 1-D pass per axis with sigma = (in / out - 1) / 2 > 0, mirrored borders, scipy's
+//      symmetric correlate order (centre, then pairs outwards), result truncated back to uint8 (the C cast of scipy's line buffer);
+//   2. bilinear sampling at f (o + 0.5) - 0.5 between floor and ceil, mirrored borders, on the image / 255; clip to the image's range;
+//   3. > 0.5.
+__device__ __forceinline__ int mirror_index(int i, int n) {          // coord_map(mode 'R'): reflect about the edge pixel centres
+    if (n == 1) return 0;
+    const int c = n - 1;
+    i = i < 0 ? -i : i;
+    const int q = i / c, r = i - q * c;
+    return (q & 1) ? c - r : r;
+}
+
+// one 1-D Gaussian pass along `axis` (0 = rows, 1 = columns) of F images (h, w); wts: lw + 1 doubles (centre first)
+__global__ __launch_bounds__(256) void gauss1d_u8_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, int F, int h, int w,
+                                                         int axis, const double* __restrict__ wts, int lw) {
+    const size_t total = (size_t)F * h * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const unsigned char* img = in + (i / ((size_t)w * h)) * (size_t)w * h;
+        const int n = axis ? w : h, pos = axis ? x : y;
+        double acc = (double)in[i] * wts[0];
+        for (int j = 1; j <= lw; ++j) {
+            const int a = mirror_index(pos + j, n), b = mirror_index(pos - j, n);
+            const double va = axis ? (double)img[(size_t)y * w + a] : (double)img[(size_t)a * w + x];
+            const double vb = axis ? (double)img[(size_t)y * w + b] : (double)img[(size_t)b * w + x];
+            acc = acc + (va + vb) * wts[j];
+        }
+        out[i] = (unsigned char)acc;                                  // truncation: acc is in [0, 255]
+    }
+}
+
+// per-frame minimum / maximum of a byte image -> mm[f] = {min, max} (ints, initialised to {255, 0} by the caller)
+__global__ __launch_bounds__(256) void u8_minmax_kernel(const unsigned char* __restrict__ in, int F, int hw, int* __restrict__ mm) {
+    const int f = blockIdx.y;
+    int lo = 255, hi = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        const int v = in[(size_t)f * hw + i];
+        lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+    }
+    __hip_atomic_fetch_min(mm + 2 * f, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // order-independent: deterministic
+    __hip_atomic_fetch_max(mm + 2 * f + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void resize_label_kernel(const unsigned char* __restrict__ in, int F, int h, int w, int OH, int OW,
+                                                           const int* __restrict__ mm, float* __restrict__ out) {
+    const size_t total = (size_t)F * OH * OW;
+    const double fr = (double)h / (double)OH, fc = (double)w / (double)OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % OW), Y = (int)((i / OW) % OH), f = (int)(i / ((size_t)OW * OH));
+        const unsigned char* img = in + (size_t)f * h * w;
+        const double r = fr * ((double)Y + 0.5) - 0.5, c = fc * ((double)X + 0.5) - 0.5;
+        const double r0 = floor(r), c0 = floor(c), r1 = ceil(r), c1 = ceil(c);
+        const double dr = r - r0, dc = c - c0;
+        const int ir0 = mirror_index((int)r0, h), ir1 = mirror_index((int)r1, h), ic0 = mirror_index((int)c0, w), ic1 = mirror_index((int)c1, w);
+        const double tl = (double)img[(size_t)ir0 * w + ic0] / 255.0, tr = (double)img[(size_t)ir0 * w + ic1] / 255.0;
+        const double bl = (double)img[(size_t)ir1 * w + ic0] / 255.0, br = (double)img[(size_t)ir1 * w + ic1] / 255.0;
+        const double top = (1.0 - dc) * tl + dc * tr, bot = (1.0 - dc) * bl + dc * br;
+        double v = (1.0 - dr) * top + dr * bot;
+        const double lo = (double)mm[2 * f] / 255.0, hi = (double)mm[2 * f + 1] / 255.0;
+        v = v < lo ? lo : (v > hi ? hi : v);
+        out[i] = v > 0.5 ? 1.f : 0.f;
     }
 }
 

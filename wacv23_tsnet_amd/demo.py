@@ -11,6 +11,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Sequence
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -90,51 +92,40 @@ RESIZE_NOTE = ("label maps resized by a restatement of skimage.transform.resize 
                "PARITY UNPINNED -- scikit-image is absent from this image, nothing to check the restatement against")
 
 
-def _mirror_index(i: torch.Tensor, n: int) -> torch.Tensor:
-    if n == 1:
-        return torch.zeros_like(i)
-    i = i.abs()
-    q, r = torch.div(i, n - 1, rounding_mode="floor"), torch.remainder(i, n - 1)
-    return torch.where(q % 2 == 1, (n - 1) - r, r)
+def _aa_kernel(n_in: int, n_out: int):
+    """scipy.ndimage.gaussian_filter1d's weights for skimage's anti-aliasing sigma, centre first -> (lw, doubles) or (-1, None)"""
+    sigma = max(0.0, (n_in / n_out - 1.0) / 2.0)
+    if sigma <= 1e-15:
+        return -1, None
+    lw = int(4.0 * sigma + 0.5)
+    k = np.arange(-lw, lw + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * k ** 2)
+    w = phi / phi.sum()
+    return lw, np.ascontiguousarray(w[lw:], dtype=np.float64)
 
 
-def resize_label(x: torch.Tensor, size=(256, 256)) -> torch.Tensor:
+def resize_label(x: torch.Tensor, size=(256, 256), lib=None) -> torch.Tensor:
     """(F,h,w) byte maps (0 / 255) -> (F,H,W) {0,1} floats: np.asarray(img_as_bool(resize(x, size))) of the reference's loaders
-    (dataset_video_face.py:104-106, 316-317, 397-398), restated from the published algorithm of scikit-image 0.18.3 -- anti-aliasing Gaussian
-    on the uint8 image (sigma = (in / out - 1) / 2, truncating cast, identity for crops below 320 pixels), bilinear sampling at
-    f (o + 0.5) - 0.5 with mirrored borders in float64, threshold 0.5.  PARITY UNPINNED (RESIZE_NOTE): the arithmetic mirrors
-    oracle/skimage_resize.py, which tests/test_resize.py holds it equal to, but neither can be run against scikit-image here."""
+    (dataset_video_face.py:104-106, 316-317, 397-398) through `tsnet_resize_label` -- restated from the published algorithm of scikit-image
+    0.18.3: anti-aliasing Gaussian on the uint8 image (sigma = (in / out - 1) / 2, truncating cast, identity for crops below 320 pixels),
+    bilinear sampling at f (o + 0.5) - 0.5 with mirrored borders in float64, threshold 0.5.  PARITY UNPINNED (RESIZE_NOTE): the kernels
+    follow oracle/skimage_resize.py, which tests/test_resize.py holds them equal to, but neither can be run against scikit-image here.
+    lib: tests pass the CPU emulation build; product code leaves it None (the in-tree HIP library, no fallback)."""
+    from . import _lib
+    lib = lib if lib is not None else _lib.load()
     F_, h, w = x.shape
     H, W = size
-    dev = x.device
-    work = x.to(torch.uint8)
-    for axis, (n_in, n_out) in ((1, (h, H)), (2, (w, W))):
-        sigma = max(0.0, (n_in / n_out - 1.0) / 2.0)
-        if sigma <= 1e-15:
-            continue
-        lw = int(4.0 * sigma + 0.5)
-        k = torch.arange(-lw, lw + 1, dtype=torch.float64)
-        wts = torch.exp(-0.5 / (sigma * sigma) * k * k)
-        wts = (wts / wts.sum()).to(dev)
-        src = work.to(torch.float64)
-        idx = torch.arange(n_in, device=dev)
-        acc = src * wts[lw]
-        for j in range(1, lw + 1):
-            acc = acc + (src.index_select(axis, _mirror_index(idx + j, n_in)) + src.index_select(axis, _mirror_index(idx - j, n_in))) * wts[lw + j]
-        work = acc.trunc().to(torch.uint8)
-    im = work.to(torch.float64) / 255.0
-    r = (h / H) * (torch.arange(H, dtype=torch.float64, device=dev) + 0.5) - 0.5
-    c = (w / W) * (torch.arange(W, dtype=torch.float64, device=dev) + 0.5) - 0.5
-    r0, c0, r1, c1 = r.floor(), c.floor(), r.ceil(), c.ceil()
-    dr, dc = (r - r0).view(1, H, 1), (c - c0).view(1, 1, W)
-    ir0, ir1 = _mirror_index(r0.long(), h), _mirror_index(r1.long(), h)
-    ic0, ic1 = _mirror_index(c0.long(), w), _mirror_index(c1.long(), w)
-    top = (1 - dc) * im[:, ir0][:, :, ic0] + dc * im[:, ir0][:, :, ic1]
-    bot = (1 - dc) * im[:, ir1][:, :, ic0] + dc * im[:, ir1][:, :, ic1]
-    out = (1 - dr) * top + dr * bot
-    lo, hi = im.amin(dim=(1, 2), keepdim=True), im.amax(dim=(1, 2), keepdim=True)
-    out = torch.minimum(torch.maximum(out, lo), hi)
-    return (out > 0.5).to(torch.float32)
+    src = x.to(torch.uint8).contiguous()
+    out = torch.empty((F_, H, W), dtype=torch.float32, device=src.device)
+    (lr, wr), (lc, wc) = _aa_kernel(h, H), _aa_kernel(w, W)
+    cuda = src.device.type == "cuda"
+    stream = torch.cuda.current_stream(src.device).cuda_stream if cuda else None
+    with (torch.cuda.device(src.device) if cuda else contextlib.nullcontext()):
+        rc = lib.tsnet_resize_label(src.data_ptr(), F_, h, w, H, W, wr.ctypes.data if wr is not None else None, lr,
+                                    wc.ctypes.data if wc is not None else None, lc, out.data_ptr(), stream)
+    if rc != 0:
+        raise RuntimeError(f"tsnet_resize_label failed ({rc}): {lib.tsnet_op_last_error().decode()}")
+    return out
 
 
 class ClipRunner:
