@@ -75,7 +75,7 @@ def test_conv_h2_tile_shapes_and_scales(emu_lib):
 def test_conv_h2d_stride2_patch_kernel(emu_lib):
     """3x3 / stride-2 layers whose output splits into 4 x 32 rectangles run on the patch kernel (conv_h2.hpp h2d): one, two and four slabs
     (stage parity), zero padding at all borders, with and without the fused IN + ReLU, two images / two tiles, both workgroup shapes
-    (four waves x 64 columns, eight waves x 128 columns) -- bit-identical to each other"""
+    (four waves x 64 columns, eight waves x 128 columns, four waves x two rows x 128 columns) -- bit-identical to each other"""
     import torch
     for cin in (16, 32, 64):
         assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, cin, 128, 3, norm=True, seed=cin, kernel=2) < REL
@@ -83,7 +83,9 @@ def test_conv_h2d_stride2_patch_kernel(emu_lib):
     assert oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 128, 16, 320, 3, norm=True, kernel=2, tile=64) < REL      # five N-tiles, two M-tiles
     a = oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, 32, 256, 3, norm=True, kernel=2, tile=64, return_output=True)
     b = oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, 32, 256, 3, norm=True, kernel=2, tile=128, return_output=True)
-    assert torch.equal(a, b)
+    c = oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, 32, 256, 3, norm=True, kernel=2, tile=2128, return_output=True)       # two rows x 128, four waves
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert oc.conv_h2r_case(emu_lib, "cpu", 2, 12, 64, 48, 128, 3, norm=True, kernel=2, tile=2128) < REL     # six output rows: three 2-row tiles per image
 
 
 def test_conv_h2s_stem_patch_kernel(emu_lib):

@@ -137,7 +137,7 @@ def test_conv_h2_two_k_groups(lib):
 
 def test_conv_h2d_downsampling_layers(lib):
     """the encoder's three stride-2 layers at their real shapes on the patch kernel (conv_h2.hpp h2d), explicitly selected (kernel = 2): the
-    four-wave / 64-column and the eight-wave / 128-column workgroups, which are bit-identical to each other.  Against the general kernel on
+    four-wave / 64-column, the eight-wave / 128-column and the four-wave / two-row x 128-column workgroups, which are bit-identical to each other.  Against the general kernel on
     the same layer only agreement to rounding is expected -- it visits the K chunks tap-major, the patch kernel slab-major."""
     import torch
     assert oc.conv_h2r_case(lib, DEV, 2, 256, 256, 64, 128, 3, norm=True, kernel=2) < REL
@@ -146,7 +146,10 @@ def test_conv_h2d_downsampling_layers(lib):
     assert oc.conv_h2r_case(lib, DEV, 4, 64, 64, 256, 512, 3, norm=True, kernel=2, tile=64) < REL
     a = oc.conv_h2r_case(lib, DEV, 2, 64, 64, 256, 512, 3, norm=True, kernel=2, tile=64, return_output=True)
     b = oc.conv_h2r_case(lib, DEV, 2, 64, 64, 256, 512, 3, norm=True, kernel=2, tile=128, return_output=True)
-    assert torch.equal(a, b)
+    c = oc.conv_h2r_case(lib, DEV, 2, 64, 64, 256, 512, 3, norm=True, kernel=2, tile=2128, return_output=True)      # two rows x 128: the forward's shape
+    d = oc.conv_h2r_case(lib, DEV, 2, 64, 64, 256, 512, 3, norm=True, kernel=2, return_output=True)                 # the launcher's own choice
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    assert oc.conv_h2r_case(lib, DEV, 4, 128, 128, 128, 256, 3, norm=True, kernel=2, tile=2128) < REL
     g = oc.conv_h2r_case(lib, DEV, 2, 64, 64, 256, 512, 3, norm=True, kernel=1, return_output=True)
     assert not torch.equal(a, g) and (a - g).abs().max().item() < 1e-4 * a.abs().max().item()
     assert oc.conv_h2r_case(lib, DEV, 2, 64, 64, 256, 512, 3, norm=True, kernel=1) < REL

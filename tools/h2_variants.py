@@ -15,10 +15,10 @@ torch.zeros(1, device="cuda")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 
 
-def code(tile=0, general=False, abl=0, opt=0, xcd=None):
+def code(tile=0, general=False, abl=0, opt=0, xcd=None, patch=False):
     """xcd: None = the launcher's choice, 0 = consecutive tiles per XCD, 1 / 2 / 4 / 8 = columns of the XCD grid over the N tiles"""
     gx = 0 if xcd is None else (1 if xcd == 0 else {1: 2, 2: 3, 4: 4, 8: 5}[xcd])
-    return tile | (4096 if general else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | (gx << 28)
+    return tile | (4096 if general else 0) | (16384 if patch else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | (gx << 28)
 
 
 def run(name, shape, variants, norms=(0, 1), iters=8):
@@ -42,6 +42,21 @@ def run(name, shape, variants, norms=(0, 1), iters=8):
 
 SEL = sys.argv[2] if len(sys.argv) > 2 else "all"
 RES = (12, 32, 32, 512, 512, 3, 1, 1, 1)
+if SEL == "down":       # stride-2 shapes
+    for nm, shp in (("down1 (64->128)", (12, 256, 256, 64, 128, 3, 2, 1, 0)), ("down2 (128->256)", (12, 128, 128, 128, 256, 3, 2, 1, 0)),
+                    ("down3 (256->512)", (12, 64, 64, 256, 512, 3, 2, 1, 0)), ("down2 B=8", (24, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 B=8", (24, 64, 64, 256, 512, 3, 2, 1, 0)),
+                    ("down2 target chain (4 images)", (4, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 target chain (4 images)", (4, 64, 64, 256, 512, 3, 2, 1, 0)),
+                    ("down3 one frame (3 images)", (3, 64, 64, 256, 512, 3, 2, 1, 0))):
+        run(nm, shp, [("h2d 4 waves x 64", code(64, patch=True)), ("h2d 8 waves x 128", code(128, patch=True)), ("h2d 2 rows x 128", code(2128, patch=True)),
+                      ("general 128", code(128, general=True)), ("the layer's own", code(0))], norms=(1,))
+    sys.exit(0)
+if SEL == "downsmall":  # stride-2 shapes of a single frame
+    for nm, shp in (("down2 one frame (3 images)", (3, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 one frame (3 images)", (3, 64, 64, 256, 512, 3, 2, 1, 0)),
+                    ("down2 1 image", (1, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 1 image", (1, 64, 64, 256, 512, 3, 2, 1, 0)),
+                    ("down2 2 frames (6 images)", (6, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 2 frames (6 images)", (6, 64, 64, 256, 512, 3, 2, 1, 0))):
+        run(nm, shp, [("h2d 4 waves x 64", code(64, patch=True)), ("h2d 8 waves x 128", code(128, patch=True)), ("h2d 2 rows x 128", code(2128, patch=True)),
+                      ("the layer's own", code(0))], norms=(1,))
+    sys.exit(0)
 if SEL == "chain":      # one accumulation chain per slab (27 MFMAs) instead of two (12 + 15): half the folds
     run("res", RES, [("4x64", code(64)), ("4x64 slab-chain", code(64, opt=4)), ("4x128", code(128)), ("4x128 slab-chain", code(128, opt=4))])
     run("fuse_c2", (12, 32, 32, 1024, 1024, 3, 1, 1, 1), [("4x128", code(128)), ("4x128 slab-chain", code(128, opt=4))])

@@ -491,26 +491,30 @@ void conv_h2s_kernel(ConvArgs a) {
 // NW = 4: 128 x 64 tile, waves 2 (M) x 2 (N), five staging rounds per slab.  NW = 8 (512 threads): 128 x 128 tile, waves 2 (M) x 4 (N)
 // with the SAME 64 x 32 wave tile -- one patch shared by eight waves (a four-wave 128-wide tile needs a 64 x 64 wave tile, which does not
 // fit the register file next to the five-round staging): half the staging work and half the L2 -> L1 activation traffic per MFMA, three
-// staging rounds per slab.  K order, chains and fold points are h2_tile's in both shapes: bit-identical results.
-template <int BN, int NWV, int NPROD, bool AFFINE>
+// staging rounds per slab.  Both 4-row shapes hold 80 KiB of LDS (two stages of a 9 x 68-slot patch): ONE workgroup per CU, two waves per
+// SIMD -- their MFMA pipe is 0.20 busy.  PR = 2 (NW = 4, BN = 128): a 2 x 32 output rectangle, waves 1 (M) x 4 (N), patch 5 x 65: 44 KiB and
+// 168 VGPRs -> THREE workgroups per CU (twelve waves), three staging rounds; 11 % more patch pixels per output than the 4-row tile.
+// K order, chains and fold points are h2_tile's in every shape: bit-identical results.
+template <int BN, int NWV, int NPROD, bool AFFINE, int PR = kPatchRows>
 __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_raw, const int tile_m, const int n0) {
-    constexpr int BM = kPatchRows * kPatchCols;
-    constexpr int WARPS_M = 2, WARPS_N = NWV / 2;
-    static_assert(NWV == 4 || NWV == 8, "four or eight waves, two output rows per wave");
+    constexpr int BM = PR * kPatchCols;
+    constexpr int WARPS_M = PR / 2, WARPS_N = NWV / WARPS_M;
+    static_assert((NWV == 4 || NWV == 8) && (PR == 2 || PR == 4), "four or eight waves, two output rows per wave");
     static_assert(NPROD == 1 || NPROD == 3, "one (bf16 operands) or three products");
     constexpr int NPL = NPROD == 1 ? 1 : 2;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 32, NTL = WN / 32;
     static_assert(MT == 2 && NTL == 1, "wave tile 64 x 32");
-    constexpr int PCI = 2 * kPatchCols + 1, PRI = 2 * kPatchRows + 1, PP = PRI * PCI;     // 65 x 9 = 585 patch pixels
+    constexpr int PCI = 2 * kPatchCols + 1, PRI = 2 * PR + 1, PP = PRI * PCI;              // 65 x 9 = 585 (65 x 5 = 325) patch pixels
     constexpr int RP = 68, ODD0 = 36;                                // row pitch in slots: 33 even columns, pad, 32 odd columns from slot 36 on: the 8 lanes of a
                                                                      // ds_write_b128 group (4 even + 4 odd pixels) then hit disjoint banks (36 * 16 B = 16 banks mod 32)
     constexpr int REGION = PRI * RP * 16;                            // one octet region: 594 slots x 16 B
     constexpr int PLANE_P = 2 * REGION, PATCH_BYTES = NPL * PLANE_P;
     constexpr int OFF_SINK = 2 * 2 * PLANE_P;                        // 2 KiB sink for pixel slots that do not exist (branch-free staging)
     constexpr int OFF_TAB = OFF_SINK + 2048;
-    constexpr int NBLK = (PP + 31) / 32;                             // 19 blocks of 32 pixels
-    constexpr int NR = (NBLK + NWV - 1) / NWV;                       // staging rounds: 5 (four waves) or 3 (eight waves)
+    constexpr int NBLK = (PP + 31) / 32;                             // 19 (11) blocks of 32 pixels
+    constexpr int NR = (NBLK + NWV - 1) / NWV;                       // staging rounds: 5 (four waves, four rows) or 3 (eight waves; two rows)
+    static_assert(NR == 5 || NR == 3, "staging schedules exist for five and three rounds");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -519,9 +523,9 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     const int wn0 = (wave % WARPS_N) * WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int tcols = a.Wo / kPatchCols, tper = (a.Ho / kPatchRows) * tcols;
+    const int tcols = a.Wo / kPatchCols, tper = (a.Ho / PR) * tcols;
     const int img = tile_m / tper, tin = tile_m - img * tper;
-    const int oy0 = (tin / tcols) * kPatchRows, ox0 = (tin % tcols) * kPatchCols;
+    const int oy0 = (tin / tcols) * PR, ox0 = (tin % tcols) * kPatchCols;
     const int ncc = a.Cin >> 4;
     float in_scale = a.in_scale, in_unscale = a.in_unscale;
     if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax + img, a.in_bound_add, in_scale, in_unscale);
@@ -700,15 +704,16 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
                                                  [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
 }
 
-constexpr int kH2dLds = 2 * 2 * 2 * (2 * kPatchRows + 1) * 68 * 16 + 2048;      // two stages x two planes x two octet regions + sink (+ 2 Cin floats x 2 of the table)
+// two stages x two planes x two octet regions + sink (+ 2 Cin floats x 2 of the table, added by the launcher)
+constexpr int h2d_lds_bytes(int PR) { return 2 * 2 * 2 * (2 * PR + 1) * 68 * 16 + 2048; }
 
-template <int BN, int NWV, int NPROD, bool AFFINE>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 3 : 2)             // eight waves: 1.5 workgroups = three waves per SIMD
+template <int BN, int NWV, int NPROD, bool AFFINE, int PR = kPatchRows>
+__global__ __launch_bounds__(64 * NWV, (NWV == 8 || PR == 2) ? 3 : 2)  // waves per SIMD: eight waves = 1.5 workgroups' worth; two rows: three workgroups of four
 void conv_h2d_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     const int bid = xcd_item(blockIdx.x, a.tiles_m * a.tiles_n);
     const int tile_m = bid / a.tiles_n;
-    h2d_tile<BN, NWV, NPROD, AFFINE>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+    h2d_tile<BN, NWV, NPROD, AFFINE, PR>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
 }
 
 }  // namespace tsnet

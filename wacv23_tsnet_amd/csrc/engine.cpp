@@ -202,13 +202,17 @@ inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool t
     const int Ho = (H + 2 * L.pad - L.ks) / L.stride + 1, Wo = (W + 2 * L.pad - L.ks) / L.stride + 1;
     const bool s1 = L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H >= 2 && W >= 2;
     if (two_sources || Ho <= 0 || Wo <= 0 || Wo % kPatchCols) return K_GENERAL;
-    if (s1 && rows == 2 && Ho % 2 == 0) return K_H2;             // an explicitly requested 2-row tile (op tests, tools)
+    const bool s2 = L.ks == 3 && L.stride == 2 && L.pad == 1 && !L.reflect && L.cin_pad >= (eligible_only ? 16 : 128) && (L.cin_pad & 15) == 0 && H == 2 * Ho && W == 2 * Wo;
+    if (rows == 2 && Ho % 2 == 0) {                              // a 2-row tile (requested explicitly, or the stride-2 layers' own choice)
+        if (s1) return K_H2;
+        if (s2) return K_H2D;
+    }
     if (Ho % kPatchRows) return K_GENERAL;
     if (s1) return K_H2;
     if (L.ks == 7 && L.stride == 1 && L.pad == 3 && L.reflect && L.cin_pad == 8 && !transform && H >= 4 && W >= 4) return K_H2S;
     // stride 2: the patch kernel from 128 input channels on (117 / 125 us on the 128 -> 256 / 256 -> 512 layers against 132 / 142 us for the
     // general kernel); with 64 channels the K loop is four slabs long and the general kernel's smaller per-tile prologue wins (147 vs 157 us)
-    if (L.ks == 3 && L.stride == 2 && L.pad == 1 && !L.reflect && L.cin_pad >= (eligible_only ? 16 : 128) && (L.cin_pad & 15) == 0 && H == 2 * Ho && W == 2 * Wo) return K_H2D;
+    if (s2) return K_H2D;
     return K_GENERAL;
 }
 
@@ -304,13 +308,16 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
             launch_conv_h2s(g, c.nprod, ctx.stream);
             ++g_launch_counters[0];
         } else if (cls == K_H2D) {
-            // eight waves x 128 columns from 128 such tiles on; below that the four-wave x 64 shape has twice the workgroups (one frame:
-            // 24 vs 32 us on 128 -> 256, 47 vs 58 us on 256 -> 512; bit-identical shapes)
-            const long t128 = (long)c.N * (hw / 128) * ((g.Cout + 127) / 128);
-            int bn = c.tile ? c.tile : ((g.Npad % 128 == 0 && g.Cout > 64 && t128 >= 128) ? 128 : 64);
+            // two rows x 128 columns (four waves, 44 KiB of LDS: three workgroups per CU) wherever the layer is 128 channels wide: 125 -> 99 us
+            // on 256 -> 512, 117 -> 109 us on 128 -> 256 at batch 4, equal or better down to one frame (profiles/round3_conv_variants.txt);
+            // the four-row shapes hold 80 KiB and run one workgroup per CU
+            int pr = 4, bn = c.tile ? c.tile % 1000 : 64;
+            if (c.tile >= 1000) pr = c.tile / 1000;
+            if (!c.tile && g.Npad % 128 == 0 && g.Cout > 64 && g.Ho % 2 == 0) { pr = 2; bn = 128; }
             if (g.Npad % bn) throw ArgError("conv(h2d): the tile width must divide the padded output width");
-            set_tiles(128, bn);
-            launch_conv_h2d(g, bn, c.nprod, ctx.stream);
+            if (g.Ho % pr) throw ArgError("conv(h2d): the output height must be a multiple of the tile's rows");
+            set_tiles(pr * kPatchCols, bn);
+            launch_conv_h2d(g, pr, bn, c.nprod, ctx.stream);
             ++g_launch_counters[0];
         } else {
             if (c.abl || c.opt) throw ArgError("conv: experiment variants exist for the 3x3 / stride-1 patch kernel only");
@@ -1581,7 +1588,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     if (iters < 1 || !ms_out) throw ArgError("bench_conv: bad argument");
     hipStream_t s = (hipStream_t)stream;
     Ctx ctx; ctx.stream = s;
-    // variant (-1 = the layer's own kernel and tile): bits 0-11 tile code (ConvCall::tile), bit 12 general kernel, bit 13 bf16 operands,
+    // variant (-1 = the layer's own kernel and tile): bits 0-11 tile code (ConvCall::tile), bit 12 general kernel, bit 13 bf16 operands, bit 14 patch kernel,
     // bits 16-22 ablation mask, bit 23 two K groups, bits 24-27 experiment mask (8 = deep prefetch; the rest tools build), bits 28-30 XCD grid
     const int v = variant < 0 ? 0 : variant;
     const int nprod = (v & 8192) ? 1 : 3;
@@ -1602,7 +1609,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     {
         OpLayer op(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s);
         ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = norm ? 64.f : 1.f; c.nprod = nprod;
-        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : 0; c.abl = (v >> 16) & 127; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0);
+        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 127; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0);
         { const int gx = (v >> 28) & 7; c.xcd_gn = gx == 0 ? -1 : (gx == 1 ? 0 : 1 << (gx - 2)); }          // bits 28-30: 0 default, 1 linear, 2..5 grid with 1, 2, 4, 8 columns
         if (norm) { c.alpha = al; c.beta = be; c.relu = 1; }
         for (int i = 0; i < 2; ++i) run_conv(ctx, op.L, c);

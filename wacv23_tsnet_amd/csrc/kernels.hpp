@@ -14,7 +14,7 @@ namespace tsnet {
 //   h2d (3x3 / stride 2): bn = 64 (four waves) or 128 (eight waves)
 void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int opt, hipStream_t s);
 void launch_conv_h2s(const ConvArgs& a, int nprod, hipStream_t s);
-void launch_conv_h2d(const ConvArgs& a, int bn, int nprod, hipStream_t s);
+void launch_conv_h2d(const ConvArgs& a, int pr, int bn, int nprod, hipStream_t s);
 // conv_h2r.hpp -- general implicit GEMM: ks in {1, 3, 7}, bn = 64 (any) or 128 (ks = 3, Cin >= 16); Cin = 8 or a power of two >= 16
 void launch_conv_h2r(const ConvArgs& a, int ks, int bn, int nprod, hipStream_t s);
 
