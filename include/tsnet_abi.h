@@ -151,8 +151,10 @@ int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64
  *   kernel: 0 = the kernel the forward runs this layer on at this frame size (patch kernels of conv_h2.hpp where the output splits into
  *   4 x 32 rectangles: 3x3 / stride 1, 3x3 / stride 2 / zero pad, 7x7 stem with 8 input channels; the general implicit GEMM of conv_h2r.hpp
  *   elsewhere), 1 = the general kernel, 2 = the patch kernel (error if the layer has none).
- *   tile: 0 = the launcher's choice; patch 3x3 / stride 1: 32, 64, 128 (4-row tiles) or 2128 (2 rows x 128); others: 64 or 128.
- *   All tiles of one kernel produce identical bits (tested); patch and general kernels sum K in different orders.
+ *   tile: 0 = the launcher's choice; patch 3x3 / stride 1: 32, 64, 128 (4-row tiles), 2128 (2 rows x 128), 20032 / 20064 (the two-K-group
+ *   tiles a single-frame forward runs); patch 3x3 / stride 2: 64, 128 (4 rows) or 2128 (2 rows x 128: the forward's shape); others: 64 or 128.
+ *   All one-group tiles of one kernel produce identical bits, and so do the two two-group tiles among themselves (tested); the two-group
+ *   tiles, and patch vs general kernels, sum K in another association / order: agreement to fp32 rounding.
  * tsnet_op_conv2d_cat <- the same on torch.cat((x, x2), channel axis) formed on load (dec.map_conv on cat(pg, sg), TSNet.py:163):
  *   x (N,H,W,C1), x2 (x2_nmod,H,W,C2) read at image n % x2_nmod; C1 a multiple of 16.  No input transform.
  * tsnet_op_head <- the decoder's RGB head: ReflectionPad2d(3) + Conv2d(C -> 3, 7x7) + bias + Tanh (TSNet.py:151-152) on relu(alpha*x+beta),
