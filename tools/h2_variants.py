@@ -2,8 +2,9 @@
 
 Per layer shape, every variant is timed in interleaved rounds inside ONE process (cdna_hip_programming.md rule 24) and the median
 reported.  variant code of tsnet_bench_conv: tile | general kernel << 12 | ablation mask << 16 | experiment mask << 24 | XCD grid << 28.
-  experiment mask (h2_tile OPT): 1 = legacy staging arithmetic (select + scalar converts), 2 = rotating wave priority, 4 = one accumulation
-    chain per slab, 8 = deep weight prefetch, 16 = two K groups per tile (24 = the product's single-frame tiles)
+  experiment mask (h2_tile OPT): 2 = one accumulation chain per slab, 4 = one per four slabs (the product: one per two), 8 = deep weight
+    prefetch, 16 = two K groups per tile (24 = the product's single-frame tiles), 32 = weights five steps ahead, 64 = launch bounds for four
+    workgroups per CU
   ablation mask  (h2_tile HABL, computes garbage): 1 no patch staging, 2 weights once, 4 A fragments once, 8 no fold, 16 no barrier
 usage: h2_variants.py [rounds] [all | xcd | small | kg | chain]"""
 import ctypes as C, os, statistics, sys
@@ -18,7 +19,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 def code(tile=0, general=False, abl=0, opt=0, xcd=None, patch=False):
     """xcd: None = the launcher's choice, 0 = consecutive tiles per XCD, 1 / 2 / 4 / 8 = columns of the XCD grid over the N tiles"""
     gx = 0 if xcd is None else (1 if xcd == 0 else {1: 2, 2: 3, 4: 4, 8: 5}[xcd])
-    return tile | (4096 if general else 0) | (16384 if patch else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | (gx << 28)
+    return tile | (4096 if general else 0) | (16384 if patch else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | ((1 << 22) if opt & 32 else 0) | ((1 << 21) if opt & 64 else 0) | (gx << 28)
 
 
 def run(name, shape, variants, norms=(0, 1), iters=8):
@@ -57,9 +58,14 @@ if SEL == "downsmall":  # stride-2 shapes of a single frame
         run(nm, shp, [("h2d 4 waves x 64", code(64, patch=True)), ("h2d 8 waves x 128", code(128, patch=True)), ("h2d 2 rows x 128", code(2128, patch=True)),
                       ("the layer's own", code(0))], norms=(1,))
     sys.exit(0)
-if SEL == "chain":      # one accumulation chain per slab (27 MFMAs) instead of two (12 + 15): half the folds
-    run("res", RES, [("4x64", code(64)), ("4x64 slab-chain", code(64, opt=4)), ("4x128", code(128)), ("4x128 slab-chain", code(128, opt=4))])
-    run("fuse_c2", (12, 32, 32, 1024, 1024, 3, 1, 1, 1), [("4x128", code(128)), ("4x128 slab-chain", code(128, opt=4))])
+if SEL == "chain":      # slabs per accumulation chain: 1, 2 (product), 4; and the ablations of the 4 x 64 tile
+    run("res", RES, [("4x64 chain 2 (product)", code(64)), ("4x64 chain 1", code(64, opt=2)), ("4x64 chain 4", code(64, opt=4)),
+                     ("4x64 weights 5 ahead", code(64, opt=32)), ("4x64 chain 4 + 5 ahead", code(64, opt=36)), ("2x128 weights 5 ahead", code(2128, opt=32)),
+                     ("4x128 chain 2 (product)", code(128)), ("4x128 chain 1", code(128, opt=2)), ("4x128 chain 4", code(128, opt=4)), ("2x128", code(2128))])
+    run("res ablations 4x64", RES, [("full", code(64))] + [(f"abl{m}", code(64, abl=m)) for m in (1, 2, 4, 7, 8, 16)], norms=(0,))
+    run("fuse_c2", (12, 32, 32, 1024, 1024, 3, 1, 1, 1), [("4x128 chain 2 (product)", code(128)), ("4x128 chain 1", code(128, opt=2)), ("4x128 chain 4", code(128, opt=4)), ("4x64", code(64))])
+    run("fuse_c1_src (512->1024)", (12, 32, 32, 512, 1024, 3, 1, 1, 1), [("4x64", code(64)), ("4x128", code(128))], norms=(0,))
+    run("dec_up0 (512->256 @64^2)", (4, 64, 64, 512, 256, 3, 1, 1, 1), [("4x64", code(64)), ("4x128", code(128))], norms=(0,))
     sys.exit(0)
 if SEL == "kg":         # two K groups per tile (eight waves, one workgroup per CU) against the co-resident four-wave workgroups
     for nm, n in (("res B=4 (12 images)", 12), ("res B=2 (6 images)", 6), ("res B=1 (3 images)", 3), ("res clip (1 image)", 1), ("res B=8 (24 images)", 24)):
@@ -99,14 +105,14 @@ if SEL in ("all", "xcd"):
 if SEL == "xcd":
     sys.exit(0)
 run("res (ResnetBlock conv, B=4 K=3)", RES,
-    [("4x64", code(64)), ("4x64 legacy-staging", code(64, opt=1)), ("4x64 prio", code(64, opt=2)), ("4x64 legacy+prio", code(64, opt=3)),
-     ("4x128", code(128)), ("4x128 legacy-staging", code(128, opt=1)), ("2x128", code(2128)), ("2x128 prio", code(2128, opt=2)), ("4x32", code(32))])
+    [("4x64", code(64)), ("4x64 chain 1", code(64, opt=2)), ("4x64 chain 4", code(64, opt=4)),
+     ("4x128", code(128)), ("2x128", code(2128)), ("4x32", code(32))])
 run("res ablations 4x64", RES,
     [("full", code(64))] + [(f"abl{m}", code(64, abl=m)) for m in (1, 2, 4, 7, 8, 16, 15, 31)], norms=(0,))
 run("res ablations 2x128", RES, [("full", code(2128))] + [(f"abl{m}", code(2128, abl=m)) for m in (1, 2, 7)], norms=(0,))
 run("res B=1 (3 images)", (3, 32, 32, 512, 512, 3, 1, 1, 1), [("4x32", code(32)), ("4x64", code(64)), ("2x128", code(2128))])
 run("fuse_c2 (1024->1024)", (12, 32, 32, 1024, 1024, 3, 1, 1, 1),
-    [("4x64", code(64)), ("4x128", code(128)), ("4x128 legacy-staging", code(128, opt=1)), ("2x128", code(2128)), ("2x128 prio", code(2128, opt=2))])
+    [("4x64", code(64)), ("4x128", code(128)), ("2x128", code(2128))])
 run("fuse_c1_src (512->1024)", (12, 32, 32, 512, 1024, 3, 1, 1, 1), [("4x64", code(64)), ("4x128", code(128)), ("2x128", code(2128))], norms=(0,))
 run("dec_up0 (512->256 @64^2)", (4, 64, 64, 512, 256, 3, 1, 1, 1), [("4x64", code(64)), ("4x128", code(128)), ("2x128", code(2128))], norms=(0,))
 run("dec_up1 (256->128 @128^2)", (4, 128, 128, 256, 128, 3, 1, 1, 1), [("4x64", code(64)), ("4x128", code(128)), ("2x128", code(2128))], norms=(0,))

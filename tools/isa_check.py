@@ -61,7 +61,9 @@ def analyse(asm_path, pattern=""):
 
 def compile_asm(tools=False):
     tmp = tempfile.mkdtemp(prefix="tsnet_isa_")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps", "-I" + os.path.join(ROOT, "include")]
+    sys.path.insert(0, ROOT)
+    from wacv23_tsnet_amd import build as B          # the library's own flags: the ISA looked at is the ISA that ships
+    cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + B.UNIT_FLAGS.get("conv_h2_launch.cpp", []) + ["-save-temps", "-I" + os.path.join(ROOT, "include")]
     if tools:
         cmd.append("-DTSNET_TOOLS")
     cmd += ["-c", os.path.join(ROOT, "wacv23_tsnet_amd", "csrc", "conv_h2_launch.cpp"), "-o", os.path.join(tmp, "x.o")]

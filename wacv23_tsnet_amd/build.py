@@ -26,6 +26,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
          "-fhip-fp32-correctly-rounded-divide-sqrt",   # IEEE / and sqrt: the /255, F.normalize and softmax divisions
          "-ffp-contract=off",                           # FMAs only where the source asks for them (fmaf)
          "-mllvm", "-amdgpu-mfma-vgpr-form"]            # MFMA C/D in VGPRs: no AGPR<->VGPR copies around the K loop
+# per-unit extras.  The patch convolutions fold accumulator registers with plain fp32 adds; the SLP vectoriser pairs them into
+# v_pk_add_f32, which beside MFMAs costs more than the two v_add_f32 it replaces (MI355X_MICROARCH.md, "price of one filler")
+UNIT_FLAGS = {"conv_h2_launch.cpp": ["-fno-slp-vectorize"]}
 
 
 def _deps():
@@ -51,7 +54,7 @@ def _build(out: str, extra, verbose: bool) -> str:
 
     def one(unit):
         obj = os.path.join(obj_dir, unit.replace(".cpp", ".o"))
-        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, unit), "-o", obj]
+        cmd = [hipcc] + FLAGS + UNIT_FLAGS.get(unit, []) + extra + ["-c", os.path.join(CSRC, unit), "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

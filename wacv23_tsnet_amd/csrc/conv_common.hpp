@@ -182,15 +182,19 @@ __device__ __forceinline__ void bf16_octet(const F4& x0, const F4& x1, F4& H) {
 // fl(x*(al*s) + be*s) == s * fl(x*al + be)), ReLU, zero padding re-imposed AFTER the transform (a padded pixel is zero in the conv's
 // input, not beta: keep = 0 there, 1 elsewhere); without a producer InstanceNorm: t = x*s (a padded slot loaded zeros).
 // Branch-free on purpose (relu_floor = 0 or -inf): a wave-uniform branch here would cut the unrolled K loop into basic blocks, and the
-// register allocator then spills across them.
-template <bool AFFINE>
+// register allocator then spills across them.  KEEP = false: the layer pads by reflection (every staged slot is a real pixel; slots
+// past the patch are never read), so the multiply is dropped -- x * 1.0f is exact, the results are the same bits either way.
+template <bool AFFINE, bool KEEP = true>
 __device__ __forceinline__ void transform_octet(const F4 (&sx)[2], const float* ta, int Cin, float in_scale, float relu_floor, float keep, F4 (&t)[2]) {
     if (AFFINE) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const F4 al = *reinterpret_cast<const F4*>(ta + q * 4), be = *reinterpret_cast<const F4*>(ta + Cin + q * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[q].v[e] = __builtin_fmaxf(__builtin_fmaf(sx[q].v[e], al.v[e], be.v[e]), relu_floor) * keep;
+            for (int e = 0; e < 4; ++e) {
+                const float v = __builtin_fmaxf(__builtin_fmaf(sx[q].v[e], al.v[e], be.v[e]), relu_floor);
+                t[q].v[e] = KEEP ? v * keep : v;
+            }
         }
     } else {
 #pragma unroll

@@ -30,10 +30,12 @@ namespace tsnet {
 //   4 x 128 (2 x 2, 64 x 64)   half the LDS / L1 bytes per MFMA, two workgroups per CU (FuseNet, decoder)
 //   4 x 32  (4 x 1, 32 x 32)   launches with few tiles (one driving frame)
 //   2 x 128 (1 x 4, 64 x 32)   the patch is staged once per 128 instead of 64 output channels (0.67 x the staging work per MFMA)
-// OPT: bits 3 + 4 = DEEP prefetch with two K groups (24: the single-frame tiles of the product).  Tools build only (tools/h2_variants.py):
-// bit 0 legacy staging arithmetic (select / scalar converts; for the A/B), bit 1 rotating wave priority, bit 2 one accumulation chain
-// per slab instead of two, bits 3 / 4 alone.  HABL (tools/h2_variants.py; non-zero computes garbage): bit0 no patch staging in the loop, bit1
-// weight fragments loaded once, bit2 A fragments read once, bit3 no fold, bit4 no slab barrier.
+// OPT: bit 0 = the layer zero-pads an InstanceNorm-ed input (the padded pixels are re-zeroed after the affine transform; reflection
+// needs no such multiply); bits 3 + 4 = DEEP prefetch with two K groups (24: the single-frame tiles of the product).  Tools build only
+// (tools/h2_variants.py): bit 1 = one chain per slab, bit 2 = one chain per four slabs (the product folds every two), bits 3 / 4 alone,
+// bit 5 = weight fragments five steps ahead (six register sets).
+// HABL (tools/h2_variants.py; non-zero computes garbage): bit0 no patch staging in the loop, bit1 weight fragments loaded once, bit2 A
+// fragments read once, bit3 no fold, bit4 no slab barrier.
 template <int PR, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int HABL = 0, int OPT = 0>
 __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_raw, const int tile_m, const int n0) {
     constexpr int BM = PR * kPatchCols;
@@ -42,13 +44,16 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     static_assert(NPROD == 1 || NPROD == 3 || NPROD == 4, "one (bf16 operands), three or four products");
     constexpr int NPL = NPROD == 1 ? 1 : 2;                          // operand planes
     constexpr bool DEEP = (OPT & 8) != 0;
-    constexpr int BD = DEEP ? 9 : 3;                                 // weight register sets: fragments are fetched BD - 1 steps ahead
+    constexpr int BD = DEEP ? 9 : ((OPT & 32) ? 6 : 3);              // weight register sets: fragments are fetched BD - 1 steps ahead (3, 6, 9: divisors of the 18 steps of a slab pair)
     constexpr bool ONE_LEVEL = NPROD == 1;                            // bf16 operands (2^-9 each): one fp32 chain over all of K -- the second
                                                                      // level buys nothing below the operand rounding and costs 16 VGPRs per tile
+    constexpr bool ZPAD_KEEP = (OPT & 1) != 0;
+    constexpr int CH = (OPT & 2) ? 1 : ((OPT & 4) ? 4 : 2);          // slabs per accumulation chain
     constexpr int KG = (OPT & 16) ? 2 : 1;                           // K groups: 4 KG waves, group g runs the slabs g, g + KG, ... of the tile
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 32, NTL = WN / 32;
     static_assert(WARPS_M * MT == PR, "a wave covers MT whole patch rows");
+    constexpr int NRW = MT + 2;                                      // patch rows under a wave's MT output rows
     constexpr int PC = kPatchCols + 2, PP = (PR + 2) * PC;           // 34 columns; 204 (PR = 4) or 136 (PR = 2) patch pixels
     constexpr int PBLK = (PP + 31) / 32;                             // 7 / 5 blocks of 32 pixel slots
     static_assert(PBLK <= 8, "two staging rounds");
@@ -122,76 +127,44 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
 #pragma unroll
         for (int q = 0; q < 2; ++q) sx[r][q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(slab_of(cn) * 64 + q * 16));
     };
-    auto stage_store = [&](int cn, int r) __attribute__((always_inline)) {
+    // par = stage the slab is written to (its local index & 1, a compile-time constant at every call site)
+    auto stage_store = [&](int cn, int par, int r) __attribute__((always_inline)) {
         const int b = wave + 4 * r;
         F4 t[2];
         const float* ta = tab + (slab_of(cn) < ncc ? slab_of(cn) * 16 : 0) + oct * 8;   // past the last slab: any valid entry (result unused)
-        if (OPT & 1) {
-            if (AFFINE) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const F4 al = *reinterpret_cast<const F4*>(ta + q * 4), be = *reinterpret_cast<const F4*>(ta + a.Cin + q * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = __builtin_fmaf(sx[r][q].v[e], al.v[e], be.v[e]);
-                        v = v > relu_floor ? v : relu_floor;
-                        t[q].v[e] = v * vM[r];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = sx[r][q].v[e] * in_scale;
-                        t[q].v[e] = v > relu_floor ? v : relu_floor;
-                    }
-            }
-        } else {
-            transform_octet<AFFINE>(sx[r], ta, a.Cin, in_scale, relu_floor, vM[r], t);
-        }
+        transform_octet<AFFINE, ZPAD_KEEP>(sx[r], ta, a.Cin, in_scale, relu_floor, vM[r], t);
         // a block past the patch does not exist: its wave writes into the sink (wave-uniform select, no branch)
-        unsigned char* dst = gbase + (b < PBLK ? (cn & 1) * PATCH_BYTES + oct * REGION + b * 512 : OFF_SINK + oct * 512) + (lane & 31) * 16;
+        unsigned char* dst = gbase + (b < PBLK ? par * PATCH_BYTES + oct * REGION + b * 512 : OFF_SINK + oct * 512) + (lane & 31) * 16;
         F4 Hh, Ll;
         if (NPROD == 1) {
             bf16_octet(t[0], t[1], Hh);
             *reinterpret_cast<F4*>(dst) = Hh;
         } else {
-            if (OPT & 1) {
-                unsigned h[8], l[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { split_h2(t[0].v[e], h[e], l[e]); split_h2(t[1].v[e], h[4 + e], l[4 + e]); }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    Hh.v[e] = __builtin_bit_cast(float, h[2 * e] | (h[2 * e + 1] << 16));
-                    Ll.v[e] = __builtin_bit_cast(float, l[2 * e] | (l[2 * e + 1] << 16));
-                }
-            } else {
-                split_h2_octet(t[0], t[1], Hh, Ll);
-            }
+            split_h2_octet(t[0], t[1], Hh, Ll);
             *reinterpret_cast<F4*>(dst) = Hh;
             *reinterpret_cast<F4*>(dst + (b < PBLK ? PLANE_P : 1024)) = Ll;
         }
     };
 
-    // ---- fragments.  Weights: lane (li, lh) takes the 16 bytes of column wn0 + j*32 + li, logical octet lh
+    // ---- fragments.  Weights: lane (li, lh) takes the 16 bytes of column wn0 + j*32 + li, logical octet lh.
+    // Step s of a slab is tap column kx = s / 3, tap row ky = s % 3 (weight tap ky*3 + kx): under one kx the MT output rows of a wave read
+    // the MT + 2 patch rows ar[0 .. MT+1], row i + ky for output row i -- every row fragment is read ONCE per tap column and serves up to
+    // three taps (12 instead of 18 LDS reads per plane and slab on a two-row wave tile, in the registers of the two alternating sets it replaces).
     const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
-    F4 af[2][NPL][MT], bf[BD][NPL][NTL];                             // [register set][plane][tile]
-    auto load_b = [&](int set, int cc, int t) __attribute__((always_inline)) {     // past the end of K the descriptor returns zeros
-        const int kc = t * ncc + slab_of(cc);
+    F4 ar[NRW][NPL], bf[BD][NPL][NTL];                               // [patch row][plane], [register set][plane][tile]
+    auto tap_of = [](int s) __attribute__((always_inline)) { return (s % 3) * 3 + s / 3; };
+    auto load_b = [&](int set, int cc, int s) __attribute__((always_inline)) {     // past the end of K the descriptor returns zeros
+        const int kc = tap_of(s) * ncc + slab_of(cc);
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0 + j * 32) * 32));
     };
     const unsigned char* abase = gbase + lh * REGION + (wrow * MT * PC + li) * 16;
-    auto load_a = [&](int set, int cc, int t) __attribute__((always_inline)) {
-        const int ky = t / 3, kx = t - ky * 3;
-        const unsigned char* pbase = abase + (cc & 1) * PATCH_BYTES;
+    auto load_row = [&](int r, int par, int kx) __attribute__((always_inline)) {
+        const unsigned char* pbase = abase + par * PATCH_BYTES;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) af[set][p][i] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + ((i + ky) * PC + kx) * 16);
+        for (int p = 0; p < NPL; ++p) ar[r][p] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + (r * PC + kx) * 16);
     };
 
     f32x16 acc[MT][NTL], tot[MT][NTL];
@@ -202,7 +175,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
-    auto product = [&](int sa, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
+    auto product = [&](int ky, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -212,65 +185,91 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c[r] = 0.f;
                 }
-                if (NPROD == 1) acc[i][j] = TSNET_MFMA_BF16(af[sa][pa][i], bf[sb][pb][j], c);
-                else acc[i][j] = TSNET_MFMA_F16(af[sa][pa][i], bf[sb][pb][j], c);
+                if (NPROD == 1) acc[i][j] = TSNET_MFMA_BF16(ar[i + ky][pa], bf[sb][pb][j], c);
+                else acc[i][j] = TSNET_MFMA_F16(ar[i + ky][pa], bf[sb][pb][j], c);
             }
     };
-    // step (cc, t): A(cc,t) in set SA, B(cc,t) in set t % BD; issues A(cc,t+1) and B of BD - 1 steps ahead first
-    auto step = [&](int cc, int t, int SA) __attribute__((always_inline)) {
-        constexpr bool SLAB_CHAIN = (OPT & 4) != 0;                  // experiment (tools build): one chain per slab instead of two
-        const bool fresh = !ONE_LEVEL && (t == 0 || (!SLAB_CHAIN && t == 4));   // chains: taps 0..3 and 4..8 of the slab
-        const int t2 = (t + BD - 1) % 9;
-        if (!(HABL & 2)) load_b(t2 % BD, cc + (t + BD - 1 >= 9 ? 1 : 0), t2);
-        if (t < 8 && !(HABL & 4)) load_a(SA ^ 1, cc, t + 1);
-        // staging of slab cc+1: round 0 fetched at tap 0 and written at tap 2, round 1 fetched at tap 3 and written at tap 5 (DEEP: fetched
-        // at taps 0 and 1, written at taps 5 and 7).  Past the last slab the loads run into the next pixel's channels or return zeros:
-        // written to the idle stage, never read.
-        if (t == 0 && !(HABL & 1)) stage_load_x(cc + 1, 0);
-        if (t == (DEEP ? 1 : 3) && !(HABL & 1)) stage_load_x(cc + 1, 1);
-        const int SB = t % BD;
-        if (NPROD == 1) {
-            product(SA, SB, 0, 0, fresh);                            // bf16 * bf16
-        } else {
-            if (NPROD == 4) product(SA, SB, NPL - 1, NPL - 1, fresh);        // lo * lo
-            product(SA, SB, NPL - 1, 0, fresh && NPROD == 3);        // lo * hi
-            product(SA, SB, 0, NPL - 1, false);                      // hi * lo
-            product(SA, SB, 0, 0, false);                            // hi * hi
+    // step s of local slab cc (stage par): B(cc, s) sits in set s % BD, the rows of its tap column in ar; issues first B of BD - 1 steps ahead
+    // and the patch row(s) the NEXT step needs: row ky + MT of this column (ky < 2); rows 0 .. MT-2 of the next column at ky = 1 (their last
+    // reader was ky = 0), row MT-1 at ky = 2.  first / last: the step opens / closes an accumulation chain.
+    auto step = [&](int cc, int par, int s, bool first, bool last) __attribute__((always_inline)) {
+        const int kx = s / 3, ky = s % 3;
+        const bool fresh = !ONE_LEVEL && first;
+        const int s2 = (s + BD - 1) % 9;
+        if (!(HABL & 2)) load_b((par * 9 + s + BD - 1) % BD, cc + (s + BD - 1 >= 9 ? 1 : 0), s2);
+        if (!(HABL & 4)) {
+            if (ky < 2) load_row(ky + MT, par, kx);
+            if (kx < 2 && ky == 1) {
+#pragma unroll
+                for (int r = 0; r + 1 < MT; ++r) load_row(r, par, kx + 1);
+            }
+            if (kx < 2 && ky == 2) load_row(MT - 1, par, kx + 1);
         }
-        if (t == (DEEP ? 5 : 2) && !(HABL & 1)) stage_store(cc + 1, 0);
-        if (t == (DEEP ? 7 : 5) && !(HABL & 1)) stage_store(cc + 1, 1);
-        if (!ONE_LEVEL && ((!SLAB_CHAIN && t == 3) || t == 8) && !(HABL & 8)) {
+        // staging of slab cc+1: round 0 fetched at step 0 and written at step 2, round 1 fetched at step 3 and written at step 5 (DEEP: fetched
+        // at steps 0 and 1, written at steps 5 and 7).  Past the last slab the loads run into the next pixel's channels or return zeros:
+        // written to the idle stage, never read.
+        if (s == 0 && !(HABL & 1)) stage_load_x(cc + 1, 0);
+        if (s == (DEEP ? 1 : 3) && !(HABL & 1)) stage_load_x(cc + 1, 1);
+        const int SB = (par * 9 + s) % BD;
+        if (NPROD == 1) {
+            product(ky, SB, 0, 0, fresh);                            // bf16 * bf16
+        } else {
+            if (NPROD == 4) product(ky, SB, NPL - 1, NPL - 1, fresh);        // lo * lo
+            product(ky, SB, NPL - 1, 0, fresh && NPROD == 3);        // lo * hi
+            product(ky, SB, 0, NPL - 1, false);                      // hi * lo
+            product(ky, SB, 0, 0, false);                            // hi * hi
+        }
+        if (s == (DEEP ? 5 : 2) && !(HABL & 1)) stage_store(cc + 1, par ^ 1, 0);
+        if (s == (DEEP ? 7 : 5) && !(HABL & 1)) stage_store(cc + 1, par ^ 1, 1);
+        // Nothing crosses a step boundary in the scheduler: the loads above stay ONE step (weights: BD - 1 steps) ahead of their first use.
+        // Left free, the scheduler sinks every load to its use to save registers (127 VGPRs, s_waitcnt vmcnt(0) before each MFMA group,
+        // 181 us on the ResnetBlock layer instead of 160).
+        __builtin_amdgcn_sched_barrier(0);
+        if (!ONE_LEVEL && last && !(HABL & 8)) {             // element by element: a vector add would be selected as v_pk_add_f32
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTL; ++j) tot[i][j] += acc[i][j];
+                for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[i][j][r] += acc[i][j][r];
         }
     };
-    const int prio_slot = (OPT & 2) ? (int)((blockIdx.x + (blockIdx.x >> 8)) % 3u) : 0;
-    auto slab = [&](int cc, int S0) __attribute__((always_inline)) {  // S0 = A register set of tap 0 = cc & 1 (9 taps: parity flips per slab)
+    // a slab: nine steps between two barriers; open / close: the slab is the first / last of its accumulation chain
+    auto slab = [&](int cc, int par, bool open, bool close) __attribute__((always_inline)) {
         if (!(HABL & 16)) __syncthreads();                           // patch(cc) complete and visible; slab cc-1 fully read
-        if (OPT & 2) {       // rotating priority: the three workgroups of a CU take turns at the head of the MFMA queue, slab by slab
-            const int p = (cc + prio_slot) % 3;
-            if (p == 0) TSNET_SETPRIO(2); else if (p == 1) TSNET_SETPRIO(1); else TSNET_SETPRIO(0);
+        if (!(HABL & 4) || cc == 0) {
+#pragma unroll
+            for (int r = 0; r < MT; ++r) load_row(r, par, 0);
         }
-        if (!(HABL & 4) || cc == 0) load_a(S0, cc, 0);
-        step(cc, 0, S0); step(cc, 1, S0 ^ 1); step(cc, 2, S0);
-        step(cc, 3, S0 ^ 1); step(cc, 4, S0); step(cc, 5, S0 ^ 1);
-        step(cc, 6, S0); step(cc, 7, S0 ^ 1); step(cc, 8, S0);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) step(cc, par, s, open && s == 0, close && s == 8);
     };
 
     // prologue: patch of slab 0, weight fragments of the first BD - 1 steps
     stage_load_x(0, 0); stage_load_x(0, 1);
 #pragma unroll
     for (int i = 0; i < BD - 1; ++i) load_b(i, 0, i);
-    stage_store(0, 0); stage_store(0, 1);
+    stage_store(0, 0, 0); stage_store(0, 0, 1);
     if (HABL & 2) load_b(2, 0, 2);
-    if (HABL & 4) { __syncthreads(); load_a(0, 0, 0); load_a(1, 0, 1); }
+    if (HABL & 4) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) load_row(r, 0, 0);
+    }
+    // K order: slab-major, (kx, ky) inside a slab.  Chains: CH = 2 slabs (18 taps x 16 channels = 288 k, 54 MFMAs), folded into the running
+    // total; a trailing pair / single slab forms a shorter chain.  With 32 slabs (512 channels) that is 16 folds of partial sums an eighth
+    // the size of the total: fewer roundings at the total's magnitude than a fold per half slab, for a quarter of the fold instructions.
     const int nloc = ncc / KG;                                       // the launcher passes KG = 2 only for an even slab count
     int cc = 0;
-    for (; cc + 2 <= nloc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
-    if (cc < nloc) slab(cc, 0);
-    if (OPT & 2) TSNET_SETPRIO(0);
+    if (CH == 4) {
+        for (; cc + 4 <= nloc; cc += 4) { slab(cc, 0, true, false); slab(cc + 1, 1, false, false); slab(cc + 2, 0, false, false); slab(cc + 3, 1, false, true); }
+    }
+    if (CH == 1) {
+        for (; cc + 2 <= nloc; cc += 2) { slab(cc, 0, true, true); slab(cc + 1, 1, true, true); }
+    } else {
+        for (; cc + 2 <= nloc; cc += 2) { slab(cc, 0, true, false); slab(cc + 1, 1, false, true); }
+    }
+    if (cc < nloc) slab(cc, 0, true, true);
     if (ONE_LEVEL) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -316,8 +315,12 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
 // LDS bytes of an h2 tile: two stages x two planes x two octet regions + the sink + the transform table (two-plane offsets in every mode)
 constexpr int h2_lds_bytes(int PR, int Cin, int KG = 1) { return KG * (2 * 2 * 2 * (((PR + 2) * (kPatchCols + 2) + 31) / 32) * 512 + 2048) + 2 * Cin * 4; }
 
+// workgroups per CU the tile is built for
+template <int PR, int BN, int WARPS_M, int WARPS_N, int NPROD, int OPT>
+constexpr int h2_wgs_per_cu() { return (OPT & 16) ? 1 : ((BN / WARPS_N) * (PR / WARPS_M) * ((OPT & 8) ? 2 : 1) <= (NPROD == 1 ? 128 : 64) ? ((OPT & 64) ? 4 : 3) : 2); }
+
 template <int PR, int BN, int WARPS_M, int WARPS_N, int NPROD, bool AFFINE, int HABL = 0, int OPT = 0>
-__global__ __launch_bounds__((OPT & 16) ? 512 : 256, (OPT & 16) ? 1 : ((BN / WARPS_N) * (PR / WARPS_M) * ((OPT & 8) ? 2 : 1) <= (NPROD == 1 ? 128 : 64) ? 3 : 2))   // wave tile 64 x 32 (bf16 operands: also 64 x 64, no second accumulator level): three workgroups per CU; 64 x 64 or DEEP 64 x 32: two; two K groups: one
+__global__ __launch_bounds__((OPT & 16) ? 512 : 256, (h2_wgs_per_cu<PR, BN, WARPS_M, WARPS_N, NPROD, OPT>()))
 void conv_h2_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     int tile_m, tile_n;

@@ -26,18 +26,22 @@ void ensure_dynamic_lds(const void* kernel, size_t bytes) {
 
 namespace {
 
+template <int PR, int BN, int WM, int WN, int NPROD, bool AFFINE, int HABL, int OPT>
+void go_h2_k(const ConvArgs& a, size_t lds, int threads, hipStream_t s) {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2_kernel<PR, BN, WM, WN, NPROD, AFFINE, HABL, OPT>), lds);
+    hipLaunchKernelGGL((conv_h2_kernel<PR, BN, WM, WN, NPROD, AFFINE, HABL, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(threads), lds, s, a);
+}
+
+// OPT bit 0 (re-zero the padded pixels after the affine transform) is the launcher's: set for a zero-padding layer with a fused InstanceNorm
 template <int PR, int BN, int WM, int WN, int NPROD, int HABL = 0, int OPT = 0>
 void go_h2(const ConvArgs& a, hipStream_t s) {
     constexpr int KG = (OPT & 16) ? 2 : 1;
+    static_assert((OPT & 1) == 0, "bit 0 is chosen here");
     if ((a.Cin >> 4) % KG) throw std::invalid_argument("conv(h2): two K groups need an even number of 16-channel slabs");
     const size_t lds = (size_t)h2_lds_bytes(PR, a.Cin, KG);
-    if (a.in_alpha) {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2_kernel<PR, BN, WM, WN, NPROD, true, HABL, OPT>), lds);
-        hipLaunchKernelGGL((conv_h2_kernel<PR, BN, WM, WN, NPROD, true, HABL, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(256 * KG), lds, s, a);
-    } else {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2_kernel<PR, BN, WM, WN, NPROD, false, HABL, OPT>), lds);
-        hipLaunchKernelGGL((conv_h2_kernel<PR, BN, WM, WN, NPROD, false, HABL, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(256 * KG), lds, s, a);
-    }
+    if (!a.in_alpha) go_h2_k<PR, BN, WM, WN, NPROD, false, HABL, OPT>(a, lds, 256 * KG, s);
+    else if (a.reflect) go_h2_k<PR, BN, WM, WN, NPROD, true, HABL, OPT>(a, lds, 256 * KG, s);
+    else go_h2_k<PR, BN, WM, WN, NPROD, true, HABL, OPT | 1>(a, lds, 256 * KG, s);
 }
 
 template <int NPROD>
@@ -76,9 +80,9 @@ void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int o
         // experiment / ablation instantiations (tools/h2_variants.py): 3 products, raw or transformed input
         if (nprod != 3) throw std::invalid_argument("conv(h2): experiment variants are built for three products");
 #define TSNET_H2_VAR(PR_, BN_, WM_, WN_, A_, O_) if (pr == PR_ && bn == BN_ && abl == A_ && opt == O_) { go_h2<PR_, BN_, WM_, WN_, 3, A_, O_>(a, s); return; }
-        TSNET_H2_VAR(4, 64, 2, 2, 0, 1) TSNET_H2_VAR(4, 64, 2, 2, 0, 2) TSNET_H2_VAR(4, 64, 2, 2, 0, 3) TSNET_H2_VAR(4, 64, 2, 2, 0, 16) TSNET_H2_VAR(4, 128, 2, 2, 0, 16)
-        TSNET_H2_VAR(4, 64, 2, 2, 0, 8) TSNET_H2_VAR(4, 32, 4, 1, 0, 8) TSNET_H2_VAR(4, 64, 2, 2, 0, 4) TSNET_H2_VAR(4, 128, 2, 2, 0, 4)
-        TSNET_H2_VAR(4, 128, 2, 2, 0, 1) TSNET_H2_VAR(2, 128, 1, 4, 0, 2)
+        TSNET_H2_VAR(4, 64, 2, 2, 0, 2) TSNET_H2_VAR(4, 64, 2, 2, 0, 4) TSNET_H2_VAR(4, 64, 2, 2, 0, 8) TSNET_H2_VAR(4, 64, 2, 2, 0, 16)
+        TSNET_H2_VAR(4, 128, 2, 2, 0, 2) TSNET_H2_VAR(4, 128, 2, 2, 0, 4) TSNET_H2_VAR(4, 128, 2, 2, 0, 16) TSNET_H2_VAR(4, 32, 4, 1, 0, 8)
+        TSNET_H2_VAR(4, 64, 2, 2, 0, 32) TSNET_H2_VAR(4, 64, 2, 2, 0, 64) TSNET_H2_VAR(4, 64, 2, 2, 0, 36) TSNET_H2_VAR(2, 128, 1, 4, 0, 32)
         TSNET_H2_VAR(4, 64, 2, 2, 1, 0) TSNET_H2_VAR(4, 64, 2, 2, 2, 0) TSNET_H2_VAR(4, 64, 2, 2, 4, 0) TSNET_H2_VAR(4, 64, 2, 2, 7, 0)
         TSNET_H2_VAR(4, 64, 2, 2, 8, 0) TSNET_H2_VAR(4, 64, 2, 2, 16, 0) TSNET_H2_VAR(4, 64, 2, 2, 15, 0) TSNET_H2_VAR(4, 64, 2, 2, 31, 0)
         TSNET_H2_VAR(2, 128, 1, 4, 1, 0) TSNET_H2_VAR(2, 128, 1, 4, 2, 0) TSNET_H2_VAR(2, 128, 1, 4, 7, 0)

@@ -311,9 +311,14 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
             // two rows x 128 columns (four waves, 44 KiB of LDS: three workgroups per CU) wherever the layer is 128 channels wide: 125 -> 99 us
             // on 256 -> 512, 117 -> 109 us on 128 -> 256 at batch 4, equal or better down to one frame (profiles/round3_conv_variants.txt);
             // the four-row shapes hold 80 KiB and run one workgroup per CU
-            int pr = 4, bn = c.tile ? c.tile % 1000 : 64;
-            if (c.tile >= 1000) pr = c.tile / 1000;
-            if (!c.tile && g.Npad % 128 == 0 && g.Cout > 64 && g.Ho % 2 == 0) { pr = 2; bn = 128; }
+            if (c.tile / 10000) throw ArgError("conv(h2d): the stride-2 tiles have no two-K-group / deep-prefetch form");
+            const int tc = c.tile % 10000;
+            int pr = tc >= 1000 ? tc / 1000 : 4, bn = tc % 1000;          // a code without a width (0, 2000, 4000) leaves the width to the heuristic
+            if (bn == 0) {
+                bn = 64;
+                if (tc < 1000 && g.Npad % 128 == 0 && g.Cout > 64 && g.Ho % 2 == 0) { pr = 2; bn = 128; }
+            }
+            if (pr != 2 && pr != 4) throw ArgError("conv(h2d): tiles have two or four output rows");
             if (g.Npad % bn) throw ArgError("conv(h2d): the tile width must divide the padded output width");
             if (g.Ho % pr) throw ArgError("conv(h2d): the output height must be a multiple of the tile's rows");
             set_tiles(pr * kPatchCols, bn);
@@ -1589,7 +1594,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     hipStream_t s = (hipStream_t)stream;
     Ctx ctx; ctx.stream = s;
     // variant (-1 = the layer's own kernel and tile): bits 0-11 tile code (ConvCall::tile), bit 12 general kernel, bit 13 bf16 operands, bit 14 patch kernel,
-    // bits 16-22 ablation mask, bit 23 two K groups, bits 24-27 experiment mask (8 = deep prefetch; the rest tools build), bits 28-30 XCD grid
+    // bits 16-20 ablation mask, bit 21 four workgroups per CU, bit 22 weights five steps ahead, bit 23 two K groups, bits 24-27 experiment mask (8 = deep prefetch; the rest tools build), bits 28-30 XCD grid
     const int v = variant < 0 ? 0 : variant;
     const int nprod = (v & 8192) ? 1 : 3;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -1609,7 +1614,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     {
         OpLayer op(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s);
         ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = norm ? 64.f : 1.f; c.nprod = nprod;
-        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 127; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0);
+        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 31; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0) | ((v & (1 << 22)) ? 32 : 0) | ((v & (1 << 21)) ? 64 : 0);
         { const int gx = (v >> 28) & 7; c.xcd_gn = gx == 0 ? -1 : (gx == 1 ? 0 : 1 << (gx - 2)); }          // bits 28-30: 0 default, 1 linear, 2..5 grid with 1, 2, 4, 8 columns
         if (norm) { c.alpha = al; c.beta = be; c.relu = 1; }
         for (int i = 0; i < 2; ++i) run_conv(ctx, op.L, c);
