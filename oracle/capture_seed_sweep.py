@@ -78,11 +78,13 @@ def main():
         json.dump(old + metas, f, indent=1)
 
 
-def capture_pair(ref_face, ref_pose, O, group, cfg, kw, B, H, W, bias_std, wseed, iseed, mask):
+def capture_pair(ref_face, ref_pose, O, group, cfg, kw, B, H, W, bias_std, wseed, iseed, mask, name=None, inp=None, extra_arrays=None, extra_meta=None):
+    """name / inp / extra_*: a pair whose inputs are DATA stored with the golden instead of PRNG draws (capture_demo_input_goldens.py)"""
     t0 = time.time()
-    name = f"g6_{group}_w{wseed}_i{iseed}"
+    name = name or f"g6_{group}_w{wseed}_i{iseed}"
     sd = O.synth_state_dict(cfg, seed=wseed, bias_std=bias_std)
-    inp = O.synth_inputs(cfg, B, H, W, seed=iseed, mask_mode=mask)
+    if inp is None:
+        inp = O.synth_inputs(cfg, B, H, W, seed=iseed, mask_mode=mask)
     m = CG.build_reference_model(ref_face, ref_pose, cfg, sd)
     m.set_test_input([x.clone() for x in inp[0]], inp[1], inp[2], inp[3], inp[4])
     with torch.no_grad():
@@ -132,6 +134,8 @@ def capture_pair(ref_face, ref_pose, O, group, cfg, kw, B, H, W, bias_std, wseed
                 ref32_vs_ref64=dict(max=noise.max().item(), mean=noise.mean().item()),
                 oracle_vs_ref=dict(rec=d32, flow=dfl, rec64=d64), has_flow=has_flow,
                 rec64_mean=rec64.mean().item(), rec64_absmax=rec64.abs().max().item())
+    meta.update(extra_meta or {})
+    arrays.update(extra_arrays or {})
     np.savez_compressed(os.path.join(CG.GOLD, name + ".npz"), meta=json.dumps(meta), **arrays)
     return meta
 

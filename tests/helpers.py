@@ -103,5 +103,24 @@ def golden_case(name):
     if key not in _SD_CACHE:
         _SD_CACHE.clear()          # 268 MB each: keep one
         _SD_CACHE[key] = O.synth_state_dict(cfg, seed=meta["wseed"], bias_std=meta["bias_std"])
-    inputs = O.synth_inputs(cfg, meta["B"], meta["H"], meta["W"], seed=meta["iseed"], mask_mode=meta["mask_mode"])
+    if meta.get("inputs") == "stored":
+        inputs = stored_inputs(meta, z, cfg)
+    else:
+        inputs = O.synth_inputs(cfg, meta["B"], meta["H"], meta["W"], seed=meta["iseed"], mask_mode=meta["mask_mode"])
     return meta, z, cfg, _SD_CACHE[key], inputs
+
+
+def stored_inputs(meta, z, cfg):
+    """Inputs that are DATA of the golden (oracle/capture_demo_input_goldens.py: frames of the reference's demo clips as the demo scripts
+    feed them -- BGR - IMG_MEAN in [-112, 154], one-hot edge-map / skeleton labels, bounding-box masks; K sources shared by the B driving
+    frames, demo_face.py:177-192)."""
+    B, W = meta["B"], meta["W"]
+    mean = np.asarray(meta["img_mean_bgr"], dtype=np.float32)
+    onehot = lambda m: torch.nn.functional.one_hot(torch.from_numpy(m.astype(np.int64)), cfg.label_nc).permute(2, 0, 1).float()
+    bits = lambda a: torch.from_numpy(np.unpackbits(a, axis=-1)[..., :W].astype(np.float32))
+    src_img = [torch.from_numpy(b.astype(np.float32) - mean).permute(2, 0, 1).unsqueeze(0).repeat(B, 1, 1, 1) for b in z["in_src_bgr"]]
+    src_lbl = [onehot(l).unsqueeze(0).repeat(B, 1, 1, 1) for l in z["in_src_lbl"]]
+    src_bbox = [bits(x).unsqueeze(0).repeat(B, 1, 1) for x in z["in_src_bbox"]]
+    tar_lbl = torch.stack([onehot(l) for l in z["in_tar_lbl"]])
+    tar_bbox = torch.stack([bits(x) for x in z["in_tar_bbox"]])
+    return src_img, src_lbl, src_bbox, tar_lbl, tar_bbox

@@ -215,3 +215,57 @@ def warp_case(lib, dev, B, h, w, C, seed=0):
     assert rc == 0, lib.tsnet_op_last_error().decode()
     _sync(dev)
     return (nchw(out.cpu()) - ref).abs().max().item()
+
+
+def conv_split_worstcase_case(lib, dev, N, H, W, Cin, Cout, tiers=(-12, -18, -24), weights_too=True, corner=False, seed=0):
+    """Adversarial dynamic range INSIDE one image for the fp16 x 2 operand split (conv_common.hpp): 1 % of the activations sit at the
+    image's maximum, the rest in equal shares at amax * 2^t for t in `tiers` (the operand scale is derived from amax alone, so the bulk
+    lands deep in fp16's lower range, the last tier in its subnormals); the weights likewise.  corner=True confines the amax values to the
+    top-left 8 x 8 pixels, so most outputs are sums of tiny terms only.
+    Returns (max|y - ref64|, max|conv_fp32 - ref64|, max|y - ref64| over outputs that see no amax activation, their max|ref64|, amax_x, amax_w):
+    the exact-fp32 chain on the same data is the yardstick (torch fp32 conv on the CPU)."""
+    def tiered(name, shape, amax, spatial=None):
+        u = prng.uniform01(seed, name + "_u", shape)                     # magnitude within a tier: [0.5, 1)
+        sgn = torch.where(prng.uniform01(seed, name + "_s", shape) < 0.5, -1.0, 1.0)
+        sel = prng.uniform01(seed, name + "_t", shape)
+        e = torch.zeros(shape)
+        nt = len(tiers)
+        for i, t in enumerate(tiers):
+            e = torch.where((sel >= 0.01 + 0.99 * i / nt) & (sel < 0.01 + 0.99 * (i + 1) / nt), float(t), e)
+        top = sel < 0.01
+        if spatial is not None:
+            top = top & spatial
+            e = torch.where((sel < 0.01) & ~spatial, float(tiers[0]), e)
+        e = torch.where(top, 0.0, e)
+        v = sgn * (0.5 + 0.5 * u) * torch.exp2(e) * amax
+        if top.any():
+            v.view(-1)[top.view(-1).nonzero()[0]] = amax                 # the maximum itself is present
+        return v.float(), top
+
+    sp = None
+    if corner:
+        sp = torch.zeros(N, Cin, H, W, dtype=torch.bool)
+        sp[:, :, :8, :8] = True
+    x, xtop = tiered("x", (N, Cin, H, W), 3.0, sp)
+    if weights_too:
+        w, _ = tiered("w", (Cout, Cin, 3, 3), 2.0 / (Cin * 9) ** 0.5)
+    else:
+        w = _rand(seed, "w", (Cout, Cin, 3, 3)) * (2.0 / (Cin * 9) ** 0.5)
+    xp = F.pad(x, (1,) * 4, mode="reflect")
+    ref = F.conv2d(xp.double(), w.double())
+    y32 = F.conv2d(xp, w)
+    bound = float(x.abs().max()) * 1.0001
+    xd, wd = nhwc(x).to(dev), w.to(dev)
+    y = torch.full((N, H, W, Cout), float("nan"), device=dev)
+    rc = lib.tsnet_op_conv2d(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), None, Cout, 3, 1, 1, 1, None, None, 0, bound, 3, 2, 0, y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    yc = nchw(y.cpu()).double()
+    e_h2 = (yc - ref).abs().max().item()
+    e_32 = (y32.double() - ref).abs().max().item()
+    # outputs whose 3 x 3 receptive field holds no amax activation in any channel
+    seen = F.max_pool2d(F.pad(xtop.any(dim=1, keepdim=True).float(), (1,) * 4, mode="reflect"), 3, 1)      # (N,1,H,W)
+    quiet = (seen == 0).expand(-1, Cout, -1, -1)
+    e_quiet = (yc - ref)[quiet].abs().max().item() if quiet.any() else 0.0
+    r_quiet = ref[quiet].abs().max().item() if quiet.any() else 0.0
+    return e_h2, e_32, e_quiet, r_quiet, float(x.abs().max()), float(w.abs().max())

@@ -144,3 +144,17 @@ def test_flow_many_tiles(emu_lib):
 
 def test_warp_out_of_range(emu_lib):
     assert oc.warp_case(emu_lib, "cpu", 2, 5, 6, 16) < TOL
+
+
+def test_conv_split_worst_case_dynamic_range(emu_lib):
+    """The fp16 x 2 split under an adversarial dynamic range inside ONE image (1 % of the activations at amax, the bulk 2^-12 .. 2^-24
+    below; weights likewise): the absolute error stays within 3 x that of the exact-fp32 chain (torch fp32 conv) on the same data, and
+    outputs built from the tiny tiers alone keep >= 19 bits relative to their own magnitude (the split's floor is 2^-40 amax per element:
+    DESIGN.md section 4.1).  GPU tier: tests/test_gpu_ops.py at the ResnetBlock shape."""
+    for corner in (False, True):
+        for wt in (True, False):
+            e, e32, eq, rq, _, _ = oc.conv_split_worstcase_case(emu_lib, "cpu", 1, 16, 32, 128, 64, corner=corner, weights_too=wt)
+            assert e <= 3.0 * e32, (corner, wt, e, e32)
+            assert eq <= rq * 2.0 ** -19, (corner, wt, eq, rq)
+    e, e32, _, _, _, _ = oc.conv_split_worstcase_case(emu_lib, "cpu", 1, 16, 32, 128, 64, tiers=(-6, -9, -12))
+    assert e <= 3.0 * e32

@@ -168,3 +168,17 @@ def test_bf16_operand_convs(lib):
     assert oc.conv_case(lib, DEV, 2, 64, 64, 256, 512, 3, 2, 1, False, norm=True, nprod=1) < 2e-2
     assert oc.conv_case(lib, DEV, 1, 256, 256, 8, 64, 7, 1, 3, True, nprod=1) < 2e-2
     assert oc.conv_case(lib, DEV, 2, 32, 32, 1024, 512, 1, 1, 0, False, nprod=1) < 2e-2
+
+
+def test_conv_split_worst_case_dynamic_range(lib):
+    """The fp16 x 2 split under an adversarial dynamic range inside ONE image at the ResnetBlock shape (512 -> 512, 32 x 32): 1 % of the
+    activations at amax, the bulk at amax * 2^-12 / 2^-18 / 2^-24, weights likewise.  Absolute error within 3 x the exact-fp32 chain's
+    (torch fp32 conv on the same data); outputs that see only the tiny tiers keep >= 19 bits relative to their own magnitude."""
+    for corner in (False, True):
+        for wt in (True, False):
+            e, e32, eq, rq, _, _ = oc.conv_split_worstcase_case(lib, DEV, 2, 32, 32, 512, 512, corner=corner, weights_too=wt)
+            print(f"worst-case split corner={corner} tiered_weights={wt}: max|err| {e:.3e} vs fp32 chain {e32:.3e} (x{e / e32:.2f}); quiet outputs {eq:.3e} of {rq:.3e}")
+            assert e <= 3.0 * e32, (corner, wt, e, e32)
+            assert eq <= rq * 2.0 ** -19, (corner, wt, eq, rq)
+    e, e32, _, _, _, _ = oc.conv_split_worstcase_case(lib, DEV, 2, 32, 32, 512, 512, tiers=(-6, -9, -12))
+    assert e <= 3.0 * e32

@@ -30,11 +30,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TOL_REC, TOL_FLOW = 1e-3, 1e-4
 NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(Hh.GOLD, "g6_cfg*_w*_i*.npz")))
+# ... and pairs on REALISTIC inputs (oracle/capture_demo_input_goldens.py): frames of the reference's demo clips as demo_face.py:150-192 /
+# demo_pose.py feed them (BGR - IMG_MEAN in [-112, 154], edge-map / skeleton labels, box masks; n_blocks = 4, K = 3, B = 1 and 2), the
+# reference itself run on them in fp32 and fp64.  Same gates.
+NAMES += sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(Hh.GOLD, "g10_*.npz")))
 _rows = []
 
 
 def test_sweep_has_at_least_eight_pairs():
     assert sum(n.startswith("g6_cfg1_") for n in NAMES) >= 8
+    assert sum(n.startswith("g10_face_") for n in NAMES) >= 2 and sum(n.startswith("g10_pose_") for n in NAMES) >= 2
     for other in ("g6_cfg2_", "g6_cfg3_", "g6_cfg4_"):          # the shapes of BASELINE.json configs[2..4]: n_blocks = 4; pose model; 512 x 512 with K = 5
         assert any(n.startswith(other) for n in NAMES), other
 

@@ -61,3 +61,25 @@ def test_manifest_lists_every_golden():
     import os
     names = {m["name"] for m in json.load(open(os.path.join(Hh.GOLD, "MANIFEST.json")))}
     assert set(SMALL) | {"g3_pose_256_k1_nb1", "g4_cfg0_full"} <= names
+
+
+@pytest.mark.parametrize("name", ["g10_face_test114_to_val024_b1", "g10_pose_00110_to_00164_b1"])
+def test_demo_range_inputs(name):
+    """Realistic inputs (oracle/capture_demo_input_goldens.py): frames of the reference's demo clips as demo_face.py:150-192 / demo_pose.py
+    feed them -- BGR - IMG_MEAN in [-112, 154], edge-map / skeleton labels, box masks, n_blocks = 4, K = 3, B = 1 -- rebuilt from the bytes
+    stored with the golden; the oracle reproduces the reference's fp32 crops / lattice / row checksums and flows (0.0 at capture)."""
+    meta, z, cfg, sd, inputs = Hh.golden_case(name)
+    assert meta["inputs"] == "stored" and meta["oracle_vs_ref"]["rec"] == 0.0 and meta["oracle_vs_ref"]["rec64"] == 0.0
+    lo, hi = min(float(x.min()) for x in inputs[0]), max(float(x.max()) for x in inputs[0])
+    assert lo < -100 and hi > 100 and [lo, hi] == meta["image_range"]
+    assert all(torch.equal(l.sum(dim=1), torch.ones_like(l[:, 0])) for l in inputs[1] + [inputs[3]])       # one-hot labels
+    out = O.tsnet_forward(sd, cfg, *inputs)
+    rec = out["rec_tar_img"]
+    H, W = meta["H"], meta["W"]
+    for tag, (ys, xs) in {"c": (slice(96, 128), slice(96, 128)), "tl": (slice(0, 16), slice(0, 16)), "br": (slice(H - 16, H), slice(W - 16, W)),
+                          "sub4": (slice(None, None, 4), slice(None, None, 4))}.items():
+        assert np.abs(rec[:, :, ys, xs].numpy() - z[f"rec32_{tag}"]).max() <= TOL, tag
+    assert np.abs(rec.double().sum(dim=3).numpy() - z["rec32_rowsum"]).max() <= W * TOL
+    if meta["has_flow"]:
+        for i in range(cfg.n_source):
+            assert np.abs(out["flows"][i].numpy() - z[f"flow32_{i}"]).max() <= TOL
