@@ -73,6 +73,12 @@ def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, n
                      scale=scale, return_output=return_output)
 
 
+def conv_w1_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, nprod=3, seed=0, scale=1.0, relu=None, return_output=False):
+    """3x3 / stride 1 / pad 1 in the Winograd F(2,3)-along-x form (conv_w1.hpp; kernel = 3): same contract as conv_h2_case"""
+    return conv_case(lib, dev, N, H, W, Cin, Cout, 3, 1, 1, reflect, norm=norm, bias=bias, seed=seed, nprod=nprod, kernel=3, scale=scale,
+                     relu=relu, return_output=return_output)
+
+
 def conv_h2r_case(lib, dev, N, H, W, Cin, Cout, ksize, norm=False, bias=True, seed=0, kernel=0, tile=0, return_output=False):
     """the encoder's stem (7x7, reflection pad 3) and downsampling (3x3, stride 2, zero pad 1) convolutions; kernel as conv_case."""
     if ksize == 7:

@@ -158,3 +158,16 @@ def test_conv_split_worst_case_dynamic_range(emu_lib):
             assert eq <= rq * 2.0 ** -19, (corner, wt, eq, rq)
     e, e32, _, _, _, _ = oc.conv_split_worstcase_case(emu_lib, "cpu", 1, 16, 32, 128, 64, tiers=(-6, -9, -12))
     assert e <= 3.0 * e32
+
+
+def test_conv_w1_winograd_x_form(emu_lib):
+    """3x3 / stride 1 / pad 1 in the Winograd F(2,3)-along-x form (conv_w1.hpp, tsnet_op_conv2d(kernel = 3)): reflection and zero padding,
+    with and without the fused IN + ReLU, one / three / five slabs (the odd counts end in an all-zero slab of the last period), two images
+    and several tiles, a second 64-channel tile column, bf16 operands.  Accuracy: the direct kernel's class (the transform precedes the
+    split; tools/probes/winograd_probe.py).  The forward does not run this form -- DESIGN.md section 4.4 has the measurements."""
+    assert oc.conv_w1_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True) < REL
+    assert oc.conv_w1_case(emu_lib, "cpu", 2, 8, 64, 48, 96, False, norm=True) < REL
+    assert oc.conv_w1_case(emu_lib, "cpu", 1, 4, 32, 80, 64, True, norm=True, relu=False) < REL
+    assert oc.conv_w1_case(emu_lib, "cpu", 1, 8, 32, 64, 128, False, bias=False) < REL
+    assert oc.conv_w1_case(emu_lib, "cpu", 1, 4, 32, 32, 64, True, scale=300.0) < REL
+    assert oc.conv_w1_case(emu_lib, "cpu", 1, 4, 32, 32, 64, True, norm=True, nprod=1) < 2e-2

@@ -182,3 +182,13 @@ def test_conv_split_worst_case_dynamic_range(lib):
             assert eq <= rq * 2.0 ** -19, (corner, wt, eq, rq)
     e, e32, _, _, _, _ = oc.conv_split_worstcase_case(lib, DEV, 2, 32, 32, 512, 512, tiers=(-6, -9, -12))
     assert e <= 3.0 * e32
+
+
+def test_conv_w1_winograd_x_form(lib):
+    """the Winograd F(2,3)-along-x form of the 3x3 / stride-1 layers (conv_w1.hpp; tsnet_op_conv2d(kernel = 3)) at the ResnetBlock, FuseNet
+    and decoder shapes: fp32-class accuracy like the direct kernel (measured 0.8 - 1.1 x its error).  Not on the forward's path: 182 us
+    against 155 us on the ResnetBlock layer."""
+    assert oc.conv_w1_case(lib, DEV, 12, 32, 32, 512, 512, True, norm=True) < REL
+    assert oc.conv_w1_case(lib, DEV, 4, 32, 32, 1024, 1024, True) < REL
+    assert oc.conv_w1_case(lib, DEV, 2, 8, 64, 48, 96, False, norm=True) < REL
+    assert oc.conv_w1_case(lib, DEV, 1, 256, 256, 128, 64, False, bias=False) < REL

@@ -16,10 +16,10 @@ torch.zeros(1, device="cuda")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 
 
-def code(tile=0, general=False, abl=0, opt=0, xcd=None, patch=False):
+def code(tile=0, general=False, abl=0, opt=0, xcd=None, patch=False, w1=False):
     """xcd: None = the launcher's choice, 0 = consecutive tiles per XCD, 1 / 2 / 4 / 8 = columns of the XCD grid over the N tiles"""
     gx = 0 if xcd is None else (1 if xcd == 0 else {1: 2, 2: 3, 4: 4, 8: 5}[xcd])
-    return tile | (4096 if general else 0) | (16384 if patch else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | ((1 << 22) if opt & 32 else 0) | ((1 << 21) if opt & 64 else 0) | (gx << 28)
+    return tile | (4096 if general else 0) | (16384 if patch else 0) | (32768 if w1 else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | ((1 << 22) if opt & 32 else 0) | ((1 << 21) if opt & 64 else 0) | (gx << 28)
 
 
 def run(name, shape, variants, norms=(0, 1), iters=8):
@@ -57,6 +57,20 @@ if SEL == "downsmall":  # stride-2 shapes of a single frame
                     ("down2 2 frames (6 images)", (6, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 2 frames (6 images)", (6, 64, 64, 256, 512, 3, 2, 1, 0))):
         run(nm, shp, [("h2d 4 waves x 64", code(64, patch=True)), ("h2d 8 waves x 128", code(128, patch=True)), ("h2d 2 rows x 128", code(2128, patch=True)),
                       ("the layer's own", code(0))], norms=(1,))
+    sys.exit(0)
+if SEL == "w1":         # Winograd F(2,3) along x (conv_w1.hpp) against the direct patch kernel, layer by layer
+    W1 = ("w1 (winograd-x)", code(w1=True))
+    run("res (B=4: 12 images)", RES, [("4x64 direct", code(64)), W1])
+    run("res w1 ablations", RES, [W1] + [(f"w1 abl{m}", code(w1=True, abl=m)) for m in (1, 2, 4, 3, 7, 8, 15)], norms=(0,))
+    run("res (B=8: 24 images)", (24, 32, 32, 512, 512, 3, 1, 1, 1), [("4x64 direct", code(64)), W1])
+    run("res (B=1: 3 images)", (3, 32, 32, 512, 512, 3, 1, 1, 1), [("4x64 deep kg2", code(64, opt=24)), W1])
+    run("res clip (1 image)", (1, 32, 32, 512, 512, 3, 1, 1, 1), [("4x32 deep kg2", code(32, opt=24)), W1])
+    run("fuse_c2 (1024->1024)", (12, 32, 32, 1024, 1024, 3, 1, 1, 1), [("4x128 direct", code(128)), W1, ("w1 grid x2", code(w1=True, xcd=2)), ("w1 grid x4", code(w1=True, xcd=4))])
+    run("fuse_c1_src (512->1024)", (12, 32, 32, 512, 1024, 3, 1, 1, 1), [("4x128 direct", code(128)), W1], norms=(0,))
+    run("fuse_c1_tar (512->1024, 4 images)", (4, 32, 32, 512, 1024, 3, 1, 1, 1), [("the layer's own", code(0)), W1], norms=(0,))
+    run("dec_up0 (512->256 @64^2)", (4, 64, 64, 512, 256, 3, 1, 1, 1), [("4x128 direct", code(128)), W1], norms=(0,))
+    run("dec_up1 (256->128 @128^2)", (4, 128, 128, 256, 128, 3, 1, 1, 1), [("the layer's own", code(0)), W1], norms=(0,))
+    run("dec_up2 (128->64 @256^2)", (4, 256, 256, 128, 64, 3, 1, 1, 1), [("the layer's own", code(0)), W1], norms=(0,))
     sys.exit(0)
 if SEL == "chain":      # slabs per accumulation chain: 1, 2 (product), 4; and the ablations of the 4 x 64 tile
     run("res", RES, [("4x64 chain 2 (product)", code(64)), ("4x64 chain 1", code(64, opt=2)), ("4x64 chain 4", code(64, opt=4)),

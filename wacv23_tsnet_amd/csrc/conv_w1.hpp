@@ -1,0 +1,288 @@
+// conv_w1.hpp -- the 3 x 3 / stride-1 / pad-1 convolution (ResnetBlocks, FuseNet, decoder up-convolutions: TSNet.py:27,42,147; 83 % of the
+// forward's FLOPs) with the Winograd F(2, 3) transform ALONG X: two adjacent output pixels of a row are computed from four transformed
+// input columns with FOUR products per tap row instead of six -- two thirds of the MFMA work of the direct form (conv_h2.hpp), which is
+// what bounds these layers (three fp16 MFMA products per fp32 product on a power-limited matrix pipe).
+//
+//   V_p[y][j] = sum_i Bt[p][i] d[y][2j-1+i]   p = 0..3:  d0-d2,  d1+d2,  d2-d1,  d1-d3        input transform  (one add / value, fp32)
+//   U_p[ky]   = sum_kx G[p][kx] g[ky][kx]              g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2     filter transform (host, fp64, at pack time)
+//   M_p[y][j] = sum_ky sum_c V_p[y+ky][j][c] U_p[ky][c]                                       4 GEMMs, K = 3 Cin: the MFMA work
+//   out[y][2j] = M0 + M1 + M2,   out[y][2j+1] = M1 - M2 - M3                                  output transform (epilogue, fp32)
+//
+// Numerics: the transform acts on the fp32 activation AFTER the producer's InstanceNorm + ReLU and BEFORE the fp16 x 2 split (sums of fp16
+// numbers need more than fp16's bits), U is rounded once to fp32 and split like any weight; products, chains (two 16-channel slabs) and
+// the running total are conv_h2's.  tools/probes/winograd_probe.py: error against fp64 0.96 x the direct kernel's at the ResnetBlock shape
+// (the 2-D transform: 1.11 x; both inside the 1.5 x line).
+//
+// A tile = 4 x 32 output pixels (64 column pairs) x 64 output channels, EIGHT waves: wave = (position p, 32-channel half), wave tile
+// 64 pairs x 32 channels of ONE position; acc + total = 64 VGPRs.  One workgroup per CU (two waves per SIMD): 768 tiles on the ResnetBlock
+// layers at the headline batch = three rounds.
+//   * the K loop runs in PERIODS of two 16-channel slabs (six steps, one barrier, one accumulation chain); V lives in LDS, three stages of
+//     [slab][position][plane][octet][6 rows x 16 pairs] x 16 B (48 KiB each): period s is consumed while period s+2 is produced, so the
+//     first A fragments of period s+1 are fetched BEFORE the barrier (no exposed LDS latency at a period's start);
+//   * waves 0..5 produce V, one input row each: a lane owns (pair, one of the period's four channel octets) -- 4 input pixels x 8 channels
+//     straight from global memory a whole period ahead (reflection / zero padding in the lane's offsets), IN + ReLU, then one position per
+//     step: transform, split, two ds_write_b128;
+//   * an A fragment = two consecutive V rows (32 pairs) of the wave's position: rows (ky, ky+1) and (ky+2, ky+3) for the two 32-pair halves:
+//     five distinct fragments serve the six (half, ky) uses of a slab; weight fragments five steps ahead (six register sets);
+//   * epilogue: the four positions of a tile meet through LDS (64 KiB over the V stages), wave (row, half) forms its 32 pixels x 32 channels
+//     and runs the shared conv_epilogue (bias, addend, fp64 statistics, in-kernel finalize, amax).
+#pragma once
+#include "conv_common.hpp"
+
+namespace tsnet {
+
+constexpr int kW1Stage(int npl) { return 2 * 4 * npl * 2 * 96 * 16; }             // bytes of one V stage: two slabs
+constexpr int w1_lds_bytes(int Cin, int npl = 2) {
+    const int v = 3 * kW1Stage(npl) + 2048, ex = 4 * 64 * 64 * 4 + 2048;           // V stages + spare | output exchange
+    return (v > ex ? v : ex) + 2 * Cin * 4;
+}
+
+// OPT bit 0: the layer zero-pads an InstanceNorm-ed input (padded pixels re-zeroed after the affine transform).  Tools build (ablations,
+// compute garbage): bit 4 no producer work in the loop, bit 5 weight fragments loaded once, bit 6 A fragments read once, bit 7 no barrier
+template <int NPROD, bool AFFINE, int OPT = 0>
+__device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_raw, const int tile_m, const int n0) {
+    static_assert(NPROD == 1 || NPROD == 3, "one (bf16 operands) or three products");
+    constexpr int NPL = NPROD == 1 ? 1 : 2;
+    constexpr bool ONE_LEVEL = NPROD == 1;
+    constexpr bool ZPAD_KEEP = (OPT & 1) != 0;
+    constexpr int BD = 6;                                            // weight register sets = the six steps of a period: fragments five steps ahead
+    constexpr int REG = 96 * 16;                                     // one (slab, position, plane, octet) region: 6 rows x 16 pairs x 16 B
+    constexpr int PLANE_V = 2 * REG, POSB = NPL * PLANE_V, SLABB = 4 * POSB, STAGE = 2 * SLABB;
+    constexpr int OFF_END = 3 * STAGE + 2048, OFF_EX_END = 4 * 64 * 64 * 4 + 2048;
+    constexpr int OFF_TAB = OFF_END > OFF_EX_END ? OFF_END : OFF_EX_END;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = TSNET_UNIFORM(tid >> 6);
+    const int pos = wave >> 1, nt = wave & 1;                        // K loop: this wave's Winograd position and 32-channel half
+    const int wn0 = nt * 32;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tcols = a.Wo / kPatchCols, tper = (a.Ho / kPatchRows) * tcols;
+    const int img = tile_m / tper, tin = tile_m - img * tper;
+    const int oy0 = (tin / tcols) * kPatchRows, ox0 = (tin % tcols) * kPatchCols;
+    const int ncc = a.Cin >> 4;
+    const int npp = (ncc + 1) >> 1;                                  // periods of two 16-channel slabs (an odd count: the last slab is all zeros)
+    float in_scale = a.in_scale, in_unscale = a.in_unscale;
+    if (NPROD != 1 && a.in_amax) {                                   // |V| <= 2 max|x|: one bit of head-room more than the direct form
+        h2_device_scale(a.in_amax + img, a.in_bound_add, in_scale, in_unscale);
+        in_scale *= 0.5f; in_unscale *= 2.0f;
+    }
+
+    const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
+    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
+    tsnet_brsrc_t rsw[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
+
+    // ---- producer geometry (waves 0..5 = the six input rows of the tile; the others compute the same addresses and never use them):
+    //      lane -> (octet of the period's 32 channels lane >> 4, pair lane & 15); its four input pixels are columns ox0 - 1 + 2 pair + q
+    const bool producer = wave < 6;
+    const int prow = producer ? wave : 5, poct4 = lane >> 4, ppair = lane & 15;
+    unsigned vP[4];
+    float vM[4];
+    {
+        int iy = oy0 - 1 + prow;
+        bool rok = true;
+        if (a.reflect) {
+            iy = iy < 0 ? -iy : iy;
+            iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
+        } else {
+            rok = iy >= 0 && iy < a.H;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int ix = ox0 - 1 + 2 * ppair + q;
+            bool ok = rok;
+            if (a.reflect) {
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= a.W ? 2 * (a.W - 1) - ix : ix;
+            } else {
+                ok = ok && ix >= 0 && ix < a.W;
+            }
+            vP[q] = ok ? (unsigned)(((img * a.H * a.W + iy * a.W + ix) * a.Cin + poct4 * 8) * 4) : kOOB;
+            vM[q] = ok ? 1.f : 0.f;
+        }
+    }
+    float* tab = reinterpret_cast<float*>(smem_raw + OFF_TAB);       // [Cin] alpha*s, then [Cin] beta*s
+    if (AFFINE) {
+        for (int c = tid; c < a.Cin; c += 512) {
+            tab[c] = a.in_alpha[(size_t)img * a.Cin + c] * in_scale;
+            tab[a.Cin + c] = a.in_beta[(size_t)img * a.Cin + c] * in_scale;
+        }
+        __syncthreads();
+    }
+    const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();
+    F4 sx[4][2];                                                     // the lane's four pixels x eight channels
+    // period pq: channels 32 pq + 8 poct4 ... (past Cin: the next pixel's channels or zeros -- multiplied by zero weights)
+    auto v_load = [&](int pq) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) sx[q][h] = TSNET_BUF_LOAD16(rsx, vP[q], (unsigned)(pq * 128 + h * 16));
+    };
+    // the producer's pipeline, spread over the steps of a period: IN + ReLU of the pixels fetched a period ago (then the next fetch is
+    // issued: a whole period in flight), then one position per step
+    F4 d[4][2];
+    auto v_xform = [&](int pq) __attribute__((always_inline)) {
+        const int c0 = pq * 32 + poct4 * 8;
+        const float* ta = tab + (c0 < a.Cin ? c0 : 0);               // past the last channel: any valid entry (zero weights)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) transform_octet<AFFINE, ZPAD_KEEP>(sx[q], ta, a.Cin, in_scale, relu_floor, vM[q], d[q]);
+    };
+    auto v_store = [&](int st, int p) __attribute__((always_inline)) {            // position p into the stage at byte offset st
+        unsigned char* dst = smem_raw + st + (poct4 >> 1) * SLABB + (poct4 & 1) * REG + (prow * 16 + ppair) * 16 + p * POSB;
+        F4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = d[0][h].v[e], d1 = d[1][h].v[e], d2 = d[2][h].v[e], d3 = d[3][h].v[e];
+                v[h].v[e] = p == 0 ? d0 - d2 : (p == 1 ? d1 + d2 : (p == 2 ? d2 - d1 : d1 - d3));
+            }
+        F4 Hh, Ll;
+        if (NPROD == 1) {
+            bf16_octet(v[0], v[1], Hh);
+            *reinterpret_cast<F4*>(dst) = Hh;
+        } else {
+            split_h2_octet(v[0], v[1], Hh, Ll);
+            *reinterpret_cast<F4*>(dst) = Hh;
+            *reinterpret_cast<F4*>(dst + PLANE_V) = Ll;
+        }
+    };
+
+    // ---- fragments
+    const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
+    F4 af[2][5][NPL], bf[BD][NPL];                                   // [slab of the period][first row of the row pair][plane], [step][plane]
+    auto load_b = [&](int set, int cc, int ky) __attribute__((always_inline)) {   // a slab past the last one, or past the end of K: zeros
+        const int kc = (ky * 4 + pos) * ncc + cc;
+        const unsigned vo = cc < ncc ? vB : kOOB;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) bf[set][p] = TSNET_BUF_LOAD16(rsw[p], vo, (unsigned)((kc * a.Npad + n0) * 32));
+    };
+    const unsigned char* abase = smem_raw + pos * POSB + lh * REG + li * 16;
+    auto load_f = [&](int sl, int f, int st) __attribute__((always_inline)) {     // rows (f, f + 1) of slab sl of the stage at byte offset st
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) af[sl][f][p] = *reinterpret_cast<const F4*>(abase + st + sl * SLABB + p * PLANE_V + f * 256);
+    };
+
+    f32x16 acc[2], tot[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; tot[i][r] = 0.f; }
+    auto product = [&](int sl, int ky, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x16 c = acc[i];
+            if (fresh) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+            }
+            if (NPROD == 1) acc[i] = TSNET_MFMA_BF16(af[sl][ky + 2 * i][pa], bf[sb][pb], c);
+            else acc[i] = TSNET_MFMA_F16(af[sl][ky + 2 * i][pa], bf[sb][pb], c);
+        }
+    };
+    // One period = two slabs = six steps (t: slab t / 3, tap row t % 3) between two barriers = one accumulation chain.  Stage offsets: st_cur
+    // read now, st_nxt = period pp + 1 (complete before this period's barrier: its first fragments are fetched at the last step), st_wr =
+    // where period pp + 2 is produced.  Step (sl, ky) uses fragments ky and ky + 2 of slab sl; weights five steps ahead.
+    auto period = [&](int pp, int st_cur, int st_nxt, int st_wr) __attribute__((always_inline)) {
+        if (!(OPT & 128)) __syncthreads();                           // V(pp + 1) complete; every read of V(pp - 1) issued
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int sl = t / 3, ky = t % 3;
+            if (!(OPT & 32)) load_b((t + BD - 1) % BD, 2 * pp + (t + BD - 1) / 3, (t + BD - 1) % 3);
+            if (!(OPT & 64)) {
+                if (ky == 0) { load_f(sl, 1, st_cur); load_f(sl, 3, st_cur); }
+                if (ky == 1) load_f(sl, 4, st_cur);
+                if (t == 2) { load_f(1, 0, st_cur); load_f(1, 2, st_cur); }
+                if (t == 5) { load_f(0, 0, st_nxt); load_f(0, 2, st_nxt); }
+            }
+            if (producer && !(OPT & 16)) {
+                if (t == 0) { v_xform(pp + 2); v_load(pp + 3); }
+                if (t >= 1 && t <= 4) v_store(st_wr, t - 1);
+            }
+            const bool fresh = !ONE_LEVEL && t == 0;
+            if (NPROD == 1) {
+                product(sl, ky, t, 0, 0, fresh);
+            } else {
+                product(sl, ky, t, 1, 0, fresh);                     // lo * hi
+                product(sl, ky, t, 0, 1, false);                     // hi * lo
+                product(sl, ky, t, 0, 0, false);                     // hi * hi
+            }
+            __builtin_amdgcn_sched_barrier(0);                       // loads stay ahead of their use (conv_h2.hpp)
+        }
+        if (!ONE_LEVEL) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][r] += acc[i][r];
+        }
+    };
+
+    // prologue: V(0), V(1), the weights of the first five steps, the first fragments of period 0
+    if (producer) {
+        v_load(0); v_xform(0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v_store(0, p);
+        v_load(1); v_xform(1);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v_store(STAGE, p);
+        v_load(2);
+    }
+#pragma unroll
+    for (int i = 0; i < BD - 1; ++i) load_b(i, i / 3, i % 3);
+    __syncthreads();
+    load_f(0, 0, 0); load_f(0, 2, 0);
+    if (OPT & 32) load_b(BD - 1, 1, 2);
+    if (OPT & 64) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int f = 0; f < 5; ++f) load_f(sl, f, 0);
+    }
+    int st0 = 0, st1 = STAGE, st2 = 2 * STAGE;                       // stage of period pp, pp + 1, pp + 2
+    for (int pp = 0; pp < npp; ++pp) {
+        period(pp, st0, st1, st2);
+        const int t0 = st0; st0 = st1; st1 = st2; st2 = t0;
+    }
+    if (ONE_LEVEL) { tot[0] = acc[0]; tot[1] = acc[1]; }
+
+    // ---- output transform: the four positions of a pair meet through LDS
+    const float unscale = a.w_unscale ? in_unscale * a.w_unscale[0] : in_unscale;
+    __syncthreads();                                                 // every stage has been read
+    float* ex = reinterpret_cast<float*>(smem_raw);                  // [position][pair 64][channel 64]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pair = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            ex[(pos * 64 + pair) * 64 + wn0 + li] = tot[i][r] * unscale;              // exact: power of two
+        }
+    __syncthreads();
+    const int mq = wave >> 1;                                        // epilogue role: output row mq of the tile, channel half nt
+    f32x16 out[1][1];
+#pragma unroll
+    for (int r2 = 0; r2 < 8; ++r2) {                                 // accumulator rows 2 r2, 2 r2 + 1 = pixels (x, x + 1) of one pair
+        const int x = ((2 * r2) & 3) + 8 * ((2 * r2) >> 2) + 4 * lh;
+        const float* m = ex + (size_t)(mq * 16 + (x >> 1)) * 64 + wn0 + li;
+        const float m0 = m[0], m1 = m[64 * 64], m2 = m[2 * 64 * 64], m3 = m[3 * 64 * 64];
+        out[0][0][2 * r2] = (m0 + m1) + m2;
+        out[0][0][2 * r2 + 1] = (m1 - m2) - m3;
+    }
+    __syncthreads();                                                 // the shared epilogue reuses the region for its reductions
+    const int m_img = img * a.Ho * a.Wo;
+    conv_epilogue<64, 4, 2, 1, 1>(a, out, smem_raw, tid, wave, n0, (size_t)img * tper + tin,
+                                  [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); });
+}
+
+template <int NPROD, bool AFFINE, int OPT = 0>
+__global__ __launch_bounds__(512, 1)
+void conv_w1_kernel(ConvArgs a) {
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    int tile_m, tile_n;
+    tile_of_block(blockIdx.x, a.tiles_m, a.tiles_n, a.xcd_gn, tile_m, tile_n);
+    w1_tile<NPROD, AFFINE, OPT>(a, smem_raw, tile_m, tile_n * 64);
+}
+
+}  // namespace tsnet

@@ -148,6 +148,7 @@ struct ConvLayer {
     int cin_real = 0, cin_pad = 0, cout = 0, ks = 1, stride = 1, pad = 0, reflect = 0;
     int cin_total = 0, cin_off = 0;   // window of the parameter's input channels this layer consumes
     int kpad = 0, npad = 0;
+    int form = 0;                     // 0: the filter as it is (ks x ks taps); 1: its Winograd F(2,3)-along-x transform, 3 x 4 "taps" (conv_w1.hpp)
     size_t w_off = 0, b_off = 0;          // offsets into the packed buffer: operand planes (16-bit units from the plane section), bias (floats)
     const unsigned short* wq = nullptr;   // device: operand planes [planes][K/16][Npad][2 octets][8] (conv_common.hpp pack_weights_kernel)
     const float* w_unscale = nullptr;     // device scalar 2^-sw (in the packed buffer: replicas receive it with the broadcast); null in bf16 mode
@@ -158,6 +159,7 @@ constexpr size_t kFinCounterInts = 65536;   // size of the arrival-counter array
 constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded to an even number of 16-deep chunks (fragment prefetch runs up to two past the end)
 
 inline int conv_kpad(int ks, int cin_pad) { return round_up(ks * ks * cin_pad, KPAD_ALIGN); }
+inline int conv_kpad_w1(int cin_pad) { return round_up(12 * cin_pad, KPAD_ALIGN); }    // Winograd-along-x form: tap row ky x position p
 inline int conv_npad(int cout) { return cout >= 128 ? round_up(cout, 128) : round_up(cout, 64); }
 inline int conv_cin_pad(int cin) { return cin <= 8 ? 8 : round_up(cin, 16); }     // 8 (two taps per k-group) or a multiple of 16
 
@@ -196,7 +198,11 @@ inline int h2_scale_log2(float bound) {
 
 // Kernel class of a layer at a frame size.  The patch kernels sum K slab-major, the general one tap-major: the class must depend on the
 // layer and the geometry alone, never on the batch (a sample's result is the same bits in any batch).
-enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3 };
+enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3, K_W1 = 4 };
+// a layer packed in the Winograd-along-x form runs conv_w1 and nothing else: 3 x 3 / stride 1 / pad 1 on frames of whole 4 x 32 tiles
+inline bool w1_eligible(const ConvLayer& L, int H, int W) {
+    return L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H >= 4 && W >= 32 && H % kPatchRows == 0 && W % kPatchCols == 0;
+}
 // eligible_only: what the layer CAN run on (an explicit request, op tests / tools); otherwise what the forward runs it on
 inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool transform, int rows = kPatchRows, bool eligible_only = false) {
     const int Ho = (H + 2 * L.pad - L.ks) / L.stride + 1, Wo = (W + 2 * L.pad - L.ks) / L.stride + 1;
@@ -224,7 +230,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
     ConvArgs g{};
     g.x = c.x; g.x2 = c.x2; g.in_alpha = c.alpha; g.in_beta = c.alpha ? c.beta : nullptr; g.in_relu = c.relu;
     if (c.alpha && !c.beta) throw ArgError("conv: alpha without beta");
-    const int sa = (bf16 || c.in_amax) ? 0 : h2_scale_log2(c.bound);
+    const int sa = (bf16 || c.in_amax) ? 0 : h2_scale_log2(L.form == 1 ? 2.f * c.bound : c.bound);   // Winograd: |V| <= 2 max |x|
     g.in_scale = std::ldexp(1.0f, sa); g.in_unscale = std::ldexp(1.0f, -sa);
     g.in_amax = bf16 ? nullptr : c.in_amax; g.in_bound_add = c.bound_add; g.amax_out = c.amax_out;
     g.w = L.wq; g.w_unscale = bf16 ? nullptr : L.w_unscale; g.bias = L.bias; g.y = c.y;
@@ -233,7 +239,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
     g.Csplit = c.x2 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
     g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1; g.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
     g.Cout = L.cout; g.Npad = L.npad; g.stride = L.stride; g.pad = L.pad; g.reflect = L.reflect;
-    g.taps = L.ks * L.ks; g.nchunks = (g.taps * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
+    g.taps = L.form == 1 ? 12 : L.ks * L.ks; g.nchunks = (g.taps * g.Cin + 15) / 16; g.M = c.N * g.Ho * g.Wo;
     if (c.N < 1 || g.Ho < 1 || g.Wo < 1) throw ArgError("conv: empty tensor");
     if (L.reflect && (L.pad >= c.H || L.pad >= c.W)) throw ArgError("conv: reflection pad needs pad < input size");
     if (c.x2 && ((g.Csplit & 15) || g.Csplit <= 0 || g.Csplit >= g.Cin)) throw ArgError("conv: channel split must be a multiple of 16 inside the channel range");
@@ -242,7 +248,9 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         throw ArgError("conv: tensor too large for 32-bit buffer offsets");
     if ((size_t)2 * g.Cin * 4 > 32 * 1024) throw ArgError("conv: too many input channels for the transform table");
     const int hw = g.Ho * g.Wo;
-    const int cls = c.kernel == 1 ? K_GENERAL : conv_class(L, c.H, c.W, c.x2 != nullptr, c.alpha != nullptr, c.tile % 10000 >= 1000 ? c.tile % 10000 / 1000 : kPatchRows, c.kernel == 2);
+    if (L.form == 1 && (c.x2 || !w1_eligible(L, c.H, c.W))) throw ArgError("conv(w1): the layer is packed in the Winograd form, which needs a single source and whole 4 x 32 tiles");
+    if (L.form == 1 && c.nprod == 4) throw ArgError("conv(w1): 1 or 3 products");
+    const int cls = L.form == 1 ? K_W1 : c.kernel == 1 ? K_GENERAL : conv_class(L, c.H, c.W, c.x2 != nullptr, c.alpha != nullptr, c.tile % 10000 >= 1000 ? c.tile % 10000 / 1000 : kPatchRows, c.kernel == 2);
     if (c.kernel == 2 && cls == K_GENERAL) throw ArgError("conv: this layer / frame size has no patch kernel");
     g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f;
     TimeScope ts(ctx, c.tclass);
@@ -261,7 +269,16 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         return g.Npad % 128 == 0 && g.Cout > 64 && c128 < c64;
     };
     try {
-        if (cls == K_H2) {
+        if (cls == K_W1) {
+            if (c.opt) throw ArgError("conv(w1): no experiment variants");
+            set_tiles(kPatchRows * kPatchCols, 64);
+            int gn = c.xcd_gn < 0 ? 0 : c.xcd_gn;
+            if (gn && ((gn != 1 && gn != 2 && gn != 4 && gn != 8) || g.tiles_n % gn || g.tiles_m % (8 / gn))) throw ArgError("conv(w1): the XCD grid does not divide the tile matrix");
+            g.xcd_gn = gn;
+            launch_conv_w1(g, c.nprod, c.abl, ctx.stream);
+            ++g_launch_counters[0];
+            if (c.tclass == TSNET_T_CONV_RES) g_launch_counters[3] = 4064 + 30000;      // 4 x 32 pixels x 64 channels, Winograd form
+        } else if (cls == K_H2) {
             int pr = 4, bn = 0, opt = c.opt;
             if (c.tile) {
                 const int tc = c.tile % 10000, mode = c.tile / 10000;          // mode 2: deep prefetch + two K groups; 1 / 3: one of the two (tools build)
@@ -455,11 +472,27 @@ void run_warp(Ctx& ctx, const float* src, const float* flow, float* out, int B, 
     check_launch("warp_mean");
 }
 
-// weights of one layer -> operand planes + the un-scale factor; `stage` holds the OIHW parameter on the device
+// weights of one layer -> operand planes + the un-scale factor; `stage` holds the OIHW parameter on the device (form 1: its transform,
+// kernel 3 x 4)
 void pack_layer(const float* stage, const ConvLayer& L, unsigned short* planes_out, int planes, float scale, hipStream_t s) {
     hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid((size_t)L.kpad * L.npad)), dim3(256), 0, s, stage, planes_out, scale, planes,
-                       L.cout, L.cin_real, L.cin_pad, L.ks, L.kpad, L.npad, L.cin_total > 0 ? L.cin_total : L.cin_real, L.cin_off);
+                       L.cout, L.cin_real, L.cin_pad, L.ks, L.form == 1 ? 4 : L.ks, L.kpad, L.npad, L.cin_total > 0 ? L.cin_total : L.cin_real, L.cin_off);
     check_launch("pack_weights");
+}
+
+// Winograd F(2,3) filter transform along x (conv_w1.hpp): (O, I, 3, 3) -> (O, I, 3, 4),  U_p[ky] = sum_kx G[p][kx] g[ky][kx] with
+// G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], evaluated in fp64 and rounded once to fp32
+std::vector<float> winograd_x_filters(const std::vector<float>& w) {
+    if (w.size() % 9) throw ArgError("winograd filter transform: not a 3 x 3 kernel");
+    std::vector<float> u(w.size() / 9 * 12);
+    for (size_t i = 0; i < w.size() / 3; ++i) {                     // one (o, i, ky) row of three taps -> four positions
+        const double g0 = w[3 * i], g1 = w[3 * i + 1], g2 = w[3 * i + 2];
+        u[4 * i] = (float)g0;
+        u[4 * i + 1] = (float)(0.5 * (g0 + g1 + g2));
+        u[4 * i + 2] = (float)(0.5 * (g0 - g1 + g2));
+        u[4 * i + 3] = (float)g2;
+    }
+    return u;
 }
 
 // torch.linspace(-1, 1, n) in float32: step = (end-start)/(n-1); first half start+i*step, second half
@@ -1275,13 +1308,15 @@ namespace {
 struct OpLayer {
     ConvLayer L;
     float* wd = nullptr; float* bd = nullptr; float* un = nullptr; unsigned short* wq = nullptr;
-    OpLayer(const float* w_oihw, const float* bias, int Cin, int Cout, int ks, int stride, int pad, int reflect, int nprod, hipStream_t s) {
+    OpLayer(const float* w_oihw, const float* bias, int Cin, int Cout, int ks, int stride, int pad, int reflect, int nprod, hipStream_t s, int form = 0) {
         L.name = "op"; L.cin_real = Cin; L.cin_pad = conv_cin_pad(Cin); L.cin_total = Cin; L.cout = Cout; L.ks = ks; L.stride = stride; L.pad = pad;
-        L.reflect = reflect; L.kpad = conv_kpad(ks, L.cin_pad); L.npad = conv_npad(Cout);
+        L.reflect = reflect; L.form = form; L.kpad = form == 1 ? conv_kpad_w1(L.cin_pad) : conv_kpad(ks, L.cin_pad); L.npad = conv_npad(Cout);
         if (L.cin_pad != Cin) throw ArgError("conv2d op: Cin must be 8 or a multiple of 16 (pad channels with zeros)");
-        const size_t wn = (size_t)Cout * Cin * ks * ks;
+        if (form == 1 && (ks != 3 || stride != 1 || pad != 1)) throw ArgError("conv2d op: the Winograd form is for 3 x 3 / stride 1 / pad 1");
+        size_t wn = (size_t)Cout * Cin * ks * ks;
         std::vector<float> hw(wn);
         HIP_TRY(hipMemcpy(hw.data(), w_oihw, wn * sizeof(float), hipMemcpyDefault));
+        if (form == 1) { hw = winograd_x_filters(hw); wn = hw.size(); }
         float mx = 0.f;
         for (float v : hw) mx = std::max(mx, std::fabs(v));
         const int planes = nprod == 1 ? 1 : 2;
@@ -1313,9 +1348,9 @@ int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w
     if (nprod != 1 && nprod != 3 && nprod != 4) throw ArgError("conv2d op: 1 (bf16 operands), 3 or 4 products");
     hipStream_t s = (hipStream_t)stream;
     Ctx ctx; ctx.stream = s;
-    OpLayer op(w_oihw, bias, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s);
+    OpLayer op(w_oihw, bias, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s, kernel == 3 ? 1 : 0);     // kernel 3: Winograd-along-x form (conv_w1.hpp)
     ConvCall c; c.x = x; c.alpha = in_alpha; c.beta = in_beta; c.relu = in_relu; c.bound = bound; c.N = N; c.H = H; c.W = W; c.y = y;
-    c.nprod = nprod; c.kernel = kernel; c.tile = tile;
+    c.nprod = nprod; c.kernel = kernel == 3 ? 0 : kernel; c.tile = kernel == 3 ? 0 : tile;
     run_conv(ctx, op.L, c);
     HIP_TRY(hipStreamSynchronize(s));
     OP_END
@@ -1612,9 +1647,10 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     fill(x, xn, 2.f, 0.f); fill(al, (size_t)N * Cin, 1.f, 1.f); fill(be, (size_t)N * Cin, 0.5f, 0.f);
     fill(nullptr, wn, 0.1f, 0.f);
     {
-        OpLayer op(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s);
+        const int form = (v & 32768) ? 1 : 0;                       // bit 15: Winograd-along-x form
+        OpLayer op(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s, form);
         ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = norm ? 64.f : 1.f; c.nprod = nprod;
-        c.tile = v & 4095; c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 31; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0) | ((v & (1 << 22)) ? 32 : 0) | ((v & (1 << 21)) ? 64 : 0);
+        c.tile = form ? 0 : (v & 4095); c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 31; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0) | ((v & (1 << 22)) ? 32 : 0) | ((v & (1 << 21)) ? 64 : 0);
         { const int gx = (v >> 28) & 7; c.xcd_gn = gx == 0 ? -1 : (gx == 1 ? 0 : 1 << (gx - 2)); }          // bits 28-30: 0 default, 1 linear, 2..5 grid with 1, 2, 4, 8 columns
         if (norm) { c.alpha = al; c.beta = be; c.relu = 1; }
         for (int i = 0; i < 2; ++i) run_conv(ctx, op.L, c);

@@ -1,5 +1,5 @@
 // kernels.hpp -- launchers of the convolution kernels.  Each kernel family lives in its own translation unit (conv_h2_launch.cpp,
-// conv_h2r_launch.cpp) so that the library builds in parallel; engine.cpp holds the host logic and the small kernels.
+// conv_h2r_launch.cpp, conv_w1_launch.cpp) so that the library builds in parallel; engine.cpp holds the host logic and the small kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -15,6 +15,9 @@ namespace tsnet {
 void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int opt, hipStream_t s);
 void launch_conv_h2s(const ConvArgs& a, int nprod, hipStream_t s);
 void launch_conv_h2d(const ConvArgs& a, int pr, int bn, int nprod, hipStream_t s);
+// conv_w1.hpp -- 3x3 / stride 1 / pad 1 as Winograd F(2,3) along x: 4 x 32 pixels x 64 channels per tile (eight waves); the layer's
+// weights are the TRANSFORMED filters (12 "taps": tap row ky x position p, pack_weights_kernel with kh = 3, kw = 4)
+void launch_conv_w1(const ConvArgs& a, int nprod, int abl, hipStream_t s);      // abl: tools build only
 // conv_h2r.hpp -- general implicit GEMM: ks in {1, 3, 7}, bn = 64 (any) or 128 (ks = 3, Cin >= 16); Cin = 8 or a power of two >= 16
 void launch_conv_h2r(const ConvArgs& a, int ks, int bn, int nprod, hipStream_t s);
 
