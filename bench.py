@@ -173,18 +173,21 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
             cnt = (ctypes.c_int64 * 4)()
             eng.lib.tsnet_debug_counters(cnt, 0)
             code = int(cnt[3]) % 10000               # + 20000: the two-K-group tiles of single-frame forwards (not this workload)
+            wino = int(cnt[3]) // 10000 == 3         # + 30000: the Winograd-along-x form (conv_w1.hpp)
             pr, bn = code // 1000, code % 1000
             flop_per_launch = 2.0 * (K * batch * P) * C * (9 * C)
             avg_ms = res_ms / res_launches
             achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = _pmc_traffic_bytes("conv_h2<%d,%d," % (pr, bn)) if cuda else (None, "not a GPU run")
+            traffic, traffic_src = _pmc_traffic_bytes("conv_w1<" if wino else "conv_h2<%d,%d," % (pr, bn)) if cuda else (None, "not a GPU run")
             roofline = {"bound": "mfma",
-                        "kernel": "conv_h2_kernel<%d rows, %d channels, ...> (3x3 ResnetBlock convolution, %d launches per forward = %.0f %% of the forward)"
-                                  % (pr, bn, res_launches // nprobe, 100.0 * res_ms / nprobe / (dt * 1e3 / steps)),
+                        "kernel": "%s<%d rows, %d channels, ...> (3x3 ResnetBlock convolution%s, %d launches per forward = %.0f %% of the forward)"
+                                  % ("conv_w1_kernel" if wino else "conv_h2_kernel", pr, bn, ", Winograd F(2,3) along x: 2/3 of the direct form's MFMA products" if wino else "",
+                                     res_launches // nprobe, 100.0 * res_ms / nprobe / (dt * 1e3 / steps)),
                         "achieved": round(achieved, 2), "peak": round(PEAK_H2_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(achieved / PEAK_H2_TFLOPS, 4),
                         "traffic": traffic, "traffic_source": traffic_src,
                         "peak_basis": "2500 TF dense fp16 MFMA / 3 fp16 products per fp32 product (2-way split of the scaled operand, conv_common.hpp)",
-                        "mfma_flops_issued_tflops": round(achieved * 3, 1),
+                        # fp16 MFMA work actually issued: 3 products per fp32 product, on 2/3 of the products in the Winograd form
+                        "mfma_flops_issued_tflops": round(achieved * (2.0 if wino else 3.0), 1),
                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                         # the strict reading -- algorithmic fp32 FLOP / dense fp16 MFMA peak, no credit for the 3 products each one costs
                         "frac_of_f16_mfma_peak_algorithmic": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),

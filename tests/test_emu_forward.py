@@ -185,3 +185,30 @@ def test_bf16_operand_mode(emu_lib):
     r2, _ = eng.forward_target(inp[3], inp[4])
     assert torch.equal(rec, r2)
     eng.close()
+
+
+def test_wide_frame_runs_the_feature_resolution_kernels(emu_lib):
+    """A 32 x 256 frame (features 4 x 32): here the ResnetBlocks, FuseNet and the first decoder up-convolution run the Winograd-along-x kernel
+    (conv_w1.hpp), the stride-2 layers their patch kernel -- the kernels of the full-size forward, which 32 x 32 frames never reach.  Against
+    the oracle; and, since a layer has one packed form and one kernel in every batch, a frame run alone equals its copy inside the batch on
+    everything those kernels produce (the layers left on the direct kernel take other tiles for a single frame: agreement to rounding)."""
+    cfg, sd, inp = _case(K=2, nb=1, B=2, H=32, W=256, enc_blocks=1, seed=5)
+    ref = O.tsnet_forward(sd, cfg, *inp, want_stages=True)
+    eng = Hh.make_engine(cfg, sd, 32, 256, 2, "cpu", lib=emu_lib)
+    emu_lib.tsnet_debug_counters(None, 1)
+    rec, flows = Hh.run_engine(eng, inp, "cpu")
+    cnt = (C.c_int64 * 4)()
+    emu_lib.tsnet_debug_counters(cnt, 1)
+    assert cnt[3] == 34064, cnt[3]                       # the ResnetBlock layers ran conv_w1 (4 x 32 pixels x 64 channels, Winograd form)
+    assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
+    for a, b in zip(flows, ref["flows"]):
+        assert (a - b).abs().max().item() < 1e-4
+    rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, 2, "cpu")
+    assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4
+    src_batch = Hh.nhwc_to_nchw(eng.stage("src_fea", "cpu").cpu())
+    sub = ([x[1:2] for x in inp[0]], [x[1:2] for x in inp[1]], [x[1:2] for x in inp[2]], inp[3][1:2], inp[4][1:2])
+    one, _ = Hh.run_engine(eng, sub, "cpu")
+    src_one = Hh.nhwc_to_nchw(eng.stage("src_fea", "cpu").cpu())
+    assert (one - rec[1:2]).abs().max().item() < 5e-4
+    assert torch.equal(src_one[0], src_batch[1]) and torch.equal(src_one[1], src_batch[3])       # image index s * B + b
+    eng.close()

@@ -113,10 +113,10 @@ def test_cfg0_batch_items_independent(cfg0):
 
 
 def test_single_frame_forward(cfg0):
-    """B = 1, the reference demo's own call (demo_face.py:185-192): launches of at most one tile per CU run the two-K-group tiles (eight
-    waves, total = P0 + P1).  Same parity bar against the reference golden as the batched forward; against the same frame inside the
-    batch only agreement to fp32 rounding (amplified by the network) -- another association of the same chains -- which is measured and
-    bounded here; run-to-run the single-frame forward is bit-identical."""
+    """B = 1, the reference demo's own call (demo_face.py:185-192).  The ResnetBlock / FuseNet layers run the Winograd-along-x kernel in every
+    batch (one packed form per layer: the same bits alone or in a batch); the layers left on the direct kernel take its two-K-group tiles
+    when a launch has at most one tile per CU (total = P0 + P1: another association of the same chains), so a frame run alone agrees
+    with its copy inside a batch to fp32 rounding amplified by the network -- bounded here; run-to-run it is bit-identical."""
     import ctypes
     from wacv23_tsnet_amd import _lib
     eng, inputs, rec, z = cfg0["eng"], cfg0["inputs"], cfg0["rec"], cfg0["z"]
@@ -125,7 +125,7 @@ def test_single_frame_forward(cfg0):
     r1, f1 = Hh.run_engine(eng, sub, DEV)
     cnt = (ctypes.c_int64 * 4)()
     _lib.load().tsnet_debug_counters(cnt, 0)
-    assert cnt[3] == 24064, cnt[3]                  # the ResnetBlock layers of one frame: 4 x 64 tiles, two K groups
+    assert cnt[3] == 34064, cnt[3]                  # the ResnetBlock layers: 4 x 32 pixels x 64 channels, Winograd form (conv_w1)
     r2, _ = Hh.run_engine(eng, sub, DEV)
     assert torch.equal(r1, r2)
     d_crop = np.abs(r1[:, :, 96:128, 96:128].numpy() - z["rec_crop"][sl]).max()
@@ -133,7 +133,7 @@ def test_single_frame_forward(cfg0):
     d_batch = (r1 - rec[sl]).abs().max().item()
     print(f"[cfg0, B=1] d_crop={d_crop:.2e} d_flow={d_flow:.2e} vs the same frame in the batch of 4: {d_batch:.2e}")
     assert d_crop <= TOL_REC and d_flow <= TOL_FLOW
-    assert 0 < d_batch <= 5e-4
+    assert d_batch <= 5e-4
     Hh.run_engine(eng, inputs, DEV)                 # leave the engine as the other tests expect it (last_B = 4)
 
 
@@ -240,8 +240,9 @@ def test_packed_weight_buffer_goes_through_rccl(cfg0):
     try:
         buf = eng.packed_weights(DEV)
         # what a replica receives is what its kernels read: two fp16 planes of the 67 M weights (+ K / N padding), the RGB-head table,
-        # biases and the per-layer un-scale factors -- nothing else (<= 300 MB)
-        assert buf.dtype == torch.uint8 and 4 * 67_000_000 < buf.numel() < 300_000_000
+        # biases and the per-layer un-scale factors -- nothing else (<= 300 MB; + 84 MB since the ResnetBlock / FuseNet layers carry
+        # their Winograd-transformed filters: 12 instead of 9 taps)
+        assert buf.dtype == torch.uint8 and 4 * 67_000_000 < buf.numel() < 360_000_000
         dist.broadcast(buf, src=0)
         torch.cuda.synchronize()
     finally:

@@ -61,7 +61,7 @@ if SEL == "downsmall":  # stride-2 shapes of a single frame
 if SEL == "w1":         # Winograd F(2,3) along x (conv_w1.hpp) against the direct patch kernel, layer by layer
     W1 = ("w1 (winograd-x)", code(w1=True))
     run("res (B=4: 12 images)", RES, [("4x64 direct", code(64)), W1])
-    run("res w1 ablations", RES, [W1] + [(f"w1 abl{m}", code(w1=True, abl=m)) for m in (1, 2, 4, 3, 7, 8, 15)], norms=(0,))
+    run("res w1 ablations", RES, [W1] + [(f"w1 abl{m}", code(w1=True, abl=m)) for m in (1, 2, 4, 3, 7, 8, 15, 16, 17)], norms=(0,))
     run("res (B=8: 24 images)", (24, 32, 32, 512, 512, 3, 1, 1, 1), [("4x64 direct", code(64)), W1])
     run("res (B=1: 3 images)", (3, 32, 32, 512, 512, 3, 1, 1, 1), [("4x64 deep kg2", code(64, opt=24)), W1])
     run("res clip (1 image)", (1, 32, 32, 512, 512, 3, 1, 1, 1), [("4x32 deep kg2", code(32, opt=24)), W1])

@@ -11,13 +11,14 @@ namespace {
 template <int NPROD, bool AFFINE, int OPT>
 void go_w1_k(const ConvArgs& a, size_t lds, hipStream_t s) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(conv_w1_kernel<NPROD, AFFINE, OPT>), lds);
-    hipLaunchKernelGGL((conv_w1_kernel<NPROD, AFFINE, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_w1_kernel<NPROD, AFFINE, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(64 * kW1Waves), lds, s, a);
 }
 
 template <int NPROD>
 void go_w1(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)w1_lds_bytes(a.Cin, NPROD == 1 ? 1 : 2);
-    if (!a.in_alpha) go_w1_k<NPROD, false, 0>(a, lds, s);
+    if (!a.in_alpha && !a.in_relu) go_w1_k<NPROD, false, 2>(a, lds, s);
+    else if (!a.in_alpha) go_w1_k<NPROD, false, 0>(a, lds, s);
     else if (a.reflect) go_w1_k<NPROD, true, 0>(a, lds, s);
     else go_w1_k<NPROD, true, 1>(a, lds, s);          // zero padding under a fused InstanceNorm: padded pixels re-zeroed after the transform
 }
@@ -29,8 +30,8 @@ void launch_conv_w1(const ConvArgs& a, int nprod, int abl, hipStream_t s) {
 #ifdef TSNET_TOOLS
         const size_t lds = (size_t)w1_lds_bytes(a.Cin, 2);
         if (nprod != 3 || a.in_alpha) throw std::invalid_argument("conv(w1): ablations are built for three products on a raw input");
-#define TSNET_W1_ABL(A_) if (abl == A_) { go_w1_k<3, false, (A_) << 4>(a, lds, s); return; }
-        TSNET_W1_ABL(1) TSNET_W1_ABL(2) TSNET_W1_ABL(4) TSNET_W1_ABL(3) TSNET_W1_ABL(7) TSNET_W1_ABL(8) TSNET_W1_ABL(15)
+#define TSNET_W1_ABL(A_) if (abl == A_) { go_w1_k<3, false, ((A_) << 4) | 2>(a, lds, s); return; }
+        TSNET_W1_ABL(1) TSNET_W1_ABL(2) TSNET_W1_ABL(4) TSNET_W1_ABL(3) TSNET_W1_ABL(7) TSNET_W1_ABL(8) TSNET_W1_ABL(15) TSNET_W1_ABL(16) TSNET_W1_ABL(17)
 #undef TSNET_W1_ABL
         throw std::invalid_argument("conv(w1): this ablation is not instantiated");
 #else

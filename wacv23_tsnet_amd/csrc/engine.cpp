@@ -272,8 +272,12 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         if (cls == K_W1) {
             if (c.opt) throw ArgError("conv(w1): no experiment variants");
             set_tiles(kPatchRows * kPatchCols, 64);
-            int gn = c.xcd_gn < 0 ? 0 : c.xcd_gn;
-            if (gn && ((gn != 1 && gn != 2 && gn != 4 && gn != 8) || g.tiles_n % gn || g.tiles_m % (8 / gn))) throw ArgError("conv(w1): the XCD grid does not divide the tile matrix");
+            // weight planes far beyond an XCD's L2 (FuseNet's 1024 -> 1024: 50 MB): a 2 x 4 XCD grid streams a quarter of them per XCD (603 -> 565 us)
+            int gn = c.xcd_gn < 0 ? (((double)L.kpad * L.npad * 4 > 16e6) ? 4 : 0) : c.xcd_gn;
+            if (gn && ((gn != 1 && gn != 2 && gn != 4 && gn != 8) || g.tiles_n % gn || g.tiles_m % (8 / gn))) {
+                if (c.xcd_gn >= 0) throw ArgError("conv(w1): the XCD grid does not divide the tile matrix");
+                gn = 0;
+            }
             g.xcd_gn = gn;
             launch_conv_w1(g, c.nprod, c.abl, ctx.stream);
             ++g_launch_counters[0];
@@ -679,6 +683,19 @@ void tsnet_engine::build_layers() {
         ++n;
     }
     dec_head = make_conv("dec.model" + std::to_string(n) + ".1", c.ngf, 3, 7, 1, 3, 1);
+    // ---- Winograd-along-x form (conv_w1.hpp) for the 3 x 3 / stride-1 layers it wins on, where the frame splits into whole 4 x 32 tiles: the
+    // ResnetBlocks (127 / 133 us against 153 / 150 us at the headline batch, 39 against 50 us for one frame), FuseNet (266 / 87 / 565 us
+    // against 293 / 101 / 618), the decoder's first up-convolution (86 against 101 us); profiles/round4_conv_variants.txt.  The later
+    // up-convolutions (128^2: equal; 256^2: 120 against 111 us) and the bf16-operand mode keep the direct kernel.  A layer has ONE packed
+    // form and therefore one kernel in every batch.
+    auto to_w1 = [&](ConvLayer& L, int hh, int ww) {
+        if (np == 1 || !w1_eligible(L, hh, ww)) return;
+        L.form = 1; L.kpad = conv_kpad_w1(L.cin_pad);
+    };
+    for (size_t i = 1 + c.n_downsampling; i < img_enc.size(); ++i) to_w1(img_enc[i], h, w);
+    to_w1(fuse_c1_src, h, w); to_w1(fuse_c1_tar, h, w); to_w1(fuse_c2, h, w);
+    for (auto& L : dec_res) to_w1(L, h, w);
+    if (!dec_up.empty()) to_w1(dec_up[0], 2 * h, 2 * w);
     for (auto& L : img_enc) all_layers.push_back(&L);
     for (auto& L : lbl_enc) all_layers.push_back(&L);
     all_layers.push_back(&fuse_c1_src); all_layers.push_back(&fuse_c1_tar);
@@ -711,7 +728,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     HIP_TRY(hipMalloc((void**)&wpack, wpack_floats * sizeof(float)));
     HIP_TRY(hipMemsetAsync(wpack, 0, wpack_floats * sizeof(float), s));
     size_t max_w = 0;
-    for (ConvLayer* L : all_layers) max_w = std::max(max_w, (size_t)L->cout * L->cin_total * L->ks * L->ks);
+    for (ConvLayer* L : all_layers) max_w = std::max(max_w, (size_t)L->cout * L->cin_total * L->ks * (L->form == 1 ? 4 : L->ks));
     max_w = std::max(max_w, (size_t)3 * cfg.ngf * 49);
     float* stage = nullptr;
     HIP_TRY(hipMalloc((void**)&stage, max_w * sizeof(float)));
@@ -719,13 +736,17 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     for (size_t i = 0; i < all_layers.size(); ++i) {
         ConvLayer* L = all_layers[i];
         const Param& pw = params[pindex[L->wparam]];
+        // the filter as the kernel consumes it: itself, or its Winograd transform along x (fp64 on the host, rounded once)
+        std::vector<float> wino;
+        if (L->form == 1) wino = winograd_x_filters(pw.host);
+        const std::vector<float>& wsrc = L->form == 1 ? wino : pw.host;
         // per layer a power-of-two scale from the largest |weight|: |w * 2^sw| <= 2^15
         float mx = 0.f;
-        for (float v : pw.host) { const float av = std::fabs(v); if (av > mx) mx = av; }
+        for (float v : wsrc) { const float av = std::fabs(v); if (av > mx) mx = av; }
         if (!std::isfinite(mx)) throw WeightError("parameter '" + L->wparam + "' holds a non-finite value");
         const int sw = (np != 1 && mx > 0.f) ? h2_scale_log2(mx) : 0;
         const float unscale = std::ldexp(1.0f, -sw);
-        HIP_TRY(hipMemcpyAsync(stage, pw.host.data(), pw.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(stage, wsrc.data(), wsrc.size() * sizeof(float), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(wpack + tab_off + i, &unscale, sizeof(float), hipMemcpyHostToDevice, s));
         pack_layer(stage, *L, planes_base + L->w_off, planes, std::ldexp(1.0f, sw), s);
         if (!L->bparam.empty()) {
