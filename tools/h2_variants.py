@@ -16,10 +16,10 @@ torch.zeros(1, device="cuda")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 
 
-def code(tile=0, general=False, abl=0, opt=0, xcd=None, patch=False, w1=False):
+def code(tile=0, general=False, abl=0, opt=0, xcd=None, patch=False, w1=False, cold=False):
     """xcd: None = the launcher's choice, 0 = consecutive tiles per XCD, 1 / 2 / 4 / 8 = columns of the XCD grid over the N tiles"""
     gx = 0 if xcd is None else (1 if xcd == 0 else {1: 2, 2: 3, 4: 4, 8: 5}[xcd])
-    return tile | (4096 if general else 0) | (16384 if patch else 0) | (32768 if w1 else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | ((1 << 22) if opt & 32 else 0) | ((1 << 21) if opt & 64 else 0) | (gx << 28)
+    return tile | (4096 if general else 0) | (16384 if patch else 0) | (32768 if w1 else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | ((1 << 22) if opt & 32 else 0) | ((1 << 21) if cold else 0) | (gx << 28)
 
 
 def run(name, shape, variants, norms=(0, 1), iters=8):
@@ -60,7 +60,7 @@ if SEL == "downsmall":  # stride-2 shapes of a single frame
     sys.exit(0)
 if SEL == "w1":         # Winograd F(2,3) along x (conv_w1.hpp) against the direct patch kernel, layer by layer
     W1 = ("w1 (winograd-x)", code(w1=True))
-    run("res (B=4: 12 images)", RES, [("4x64 direct", code(64)), W1])
+    run("res (B=4: 12 images)", RES, [("4x64 direct", code(64)), W1, ("4x64 direct, cold weights", code(64, cold=True)), ("w1, cold weights", code(w1=True, cold=True))], iters=24)
     run("res w1 ablations", RES, [W1] + [(f"w1 abl{m}", code(w1=True, abl=m)) for m in (1, 2, 4, 3, 7, 8, 15, 16, 17)], norms=(0,))
     run("res (B=8: 24 images)", (24, 32, 32, 512, 512, 3, 1, 1, 1), [("4x64 direct", code(64)), W1])
     run("res (B=1: 3 images)", (3, 32, 32, 512, 512, 3, 1, 1, 1), [("4x64 deep kg2", code(64, opt=24)), W1])

@@ -205,7 +205,7 @@ __device__ __forceinline__ void transform_octet(const F4 (&sx)[2], const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Shared epilogue: bias, optional per-pixel addend, fp64 InstanceNorm partial sums of the tile (fixed order: deterministic), fp32 store.
+// Shared epilogue: bias, optional per-pixel addend, fp64 InstanceNorm partial sums of the tile (fixed order: deterministic), fp32 store (last).
 // m_of(l) maps the local row l of the tile to the output position m (or -1: a row past the end of the image).
 template <int BN, int WARPS_M, int WARPS_N, int MT, int NTL, typename MOf>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[MT][NTL], unsigned char* smem_raw, int tid, int wave, int n0,
@@ -218,6 +218,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
 #pragma unroll
     for (int j = 0; j < NTL; ++j) { csum[j] = 0.0; csq[j] = 0.0; }
     float vmax = 0.f;
+    // pass 1: the values (bias, addend) in place, their statistics and maximum.  The stores come LAST (pass 2 below): the statistics
+    // hand-off drains this wave's outstanding stores before the workgroup counts itself, and with the tile's 32 - 64 KiB of output in
+    // flight that drain was the longest wait of the epilogue -- exposed in full where one workgroup owns the CU (conv_w1).
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -234,10 +237,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
                     const int img = m / hw;
                     v += a.addend[((size_t)(img % a.add_nmod) * hw + (m - img * hw)) * a.Cout + n];
                 }
+                tot[i][j][r] = v;
                 if (a.stat_part && mok) { csum[j] += (double)v; csq[j] += (double)v * (double)v; }
-                if (!nok || !mok) continue;
-                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
-                a.y[(size_t)m * a.Cout + n] = v;
+                if (nok && mok) vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
             }
         }
     }
@@ -299,6 +301,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
                     a.fin_beta[(size_t)img * a.Cout + n0 + tid] = -((float)mean) * al;
                 }
                 if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+        }
+    }
+    // pass 2: the fp32 stores
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int n = n0 + wn0 + j * 32 + li;
+            if (n >= a.Cout) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_of(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+                if (active && m >= 0) a.y[(size_t)m * a.Cout + n] = tot[i][j][r];
             }
         }
     }

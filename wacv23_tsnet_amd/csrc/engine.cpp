@@ -13,8 +13,12 @@
 //   dec map 1x1 (cat on load) -> ResnetBlocks -> 3x (upsample, conv) -> 7x7+tanh [A8, A9]
 // Every convolution reads the producer's RAW fp32 output and applies that producer's InstanceNorm + ReLU while it stages its operand
 // tile; operands enter the matrix pipe as fp16 x 2 splits (three products) or, with tsnet_cfg.operand_mode = 1, as one bf16 plane.
-// Which kernel a layer runs on (patch kernels of conv_h2.hpp where the output splits into 4 x 32 rectangles, the general implicit GEMM of
-// conv_h2r.hpp elsewhere) depends on the layer and the frame size only -- never on the batch, never on the environment.
+// Which kernel a layer runs on (the Winograd-along-x kernel of conv_w1.hpp for the ResnetBlock / FuseNet / first up-convolution layers and
+// the patch kernels of conv_h2.hpp where the output splits into 4 x 32 rectangles, the general implicit GEMM of conv_h2r.hpp elsewhere)
+// depends on the layer and the frame size only -- never on the batch, never on the environment.  The TILE a direct patch kernel takes
+// does depend on the batch in one case: a forward of ONE frame (B = 1) runs launches of at most a tile per CU as two K groups, another
+// association of the same chains -- a frame run alone agrees with its copy inside a batch to fp32 rounding on those layers, bit for bit
+// on every other one and in any two batches of >= 2 frames (tests/test_gpu_forward.py::test_single_frame_forward).
 // InstanceNorm statistics: fp64 partial sums in the producing conv's epilogue, finalised there by the last-arriving workgroup
 // (or by in_finalize2 when an image has many tiles).
 #include <hip/hip_runtime.h>
@@ -25,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -197,7 +202,7 @@ inline int h2_scale_log2(float bound) {
 }
 
 // Kernel class of a layer at a frame size.  The patch kernels sum K slab-major, the general one tap-major: the class must depend on the
-// layer and the geometry alone, never on the batch (a sample's result is the same bits in any batch).
+// layer and the geometry alone, never on the batch (a sample's result is the same bits in any batch of >= 2 frames; B = 1: see run_conv).
 enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3, K_W1 = 4 };
 // a layer packed in the Winograd-along-x form runs conv_w1 and nothing else: 3 x 3 / stride 1 / pad 1 on frames of whole 4 x 32 tiles
 inline bool w1_eligible(const ConvLayer& L, int H, int W) {
@@ -1650,7 +1655,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     hipStream_t s = (hipStream_t)stream;
     Ctx ctx; ctx.stream = s;
     // variant (-1 = the layer's own kernel and tile): bits 0-11 tile code (ConvCall::tile), bit 12 general kernel, bit 13 bf16 operands, bit 14 patch kernel,
-    // bits 16-20 ablation mask, bit 21 four workgroups per CU, bit 22 weights five steps ahead, bit 23 two K groups, bits 24-27 experiment mask (8 = deep prefetch; the rest tools build), bits 28-30 XCD grid
+    // bits 16-20 ablation mask, bit 21 cold weights (a fresh copy of the planes per launch), bit 22 weights five steps ahead, bit 23 two K groups, bits 24-27 experiment mask (8 = deep prefetch; the rest tools build), bits 28-30 XCD grid
     const int v = variant < 0 ? 0 : variant;
     const int nprod = (v & 8192) ? 1 : 3;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -1670,15 +1675,19 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     {
         const int form = (v & 32768) ? 1 : 0;                       // bit 15: Winograd-along-x form
         OpLayer op(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s, form);
+        // bit 21: COLD weights -- every launch reads another copy of the packed planes (24 copies: beyond the 256 MiB Infinity Cache for the
+        // big layers), as consecutive layers of a forward do; the default re-launches one layer, whose planes stay cache-resident
+        std::vector<std::unique_ptr<OpLayer>> cold;
+        if (v & (1 << 21)) for (int i = 0; i < 24; ++i) cold.emplace_back(new OpLayer(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s, form));
         ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = norm ? 64.f : 1.f; c.nprod = nprod;
-        c.tile = form ? 0 : (v & 4095); c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 31; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0) | ((v & (1 << 22)) ? 32 : 0) | ((v & (1 << 21)) ? 64 : 0);
+        c.tile = form ? 0 : (v & 4095); c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 31; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0) | ((v & (1 << 22)) ? 32 : 0);
         { const int gx = (v >> 28) & 7; c.xcd_gn = gx == 0 ? -1 : (gx == 1 ? 0 : 1 << (gx - 2)); }          // bits 28-30: 0 default, 1 linear, 2..5 grid with 1, 2, 4, 8 columns
         if (norm) { c.alpha = al; c.beta = be; c.relu = 1; }
         for (int i = 0; i < 2; ++i) run_conv(ctx, op.L, c);
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) run_conv(ctx, op.L, c);
+        for (int i = 0; i < iters; ++i) run_conv(ctx, cold.empty() ? op.L : cold[(size_t)i % cold.size()]->L, c);
         HIP_TRY(hipEventRecord(e1, s));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
