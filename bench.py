@@ -243,6 +243,19 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
                   "frac_of_bf16_mfma_peak": round(8 * n2 / d2 * g2 / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
                   "parity": "own tolerance, tests/test_gpu_forward.py::test_cfg2_bf16_face_checkpoint_shape_b8 (helpers.bf16_mode_report)"}
         e2.close()
+        # the same with bf16 STORAGE of the large activations on top (operand_mode 2)
+        e3 = TSNetEngine(label_nc=2, n_blocks=4, n_downsampling=3, n_source=3, height=height, width=width, max_batch=8, operands="bf16s", lib=lib)
+        build_replica(e3, synth.state_dict(e3.param_shapes(), seed=0), dev, src=0)
+        for _ in range(5):
+            e3.forward(*i2)
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(n2):
+            e3.forward(*i2)
+        sync()
+        d3 = time.perf_counter() - t3
+        second["with_bf16_storage"] = {"value": round(8 * n2 / d3, 2), "unit": "frames/s", "ms_per_step": round(d3 / n2 * 1e3, 3)}
+        e3.close()
         eng = TSNetEngine(height=height, width=width, max_batch=batch, lib=lib, **eng_kw)      # forward_macs below
 
     frames = world * batch * steps

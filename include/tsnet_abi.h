@@ -52,7 +52,10 @@ typedef struct tsnet_cfg {
     int max_batch;       /* largest B a forward will be called with (workspace is sized once) */
     int operand_mode;    /* 0 = fp32-class arithmetic (default: split operands, parity 1e-3 with the fp32 reference);
                           * 1 = bf16 operands (BASELINE.json configs[2] / [4]): every convolution input and weight is rounded to bf16,
-                          *     one MFMA product, fp32 accumulate, fp32 InstanceNorm / softmax / RGB head.  Own tolerance. */
+                          *     one MFMA product, fp32 accumulate, fp32 InstanceNorm / softmax / RGB head.  Own tolerance.
+                          * 2 = mode 1 + bf16 STORAGE of the large convolution-to-convolution activations (the encoders' 256^2 .. 64^2 maps,
+                          *     the decoder's up-convolution outputs and upsampled inputs): statistics from the fp32 accumulators, the
+                          *     stored tensor rounded once, widened exactly by its consumer. */
 } tsnet_cfg;
 
 /* ---- lifecycle ---------------------------------------------------------------------------

@@ -69,18 +69,41 @@ def _conv(x, w, b=None, **kw):
     return F.conv2d(_r(x), _r(w), b, **kw)
 
 
+_STORE_BF16 = False     # set by tsnet_forward(round_operands="bf16s"): the engine's bf16-STORAGE mode (tsnet_cfg.operand_mode = 2)
+
+
+def _s(t: torch.Tensor) -> torch.Tensor:
+    """bf16 storage: a tensor the engine keeps in bf16 between two kernels is rounded once where it is written"""
+    return t.to(torch.bfloat16).to(t.dtype) if _STORE_BF16 else t
+
+
+def _in_s(x: torch.Tensor) -> torch.Tensor:
+    """InstanceNorm of a convolution output that the bf16-storage mode keeps in bf16: the statistics come from the fp32 accumulators (the
+    unrounded tensor), the normalised tensor is the stored (rounded) one"""
+    if not _STORE_BF16:
+        return _in(x)
+    mean = x.mean(dim=(2, 3), keepdim=True)
+    var = x.var(dim=(2, 3), unbiased=False, keepdim=True)
+    return (_s(x) - mean) * torch.rsqrt(var + 1e-5)
+
+
 class bf16_operands:
     """context manager: the layer functions of this module (encoder, fuse_net, decoder, ...) round their convolution operands to
-    bf16 inside it -- for checks of one stage of the engine's bf16-operand mode in isolation"""
+    bf16 inside it (storage=True: and keep the large activations in bf16, operand_mode 2) -- for checks of one stage of the engine's bf16
+    modes in isolation"""
+
+    def __init__(self, storage: bool = False):
+        self.storage = storage
 
     def __enter__(self):
-        global _ROUND_BF16
-        self._old, _ROUND_BF16 = _ROUND_BF16, True
+        global _ROUND_BF16, _STORE_BF16
+        self._old, _ROUND_BF16 = (_ROUND_BF16, _STORE_BF16), True
+        _STORE_BF16 = self.storage
         return self
 
     def __exit__(self, *a):
-        global _ROUND_BF16
-        _ROUND_BF16 = self._old
+        global _ROUND_BF16, _STORE_BF16
+        _ROUND_BF16, _STORE_BF16 = self._old
         return False
 
 
@@ -122,11 +145,11 @@ def encoder(x: torch.Tensor, sd: Dict[str, torch.Tensor], net: str, cfg: TSNetCo
         x = coord_conv(x)
     p = net + ".model."
     x = _conv(F.pad(x, (3, 3, 3, 3), mode="reflect"), sd[p + "1.weight"], sd[p + "1.bias"])
-    x = F.relu(_in(x))
+    x = F.relu(_in_s(x) if cfg.n_downsampling > 0 else _in(x))      # bf16 storage: the stem's and all but the last down-convolution's outputs
     idx = 4
-    for _ in range(cfg.n_downsampling):
+    for l in range(cfg.n_downsampling):
         x = _conv(x, sd[p + f"{idx}.weight"], sd[p + f"{idx}.bias"], stride=2, padding=1)
-        x = F.relu(_in(x))
+        x = F.relu(_in_s(x) if l + 1 < cfg.n_downsampling else _in(x))
         idx += 3
     for _ in range(n_blocks):
         x = resnet_block(x, sd, p + f"{idx}.")
@@ -156,9 +179,9 @@ def decoder(prop: torch.Tensor, syn: torch.Tensor, sd: Dict[str, torch.Tensor], 
         x = resnet_block(x, sd, f"dec.model{n}.0.")
         n += 1
     for i in range(cfg.n_downsampling):
-        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        x = _s(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False))     # bf16 storage: the upsampled input ...
         x = _conv(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[f"dec.model{n}.2.weight"], sd[f"dec.model{n}.2.bias"])
-        x = F.relu(_in(x))
+        x = F.relu(_in_s(x))                                                                # ... and the up-convolution's output
         if stages is not None:
             stages[f"dec_up{i}"] = x
         n += 1
@@ -256,14 +279,16 @@ def tsnet_forward(sd: Dict[str, torch.Tensor], cfg: TSNetConfig,
     Every convolution input and weight is rounded to bfloat16 where the engine rounds it -- all convolutions except the RGB head, and
     `fuse_net.conv` (1x1, linear) applied to the mean over sources like the engine does -- while products, sums, InstanceNorm, the
     transformation branch and the head stay fp32.  What remains between the two is summation order and the bf16 roundings it flips."""
-    global _ROUND_BF16
-    if round_operands not in (None, "bf16"):
-        raise ValueError("round_operands: None or 'bf16'")
-    _ROUND_BF16 = round_operands == "bf16"
+    global _ROUND_BF16, _STORE_BF16
+    if round_operands not in (None, "bf16", "bf16s"):
+        raise ValueError("round_operands: None, 'bf16' or 'bf16s' (bf16 operands + bf16 storage of the large activations: operand_mode 2)")
+    _ROUND_BF16 = round_operands in ("bf16", "bf16s")
+    _STORE_BF16 = round_operands == "bf16s"
     try:
         return _forward(sd, cfg, src_img_list, src_lbl_list, src_bbox_list, tar_lbl, tar_bbox, want_stages, tar_img)
     finally:
         _ROUND_BF16 = False
+        _STORE_BF16 = False
 
 
 def _forward(sd, cfg, src_img_list, src_lbl_list, src_bbox_list, tar_lbl, tar_bbox, want_stages, tar_img) -> dict:

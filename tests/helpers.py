@@ -60,17 +60,18 @@ def stage_report(eng, ref_stages, K, B, device):
     return out
 
 
-def bf16_mode_report(eng, cfg, sd, inp, rec, B, dev):
+def bf16_mode_report(eng, cfg, sd, inp, rec, B, dev, mode="bf16"):
     """What can be asserted about the bf16-operand mode (shared with the GPU tier).  The encoders, FuseNet and the decoder are smooth: the
     engine must sit within bf16 rounding-flip noise of the oracle that rounds the same operands.  The transformation branch is not:
     softmax(100 * corr) turns a 1e-2 feature difference into a different flow (pg differs by O(1) on random weights, in the reference's
     own arithmetic too), so the decoder is checked on the ENGINE's (pg, sg) and the end-to-end distances are reported, not gated."""
-    ref16 = O.tsnet_forward(sd, cfg, *inp, round_operands="bf16", want_stages=True)
+    # mode "bf16s": bf16 operands + bf16 storage of the large activations (operand_mode 2); the oracle rounds at the same points
+    ref16 = O.tsnet_forward(sd, cfg, *inp, round_operands=mode, want_stages=True)
     ref32 = O.tsnet_forward(sd, cfg, *inp)
     rep = stage_report(eng, ref16["stages"], cfg.n_source, B, dev)
     pg = nhwc_to_nchw(eng.stage("pg", dev).cpu())
     sg = nhwc_to_nchw(eng.stage("sg", dev).cpu())
-    with O.bf16_operands():
+    with O.bf16_operands(storage=mode == "bf16s"):
         dec, _ = O.decoder(pg, sg, sd, cfg)
     if cfg.pose and cfg.use_mask:
         dec = O.pose_composite(dec, cfg)

@@ -175,12 +175,37 @@ def test_bf16_operand_mode(emu_lib):
     rec, flows = Hh.run_engine(eng, inp, "cpu")
     cnt = (C.c_int64 * 4)()
     emu_lib.tsnet_debug_counters(cnt, 1)
-    assert cnt[0] == 14 and cnt[1] == 6
+    assert cnt[0] == 12 and cnt[1] == 8          # bf16 operands: the stride-2 layers take the general kernel (engine.cpp conv_class)
     r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, 1, "cpu")
     print("[bf16 mode] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
     assert r["src_fea"] < 5e-2 and r["tar_fea"] < 2e-2 and r["sg"] < 8e-2          # bf16 flip noise on a +-18 range
     assert r["decoder_on_engine_features"] < 3e-2
     assert r["end_to_end_vs_fp32_oracle"] > 10 * r["decoder_on_engine_features"]    # it IS a bf16 computation
+    eng.set_sources(inp[0], inp[1], inp[2])
+    r2, _ = eng.forward_target(inp[3], inp[4])
+    assert torch.equal(rec, r2)
+    eng.close()
+
+
+def test_bf16_storage_mode(emu_lib):
+    """tsnet_cfg.operand_mode = 2: bf16 operands AND bf16 storage of the large convolution-to-convolution activations (the encoders' stem /
+    first down-convolution outputs, the decoder's upsampled inputs and up-convolution outputs): the producers round once where they store
+    (statistics from the fp32 accumulators), the consumers -- general, stride-2 patch and 3x3 patch kernels, upsample, RGB head -- widen
+    exactly.  Against the oracle that rounds at the same points; and different from mode 1 (it IS another computation)."""
+    cfg = O.TSNetConfig(label_nc=2, n_blocks=1, n_source=1, ngf=32, enc_blocks=1, fuse_ngf=512)
+    sd = O.synth_state_dict(cfg, seed=14, bias_std=0.02)
+    sd = {k: (v * 2 if k.endswith("weight") else v) for k, v in sd.items()}
+    inp = O.synth_inputs(cfg, 1, 32, 256, seed=15, mask_mode="box")
+    eng = Hh.make_engine(cfg, sd, 32, 256, 1, "cpu", lib=emu_lib, operands="bf16s")
+    rec, flows = Hh.run_engine(eng, inp, "cpu")
+    r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, 1, "cpu", mode="bf16s")
+    print("[bf16 storage mode] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
+    assert r["src_fea"] < 5e-2 and r["tar_fea"] < 2e-2 and r["sg"] < 8e-2
+    assert r["decoder_on_engine_features"] < 3e-2
+    e1 = Hh.make_engine(cfg, sd, 32, 256, 1, "cpu", lib=emu_lib, operands="bf16")
+    rec1, _ = Hh.run_engine(e1, inp, "cpu")
+    assert not torch.equal(rec, rec1)
+    e1.close()
     eng.set_sources(inp[0], inp[1], inp[2])
     r2, _ = eng.forward_target(inp[3], inp[4])
     assert torch.equal(rec, r2)

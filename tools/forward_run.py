@@ -15,9 +15,10 @@ ap.add_argument("--clip", action="store_true")
 ap.add_argument("--size", type=int, default=256, help="frame height = width (512: BASELINE.json configs[4])")
 ap.add_argument("--n-source", type=int, default=3)
 ap.add_argument("--bf16", action="store_true", help="tsnet_cfg.operand_mode = 1 (bf16 convolution operands)")
+ap.add_argument("--bf16s", action="store_true", help="tsnet_cfg.operand_mode = 2 (bf16 operands + bf16 storage of the large activations)")
 a = ap.parse_args()
 H = W = a.size
-eng = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=a.n_source, height=H, width=W, max_batch=a.batch, operands="bf16" if a.bf16 else "fp32")
+eng = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=a.n_source, height=H, width=W, max_batch=a.batch, operands="bf16s" if a.bf16s else ("bf16" if a.bf16 else "fp32"))
 eng.load_state_dict(synth.state_dict(eng.param_shapes(), seed=0)); eng.finalize("cuda")
 inp = synth.inputs(a.n_source, 2, a.batch, H, W, seed=1)
 si, sl, sb, tl, tb = [[t.cuda() for t in x] if isinstance(x, list) else x.cuda() for x in inp]

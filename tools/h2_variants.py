@@ -16,10 +16,10 @@ torch.zeros(1, device="cuda")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 
 
-def code(tile=0, general=False, abl=0, opt=0, xcd=None, patch=False, w1=False, cold=False):
+def code(tile=0, general=False, abl=0, opt=0, xcd=None, patch=False, w1=False, cold=False, bf16=False):
     """xcd: None = the launcher's choice, 0 = consecutive tiles per XCD, 1 / 2 / 4 / 8 = columns of the XCD grid over the N tiles"""
     gx = 0 if xcd is None else (1 if xcd == 0 else {1: 2, 2: 3, 4: 4, 8: 5}[xcd])
-    return tile | (4096 if general else 0) | (16384 if patch else 0) | (32768 if w1 else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | ((1 << 22) if opt & 32 else 0) | ((1 << 21) if cold else 0) | (gx << 28)
+    return tile | (8192 if bf16 else 0) | (4096 if general else 0) | (16384 if patch else 0) | (32768 if w1 else 0) | (abl << 16) | ((opt & 15) << 24) | ((1 << 23) if opt & 16 else 0) | ((1 << 22) if opt & 32 else 0) | ((1 << 21) if cold else 0) | (gx << 28)
 
 
 def run(name, shape, variants, norms=(0, 1), iters=8):
@@ -50,6 +50,16 @@ if SEL == "down":       # stride-2 shapes
                     ("down3 one frame (3 images)", (3, 64, 64, 256, 512, 3, 2, 1, 0))):
         run(nm, shp, [("h2d 4 waves x 64", code(64, patch=True)), ("h2d 8 waves x 128", code(128, patch=True)), ("h2d 2 rows x 128", code(2128, patch=True)),
                       ("general 128", code(128, general=True)), ("the layer's own", code(0))], norms=(1,))
+    sys.exit(0)
+if SEL == "bf16":       # the bf16-operand kernels against the fp16 x 2 ones, layer by layer at the configs[2] batch (24 source images)
+    for nm, shp in (("stem (8->64, 7x7)", (24, 256, 256, 8, 64, 7, 1, 3, 1)), ("down1 (64->128)", (24, 256, 256, 64, 128, 3, 2, 1, 0)),
+                    ("down2 (128->256)", (24, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 (256->512)", (24, 64, 64, 256, 512, 3, 2, 1, 0)),
+                    ("res (512->512)", (24, 32, 32, 512, 512, 3, 1, 1, 1)), ("dec_up1 (256->128 @128^2)", (8, 128, 128, 256, 128, 3, 1, 1, 1)),
+                    ("dec_up2 (128->64 @256^2)", (8, 256, 256, 128, 64, 3, 1, 1, 1))):
+        vs = [("fp16x2, the layer's own", code(0)), ("bf16, the layer's own", code(0, bf16=True))]
+        if shp[6] == 2 and shp[3] >= 128:
+            vs += [("bf16 h2d 4 waves x 64", code(64, patch=True, bf16=True)), ("bf16 h2d 8 waves x 128", code(128, patch=True, bf16=True)), ("bf16 general 128", code(128, general=True, bf16=True))]
+        run(nm, shp, vs, norms=(0,) if shp[5] == 7 else (1,))
     sys.exit(0)
 if SEL == "downsmall":  # stride-2 shapes of a single frame
     for nm, shp in (("down2 one frame (3 images)", (3, 128, 128, 128, 256, 3, 2, 1, 0)), ("down3 one frame (3 images)", (3, 64, 64, 256, 512, 3, 2, 1, 0)),

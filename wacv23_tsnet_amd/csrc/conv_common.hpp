@@ -92,6 +92,17 @@ __device__ __forceinline__ unsigned short bf16_rne(float f) {
     const unsigned u = __builtin_bit_cast(unsigned, f);
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);     // finite inputs only (activations / weights)
 }
+// two floats -> one dword of two bf16 (round to nearest even), low half = a.  gfx950 has the instruction; the integer form above costs
+// five VALU operations per element, and the bf16-operand kernels -- a third of the MFMA work of the fp16 x 2 ones -- are bound by exactly
+// that staging arithmetic.  Same bits as bf16_rne for finite inputs (tests/emu runs the integer form).
+#ifndef TSNET_CVT_PK_BF16
+__device__ __forceinline__ unsigned tsnet_cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#define TSNET_CVT_PK_BF16(a, b) tsnet_cvt_pk_bf16((a), (b))
+#endif
 
 // max |v| of the workgroup's values -> ONE atomic per workgroup (atomics on one address serialise at ~12 ns each; non-negative
 // floats order like their bit patterns, and a max is order-independent: deterministic).  Every thread of the workgroup must call it.
@@ -133,7 +144,32 @@ struct ConvArgs {
     // (alpha = rstd, beta = -mean*rstd), replacing the in_finalize2 launch; null = off
     float* fin_alpha; float* fin_beta; int* fin_counter; int fin_S; float fin_eps;
     unsigned* amax_out;        // null, or amax_out[image] <- max |y| of that image (float bits, atomic max)
+    // bf16 STORAGE (tsnet_cfg.operand_mode = 2, bf16-operand kernels only): x / y hold bf16 instead of fp32 -- same shapes, half the bytes.
+    // The statistics still come from the fp32 accumulators; the consumer widens exactly (bf16 -> fp32 is a shift).
+    int x_bf16, y_bf16;
 };
+
+// eight consecutive bf16 channels (one 16-byte vector) -> two float4, exactly
+__device__ __forceinline__ void bf16x8_widen(const F4& p, F4 (&o)[2]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned w = __builtin_bit_cast(unsigned, p.v[e]);
+        o[e >> 1].v[(e & 1) * 2] = __builtin_bit_cast(float, w << 16);
+        o[e >> 1].v[(e & 1) * 2 + 1] = __builtin_bit_cast(float, w & 0xFFFF0000u);
+    }
+}
+
+// The eight channels at fp32 byte offset (voff + soff) of an activation tensor -- or, xb16, of the same tensor stored as bf16 (half the
+// offsets, one load).  A lane whose voff is kOOB reads zeros either way (kOOB / 2 still lies past any descriptor: tensors are < 2 GiB).
+__device__ __forceinline__ void load_x_octet(const tsnet_brsrc_t& rs, bool xb16, unsigned voff, unsigned soff, F4 (&o)[2]) {
+    if (xb16) {
+        const F4 p = TSNET_BUF_LOAD16(rs, voff >> 1, soff >> 1);
+        bf16x8_widen(p, o);
+    } else {
+        o[0] = TSNET_BUF_LOAD16(rs, voff, soff);
+        o[1] = TSNET_BUF_LOAD16(rs, voff, soff + 16u);
+    }
+}
 
 // power-of-two operand scale for |x| <= bound: |x * 2^sa| <= 2^15 (the host's h2_scale_log2, engine.cpp)
 __device__ __forceinline__ void h2_device_scale(const unsigned* amax, float add, float& scale, float& unscale) {
@@ -171,8 +207,8 @@ __device__ __forceinline__ void bf16_octet(const F4& x0, const F4& x1, F4& H) {
     unsigned hw[4];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        hw[e] = (unsigned)bf16_rne(x0.v[2 * e]) | ((unsigned)bf16_rne(x0.v[2 * e + 1]) << 16);
-        hw[2 + e] = (unsigned)bf16_rne(x1.v[2 * e]) | ((unsigned)bf16_rne(x1.v[2 * e + 1]) << 16);
+        hw[e] = TSNET_CVT_PK_BF16(x0.v[2 * e], x0.v[2 * e + 1]);
+        hw[2 + e] = TSNET_CVT_PK_BF16(x1.v[2 * e], x1.v[2 * e + 1]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) H.v[e] = __builtin_bit_cast(float, hw[e]);
@@ -304,7 +340,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
             }
         }
     }
-    // pass 2: the fp32 stores
+    // pass 2: the stores (fp32, or bf16 in the bf16-storage mode)
+    unsigned short* const y16 = reinterpret_cast<unsigned short*>(a.y);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -314,7 +351,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m_of(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
-                if (active && m >= 0) a.y[(size_t)m * a.Cout + n] = tot[i][j][r];
+                if (!(active && m >= 0)) continue;
+                if (a.y_bf16) y16[(size_t)m * a.Cout + n] = bf16_rne(tot[i][j][r]);
+                else a.y[(size_t)m * a.Cout + n] = tot[i][j][r];
             }
         }
     }

@@ -83,7 +83,8 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax + img, a.in_bound_add, in_scale, in_unscale);
 
     const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
-    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
+    const bool xb16 = NPROD == 1 && a.x_bf16;                        // bf16 storage: the input tensor holds bf16 (conv_common.hpp load_x_octet)
+    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * (xb16 ? 2 : 4)));
     tsnet_brsrc_t rsw[NPL];
 #pragma unroll
     for (int p = 0; p < NPL; ++p) rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
@@ -124,8 +125,11 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     auto slab_of = [&](int lc) __attribute__((always_inline)) { return lc * KG + kg; };
     F4 sx[2][2];                                                     // staging registers [round][half octet] (DEEP: both rounds live at once)
     auto stage_load_x = [&](int cn, int r) __attribute__((always_inline)) {
+        if (NPROD == 1) load_x_octet(rsx, xb16, vP[r], (unsigned)(slab_of(cn) * 64), sx[r]);
+        else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) sx[r][q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(slab_of(cn) * 64 + q * 16));
+            for (int q = 0; q < 2; ++q) sx[r][q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(slab_of(cn) * 64 + q * 16));
+        }
     };
     // par = stage the slab is written to (its local index & 1, a compile-time constant at every call site)
     auto stage_store = [&](int cn, int par, int r) __attribute__((always_inline)) {
@@ -534,7 +538,8 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     if (NPROD != 1 && a.in_amax) h2_device_scale(a.in_amax + img, a.in_bound_add, in_scale, in_unscale);
 
     const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
-    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * 4));
+    const bool xb16 = NPROD == 1 && a.x_bf16;                        // bf16 storage: the input tensor holds bf16
+    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Cin * (xb16 ? 2 : 4)));
     tsnet_brsrc_t rsw[NPL];
 #pragma unroll
     for (int p = 0; p < NPL; ++p) rsw[p] = tsnet_make_brsrc(a.w + p * planew, (unsigned)(planew * 2));
@@ -569,8 +574,11 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();
     F4 sx[2];                                                        // staging registers: one round of x in flight
     auto stage_load_x = [&](int cn, int r) __attribute__((always_inline)) {
+        if (NPROD == 1) load_x_octet(rsx, xb16, vP[r], (unsigned)(cn * 64), sx);
+        else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) sx[q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(cn * 64 + q * 16));
+            for (int q = 0; q < 2; ++q) sx[q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(cn * 64 + q * 16));
+        }
     };
     auto stage_store = [&](int cn, int r) __attribute__((always_inline)) {
         F4 t[2];

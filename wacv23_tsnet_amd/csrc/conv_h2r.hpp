@@ -48,7 +48,8 @@ void conv_h2r_kernel(ConvArgs a) {
 
     const int C2 = a.Cin - a.Csplit;
     const size_t planew = (size_t)((a.nchunks + 1) / 2 * 2) * a.Npad * 16;
-    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Csplit * 4));
+    const bool xb16 = NPROD == 1 && a.x_bf16 && !a.x2;               // bf16 storage: the (single) input tensor holds bf16
+    const tsnet_brsrc_t rsx = tsnet_make_brsrc(a.x, (unsigned)((size_t)a.N * a.H * a.W * a.Csplit * (xb16 ? 2 : 4)));
     const tsnet_brsrc_t rsx2 = tsnet_make_brsrc(a.x2 ? a.x2 : a.x, a.x2 ? (unsigned)((size_t)a.x2_nmod * a.H * a.W * C2 * 4) : 0u);
     tsnet_brsrc_t rsw[NPL];
 #pragma unroll
@@ -105,6 +106,7 @@ void conv_h2r_kernel(ConvArgs a) {
         const unsigned v2 = ok ? (unsigned)(((s_pix2 + iy * a.W + ix) * C2 + (c0 - a.Csplit)) * 4) : kOOB;
         const unsigned v = second ? v2 : v1;
         if (second) { ar[set][0] = TSNET_BUF_LOAD16(rsx2, v, 0u); ar[set][1] = TSNET_BUF_LOAD16(rsx2, v, 16u); }
+        else if (NPROD == 1) load_x_octet(rsx, xb16, v, 0u, ar[set]);
         else { ar[set][0] = TSNET_BUF_LOAD16(rsx, v, 0u); ar[set][1] = TSNET_BUF_LOAD16(rsx, v, 16u); }
         am[set] = ok ? 1.f : 0.f;
         ac0[set] = ok ? c0 : 0;

@@ -174,8 +174,8 @@ __device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_r
                 }
                 if (NPROD == 1) {
                     U2 h;
-                    h.x = (unsigned)bf16_rne(v[0]) | ((unsigned)bf16_rne(v[1]) << 16);
-                    h.y = (unsigned)bf16_rne(v[2]) | ((unsigned)bf16_rne(v[3]) << 16);
+                    h.x = TSNET_CVT_PK_BF16(v[0], v[1]);
+                    h.y = TSNET_CVT_PK_BF16(v[2], v[3]);
                     *reinterpret_cast<U2*>(dst + p * POSB) = h;
                 } else {
                     U2 h, l;

@@ -180,6 +180,7 @@ struct ConvCall {
     double* stat_part = nullptr; mutable int stat_S = 0;        // stat_S out: partials per image; 0 = none; -1 = finalised in the kernel
     float* fin_alpha = nullptr; float* fin_beta = nullptr; int* fin_counter = nullptr;
     unsigned* amax_out = nullptr;   // publish max |y| per image (operand scale of a consumer without an a-priori bound)
+    int x_bf16 = 0, y_bf16 = 0; // bf16 storage mode (bf16-operand kernels only): the input / output tensor holds bf16
     int nprod = 3;              // products per k-group: 3 (4 adds lo*lo), or 1 = bf16 operands
     int kernel = 0;             // 0 = the layer's own kernel class, 1 = force the general kernel, 2 = require a patch kernel (op tests)
     int tile = 0;               // 0 = heuristic; else rows * 1000 + width of the patch tile (32, 64, 128 = 4 rows; 2128 = 2 x 128; + 20000 = its
@@ -209,7 +210,7 @@ inline bool w1_eligible(const ConvLayer& L, int H, int W) {
     return L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H >= 4 && W >= 32 && H % kPatchRows == 0 && W % kPatchCols == 0;
 }
 // eligible_only: what the layer CAN run on (an explicit request, op tests / tools); otherwise what the forward runs it on
-inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool transform, int rows = kPatchRows, bool eligible_only = false) {
+inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool transform, int rows = kPatchRows, bool eligible_only = false, bool bf16 = false) {
     const int Ho = (H + 2 * L.pad - L.ks) / L.stride + 1, Wo = (W + 2 * L.pad - L.ks) / L.stride + 1;
     const bool s1 = L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H >= 2 && W >= 2;
     if (two_sources || Ho <= 0 || Wo <= 0 || Wo % kPatchCols) return K_GENERAL;
@@ -223,7 +224,9 @@ inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool t
     if (L.ks == 7 && L.stride == 1 && L.pad == 3 && L.reflect && L.cin_pad == 8 && !transform && H >= 4 && W >= 4) return K_H2S;
     // stride 2: the patch kernel from 128 input channels on (117 / 125 us on the 128 -> 256 / 256 -> 512 layers against 132 / 142 us for the
     // general kernel); with 64 channels the K loop is four slabs long and the general kernel's smaller per-tile prologue wins (147 vs 157 us)
-    if (s2) return K_H2D;
+    // bf16 operands: a third of the MFMA work per staged byte -- the patch tiles' five-round staging binds (459 / 378 us on 128 -> 256 /
+    // 256 -> 512 at 24 images against 180 us for the general kernel's 128-wide tile: profiles/round4_bf16_layers.txt)
+    if (s2 && (eligible_only || !bf16)) return K_H2D;
     return K_GENERAL;
 }
 
@@ -240,6 +243,9 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
     g.in_amax = bf16 ? nullptr : c.in_amax; g.in_bound_add = c.bound_add; g.amax_out = c.amax_out;
     g.w = L.wq; g.w_unscale = bf16 ? nullptr : L.w_unscale; g.bias = L.bias; g.y = c.y;
     g.stat_part = c.stat_part; g.addend = c.addend; g.add_nmod = c.add_nmod > 0 ? c.add_nmod : 1;
+    g.x_bf16 = c.x_bf16; g.y_bf16 = c.y_bf16;
+    if ((c.x_bf16 || c.y_bf16) && !bf16) throw ArgError("conv: bf16 storage goes with bf16 operands");
+    if (c.x_bf16 && c.x2) throw ArgError("conv: bf16 storage of a concatenated input is not built");
     g.N = c.N; g.H = c.H; g.W = c.W; g.Cin = L.cin_pad; g.cin_log2 = ilog2(L.cin_pad);
     g.Csplit = c.x2 ? c.csplit : L.cin_pad; g.x2_nmod = c.x2_nmod > 0 ? c.x2_nmod : 1;
     g.Ho = (c.H + 2 * L.pad - L.ks) / L.stride + 1; g.Wo = (c.W + 2 * L.pad - L.ks) / L.stride + 1;
@@ -255,7 +261,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
     const int hw = g.Ho * g.Wo;
     if (L.form == 1 && (c.x2 || !w1_eligible(L, c.H, c.W))) throw ArgError("conv(w1): the layer is packed in the Winograd form, which needs a single source and whole 4 x 32 tiles");
     if (L.form == 1 && c.nprod == 4) throw ArgError("conv(w1): 1 or 3 products");
-    const int cls = L.form == 1 ? K_W1 : c.kernel == 1 ? K_GENERAL : conv_class(L, c.H, c.W, c.x2 != nullptr, c.alpha != nullptr, c.tile % 10000 >= 1000 ? c.tile % 10000 / 1000 : kPatchRows, c.kernel == 2);
+    const int cls = L.form == 1 ? K_W1 : c.kernel == 1 ? K_GENERAL : conv_class(L, c.H, c.W, c.x2 != nullptr, c.alpha != nullptr, c.tile % 10000 >= 1000 ? c.tile % 10000 / 1000 : kPatchRows, c.kernel == 2, bf16);
     if (c.kernel == 2 && cls == K_GENERAL) throw ArgError("conv: this layer / frame size has no patch kernel");
     g.fin_alpha = c.fin_alpha; g.fin_beta = c.fin_beta; g.fin_eps = 1e-5f;
     TimeScope ts(ctx, c.tclass);
@@ -420,10 +426,10 @@ void run_norm_act(Ctx& ctx, const float* x, const float* alpha, const float* bet
     check_launch("norm_act");
 }
 
-void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, int N, int H, int W, int C, float* y) {
+void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* beta, int relu, int N, int H, int W, int C, float* y, int x_bf16 = 0, int y_bf16 = 0) {
     if (C & 3) throw ArgError("upsample: C must be a multiple of 4");
     TimeScope ts(ctx, TSNET_T_UPSAMPLE);
-    UpsampleArgs a{x, alpha, beta, y, N, H, W, C, relu};
+    UpsampleArgs a{x, alpha, beta, y, N, H, W, C, relu, x_bf16, y_bf16};
     if (2 * H > 65535 || N > 65535) throw ArgError("upsample: tensor too large");
     const size_t row4 = (size_t)2 * W * C / 4;
     hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)std::min<size_t>((row4 + 255) / 256, 64), 2 * H, N), dim3(256), 0, ctx.stream, a);
@@ -542,6 +548,8 @@ struct tsnet_engine {
     int C = 0, h = 0, w = 0, P = 0, K = 0, Bmax = 0;
     int cp_img = 0, cp_lbl = 0;
     int np = 3;                           // MFMA products per k-group: 3 (fp16 x 2 operands), or 1 = bf16-operand mode (cfg.operand_mode)
+    bool st16 = false;                    // cfg.operand_mode = 2: bf16 operands AND bf16 storage of the large conv-to-conv activations (the encoder's
+                                          // 256^2 .. 64^2 maps, the decoder's up-convolution outputs and upsampled inputs); statistics from fp32 accumulators
 
     struct Param { std::string name; std::vector<int64_t> shape; std::vector<float> host; bool loaded = false; };
     std::vector<Param> params;
@@ -872,6 +880,7 @@ void tsnet_engine::encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin,
     auto st = next_ab(ctx);
     {
         ConvCall a; a.x = xin; a.in_amax = xin_amax; a.bound = 1.f; a.N = N; a.H = hh; a.W = ww; a.y = raw[0];
+        a.y_bf16 = st16;                                             // bf16 storage: the stem's and the first down-convolutions' raw outputs
         conv_stats(ctx, L[0], a, N, hh * ww, st.first, st.second);
     }
     for (int l = 1; l <= cfg.n_downsampling; ++l) {
@@ -880,6 +889,7 @@ void tsnet_engine::encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin,
         st = next_ab(ctx);
         ConvCall d; d.x = raw[l - 1]; d.alpha = prev.first; d.beta = prev.second; d.relu = 1; d.bound = std::sqrt((float)(hh * ww));
         d.N = N; d.H = hh; d.W = ww; d.y = raw[l];
+        d.x_bf16 = st16; d.y_bf16 = st16 && l < cfg.n_downsampling;  // the last one feeds norm_act (32 x 32 features: fp32)
         hh /= 2; ww /= 2;
         conv_stats(ctx, L[l], d, N, hh * ww, st.first, st.second);
     }
@@ -1006,11 +1016,12 @@ void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb,
         // input of up-convolution i = bilinear x2 of relu(IN(previous)) -- a convex combination of InstanceNorm outputs, bounded by
         // sqrt(HW) of the low-resolution map; the first one upsamples the decoder stream itself: published max |D_0| + n_blocks sqrt(P)
         const float in_bound = std::sqrt((float)(hh * ww));
-        run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, U[i]);
+        run_upsample(ctx, cur, cal, cbe, cal ? 1 : 0, B, hh, ww, cc, U[i], st16 && i > 0, st16);
         hh *= 2; ww *= 2;
         cc /= 2;
         auto st = next_ab(ctx);
         ConvCall a; a.x = U[i]; a.bound = in_bound; a.N = B; a.H = hh; a.W = ww; a.y = R[i];
+        a.x_bf16 = st16; a.y_bf16 = st16;
         if (!cal) { a.in_amax = amax_dec(); a.bound_add = (float)cfg.n_blocks * sqP; }
         conv_stats(ctx, dec_up[i], a, B, hh * ww, st.first, st.second);
         cur = R[i]; cal = st.first; cbe = st.second;
@@ -1019,7 +1030,7 @@ void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb,
         TimeScope ts(ctx, TSNET_T_CONV);     // it is a convolution: keep it in the conv class for the roofline accounting
         HeadArgs ha{};
         ha.x = cur; ha.alpha = cal; ha.beta = cbe; ha.w = head_w; ha.bias = head_bias; ha.y = out_rgb;
-        ha.N = B; ha.H = hh; ha.W = ww; ha.C = cc;
+        ha.N = B; ha.H = hh; ha.W = ww; ha.C = cc; ha.x_bf16 = st16 && cfg.n_downsampling > 0;
         ha.composite = cfg.pose_composite; ha.fore_x0 = 64; ha.fore_x1 = 192;          // TSNet_pose.py:279
         for (int c = 0; c < 3; ++c) ha.bg[c] = (-cfg.pose_mean[c]) / 255.0f;             // TSNet_pose.py:276
         launch_head(ha, hh, ww, B, ctx.stream);
@@ -1058,7 +1069,7 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
     if (cfg->max_batch < 1) return bad("max_batch must be >= 1");
     if (cfg->pose_composite && (cfg->height != 256 || cfg->width != 256))
         return bad("pose composite is defined for 256x256 frames only (TSNet_pose.py:277-280)");
-    if (cfg->operand_mode != 0 && cfg->operand_mode != 1) return bad("operand_mode must be 0 (fp32-class) or 1 (bf16 operands)");
+    if (cfg->operand_mode < 0 || cfg->operand_mode > 2) return bad("operand_mode must be 0 (fp32-class), 1 (bf16 operands) or 2 (bf16 operands + bf16 storage)");
     try {
         tsnet_engine* e = new tsnet_engine();
         e->cfg = *cfg;
@@ -1066,7 +1077,8 @@ int tsnet_create(const tsnet_cfg* cfg, tsnet_handle* out) {
         for (int s = 0; s < TSNET_MAX_SOURCES; ++s) e->src_div[s] = 255.0f;
         e->C = cfg->ngf << cfg->n_downsampling;
         e->h = cfg->height / ds; e->w = cfg->width / ds; e->P = e->h * e->w;
-        e->np = cfg->operand_mode == 1 ? 1 : 3;
+        e->np = cfg->operand_mode != 0 ? 1 : 3;
+        e->st16 = cfg->operand_mode == 2;
         e->build_layers();
         *out = e;
     } catch (const std::exception& ex) { g_create_error = ex.what(); return TSNET_ERR_NOMEM; }
@@ -1269,6 +1281,12 @@ int tsnet_stage_ptr(tsnet_handle h, const char* name, const float** dev_ptr, siz
     else if (n.rfind("dec_up", 0) == 0 && n.size() == 7 && n[6] >= '0' && n[6] < '0' + h->cfg.n_downsampling) {
         const int i = n[6] - '0';        // raw output of the i-th decoder up-convolution (before its InstanceNorm)
         p = h->R[i]; c = B * ((size_t)(h->h << (i + 1)) * (h->w << (i + 1)) * (h->C >> (i + 1)));
+        if (h->st16) {                   // stored as bf16: widened into the (now idle, twice as large) upsampled-input buffer of the same level
+            hipLaunchKernelGGL(bf16_widen_kernel, dim3(ew_grid(c)), dim3(256), 0, nullptr, reinterpret_cast<const unsigned short*>(h->R[i]), h->U[i], c);
+            check_launch("bf16_widen");
+            HIP_TRY(hipStreamSynchronize(nullptr));
+            p = h->U[i];
+        }
     }
     else throw ArgError("unknown stage '" + n + "'");
     if (dev_ptr) *dev_ptr = p;

@@ -23,7 +23,16 @@ struct HeadArgs {
     int N, H, W, C;
     int composite, fore_x0, fore_x1;
     float bg[3];
+    int x_bf16;           // bf16 storage mode: x holds bf16
 };
+
+// four consecutive channels of an fp32 tensor, or of the same tensor stored as bf16 (bf16 storage mode; exact widening)
+__device__ __forceinline__ float4 head_ld4(const float* base, size_t elem, bool b16) {
+    if (!b16) return *reinterpret_cast<const float4*>(base + elem);
+    const uint2 p = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+    return make_float4(__builtin_bit_cast(float, p.x << 16), __builtin_bit_cast(float, p.x & 0xFFFF0000u),
+                       __builtin_bit_cast(float, p.y << 16), __builtin_bit_cast(float, p.y & 0xFFFF0000u));
+}
 
 constexpr int kHeadT = 16, kHeadP = kHeadT + 6, kHeadCh = 16;
 
@@ -47,7 +56,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(HeadArgs a) {
             ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
             const int c = c0 + q * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < a.C) v = *reinterpret_cast<const float4*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.C + c);
+            if (c < a.C) v = head_ld4(a.x, (((size_t)n * a.H + iy) * a.W + ix) * a.C + c, a.x_bf16 != 0);
             if (a.alpha && c < a.C) {
                 const float4 al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * a.C + c);
                 const float4 be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * a.C + c);
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void head_conv3_kernel(HeadArgs a) {
     float4 sreg[NPE], wreg[NWE];
     auto stage_load = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < NPE; ++e) sreg[e] = *reinterpret_cast<const float4*>(a.x + src_off[e] + c0);
+        for (int e = 0; e < NPE; ++e) sreg[e] = head_ld4(a.x, (size_t)src_off[e] + c0, a.x_bf16 != 0);
 #pragma unroll
         for (int e = 0; e < NWE; ++e) {
             const float* src = a.w + wsrc[e] + c0 * 4;

@@ -284,7 +284,16 @@ struct UpsampleArgs {
     const float* beta;
     float* y;             // (N,2H,2W,C)
     int N, H, W, C, relu;
+    int x_bf16, y_bf16;   // bf16 storage mode: x / y hold bf16 (ConvArgs)
 };
+
+// four consecutive channels of an fp32 tensor, or of the same tensor stored as bf16 (exact widening)
+__device__ __forceinline__ float4 ld4_f32_or_bf16(const float* base, size_t elem, bool b16) {
+    if (!b16) return *reinterpret_cast<const float4*>(base + elem);
+    const uint2 p = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+    return make_float4(__builtin_bit_cast(float, p.x << 16), __builtin_bit_cast(float, p.x & 0xFFFF0000u),
+                       __builtin_bit_cast(float, p.y << 16), __builtin_bit_cast(float, p.y & 0xFFFF0000u));
+}
 
 __device__ __forceinline__ float4 na4(float4 v, const float4& al, const float4& be, bool norm, bool relu) {
     if (norm) {
@@ -319,18 +328,32 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(UpsampleArgs a) {
             al = *reinterpret_cast<const float4*>(a.alpha + (size_t)n * a.C + c);
             be = *reinterpret_cast<const float4*>(a.beta + (size_t)n * a.C + c);
         }
-        const float* base = a.x + ((size_t)n * a.H * a.W) * a.C + c;
-        const float4 v00 = na4(*reinterpret_cast<const float4*>(base + ((size_t)y0 * a.W + x0) * a.C), al, be, norm, a.relu);
-        const float4 v01 = na4(*reinterpret_cast<const float4*>(base + ((size_t)y0 * a.W + x1) * a.C), al, be, norm, a.relu);
-        const float4 v10 = na4(*reinterpret_cast<const float4*>(base + ((size_t)y1 * a.W + x0) * a.C), al, be, norm, a.relu);
-        const float4 v11 = na4(*reinterpret_cast<const float4*>(base + ((size_t)y1 * a.W + x1) * a.C), al, be, norm, a.relu);
+        const size_t base = ((size_t)n * a.H * a.W) * a.C + c;
+        const bool xb = a.x_bf16 != 0;
+        const float4 v00 = na4(ld4_f32_or_bf16(a.x, base + ((size_t)y0 * a.W + x0) * a.C, xb), al, be, norm, a.relu);
+        const float4 v01 = na4(ld4_f32_or_bf16(a.x, base + ((size_t)y0 * a.W + x1) * a.C, xb), al, be, norm, a.relu);
+        const float4 v10 = na4(ld4_f32_or_bf16(a.x, base + ((size_t)y1 * a.W + x0) * a.C, xb), al, be, norm, a.relu);
+        const float4 v11 = na4(ld4_f32_or_bf16(a.x, base + ((size_t)y1 * a.W + x1) * a.C, xb), al, be, norm, a.relu);
         float4 o;
         o.x = wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
         o.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
         o.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
         o.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
-        reinterpret_cast<float4*>(a.y)[i] = o;
+        if (a.y_bf16) {
+            uint2 q;
+            q.x = TSNET_CVT_PK_BF16(o.x, o.y);
+            q.y = TSNET_CVT_PK_BF16(o.z, o.w);
+            reinterpret_cast<uint2*>(a.y)[i] = q;
+        } else {
+            reinterpret_cast<float4*>(a.y)[i] = o;
+        }
     }
+}
+
+// bf16 -> fp32 (debug accessor of the bf16-storage mode)
+__global__ void bf16_widen_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = __builtin_bit_cast(float, (unsigned)x[i] << 16);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -52,9 +52,10 @@ class TSNetEngine:
         for i in range(3):
             cfg.pose_mean[i] = float(pose_mean[i])
         cfg.height, cfg.width, cfg.max_batch = height, width, max_batch
-        if operands not in ("fp32", "bf16"):
-            raise ValueError("operands must be 'fp32' (fp32-class arithmetic) or 'bf16' (bf16 conv operands, fp32 accumulate)")
-        cfg.operand_mode = 1 if operands == "bf16" else 0
+        if operands not in ("fp32", "bf16", "bf16s"):
+            raise ValueError("operands must be 'fp32' (fp32-class arithmetic), 'bf16' (bf16 conv operands, fp32 accumulate) or 'bf16s' (+ bf16 storage "
+                             "of the large activations)")
+        cfg.operand_mode = {"fp32": 0, "bf16": 1, "bf16s": 2}[operands]
         self.cfg = cfg
         self.K = n_source
         self.h = height >> n_downsampling
