@@ -160,6 +160,16 @@ struct ConvLayer {
     const float* bias = nullptr;          // device (cout)
 };
 
+// device allocations of an operator entry point: freed on every exit path (a rejected tile / variant throws out of run_conv routinely)
+struct DevBufs {
+    std::vector<void*> p;
+    template <typename T> T* alloc(size_t bytes) { void* q = nullptr; HIP_TRY(hipMalloc(&q, bytes)); p.push_back(q); return static_cast<T*>(q); }
+    ~DevBufs() { for (void* q : p) (void)hipFree(q); }
+    DevBufs() = default;
+    DevBufs(const DevBufs&) = delete;
+    DevBufs& operator=(const DevBufs&) = delete;
+};
+
 constexpr size_t kFinCounterInts = 65536;   // size of the arrival-counter arrays of the in-kernel statistics finalize
 constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded to an even number of 16-deep chunks (fragment prefetch runs up to two past the end)
 
@@ -1351,6 +1361,7 @@ namespace {
 // one convolution layer with its own packed weights, for the operator entry points
 struct OpLayer {
     ConvLayer L;
+    DevBufs mem;                  // a member: destroyed even when the constructor throws after the first allocation
     float* wd = nullptr; float* bd = nullptr; float* un = nullptr; unsigned short* wq = nullptr;
     OpLayer(const float* w_oihw, const float* bias, int Cin, int Cout, int ks, int stride, int pad, int reflect, int nprod, hipStream_t s, int form = 0) {
         L.name = "op"; L.cin_real = Cin; L.cin_pad = conv_cin_pad(Cin); L.cin_total = Cin; L.cout = Cout; L.ks = ks; L.stride = stride; L.pad = pad;
@@ -1365,20 +1376,19 @@ struct OpLayer {
         for (float v : hw) mx = std::max(mx, std::fabs(v));
         const int planes = nprod == 1 ? 1 : 2;
         const int sw = (nprod != 1 && mx > 0.f) ? h2_scale_log2(mx) : 0;
-        HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
-        HIP_TRY(hipMalloc((void**)&wq, (size_t)L.kpad * L.npad * 2 * planes));
-        HIP_TRY(hipMalloc((void**)&un, sizeof(float)));
+        wd = mem.alloc<float>(wn * sizeof(float));
+        wq = mem.alloc<unsigned short>((size_t)L.kpad * L.npad * 2 * planes);
+        un = mem.alloc<float>(sizeof(float));
         HIP_TRY(hipMemcpy(wd, hw.data(), wn * sizeof(float), hipMemcpyHostToDevice));
         const float unscale = std::ldexp(1.0f, -sw);
         HIP_TRY(hipMemcpy(un, &unscale, sizeof(float), hipMemcpyHostToDevice));
         pack_layer(wd, L, wq, planes, std::ldexp(1.0f, sw), s);
         if (bias) {
-            HIP_TRY(hipMalloc((void**)&bd, Cout * sizeof(float)));
+            bd = mem.alloc<float>(Cout * sizeof(float));
             HIP_TRY(hipMemcpy(bd, bias, Cout * sizeof(float), hipMemcpyDefault));
         }
         L.wq = wq; L.w_unscale = nprod == 1 ? nullptr : un; L.bias = bd;
     }
-    ~OpLayer() { (void)hipFree(wd); (void)hipFree(wq); (void)hipFree(un); (void)hipFree(bd); }
     OpLayer(const OpLayer&) = delete;
     OpLayer& operator=(const OpLayer&) = delete;
 };
@@ -1420,11 +1430,11 @@ int tsnet_op_head(const float* x, int N, int H, int W, int C, const float* in_al
     if (C < 4 || (C & 3)) throw ArgError("head op: C must be a multiple of 4");
     if (in_alpha && !in_beta) throw ArgError("head op: alpha without beta");
     hipStream_t s = (hipStream_t)stream;
-    float *wd = nullptr, *tab = nullptr, *bd = nullptr;
     const size_t wn = (size_t)3 * C * 49;
-    HIP_TRY(hipMalloc((void**)&wd, wn * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&tab, ((size_t)49 * C * 4 + 64) * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&bd, 4 * sizeof(float)));
+    DevBufs mem;
+    float* wd = mem.alloc<float>(wn * sizeof(float));
+    float* tab = mem.alloc<float>(((size_t)49 * C * 4 + 64) * sizeof(float));
+    float* bd = mem.alloc<float>(4 * sizeof(float));
     HIP_TRY(hipMemsetAsync(tab, 0, ((size_t)49 * C * 4 + 64) * sizeof(float), s));
     HIP_TRY(hipMemcpy(wd, w_oihw, wn * sizeof(float), hipMemcpyDefault));
     HIP_TRY(hipMemcpy(bd, bias, 3 * sizeof(float), hipMemcpyDefault));
@@ -1437,7 +1447,6 @@ int tsnet_op_head(const float* x, int N, int H, int W, int C, const float* in_al
     for (int c = 0; c < 3; ++c) ha.bg[c] = bg ? bg[c] : 0.f;
     launch_head(ha, H, W, N, s);
     HIP_TRY(hipStreamSynchronize(s));
-    (void)hipFree(wd); (void)hipFree(tab); (void)hipFree(bd);
     OP_END
 }
 
@@ -1445,11 +1454,10 @@ int tsnet_op_instnorm_stats(const float* x, int N, int HW, int C, float* alpha, 
     OP_BEGIN
     if (!x || !alpha || !beta) throw ArgError("null tensor");
     Ctx ctx; ctx.stream = (hipStream_t)stream;
-    double* part = nullptr;
-    HIP_TRY(hipMalloc((void**)&part, (size_t)N * 64 * C * 2 * sizeof(double)));
+    DevBufs mem;
+    double* part = mem.alloc<double>((size_t)N * 64 * C * 2 * sizeof(double));
     run_stats(ctx, x, N, HW, C, part, alpha, beta);
     HIP_TRY(hipStreamSynchronize(ctx.stream));
-    (void)hipFree(part);
     OP_END
 }
 
@@ -1678,9 +1686,9 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     const int nprod = (v & 8192) ? 1 : 3;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const size_t xn = (size_t)N * H * W * Cin, yn = (size_t)N * Ho * Wo * Cout, wn = (size_t)Cout * Cin * ksize * ksize;
-    float *x = nullptr, *y = nullptr, *al = nullptr, *be = nullptr;
-    HIP_TRY(hipMalloc((void**)&x, xn * 4)); HIP_TRY(hipMalloc((void**)&y, yn * 4));
-    HIP_TRY(hipMalloc((void**)&al, (size_t)N * Cin * 4)); HIP_TRY(hipMalloc((void**)&be, (size_t)N * Cin * 4));
+    DevBufs mem;
+    float* x = mem.alloc<float>(xn * 4); float* y = mem.alloc<float>(yn * 4);
+    float* al = mem.alloc<float>((size_t)N * Cin * 4); float* be = mem.alloc<float>((size_t)N * Cin * 4);
     // pseudo-random fill (not zeros: MI355X clocks higher on zero operands, cdna_hip_programming.md rule 25)
     std::vector<float> hbuf(std::max(std::max(xn, wn), (size_t)N * Cin));
     unsigned st = 12345u;
@@ -1713,7 +1721,6 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
         *ms_out = ms / iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
-    (void)hipFree(x); (void)hipFree(y); (void)hipFree(al); (void)hipFree(be);
     OP_END
 }
 

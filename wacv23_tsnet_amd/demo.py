@@ -134,7 +134,11 @@ class ClipRunner:
       * every driving frame is one `tsnet_forward_target` at batch 1, re-normalised to the first source image's statistics and turned
         into RGB bytes on the device (`DemoPostprocessor`); only the bytes cross PCIe;
       * the three-panel strips and the GIF are written with PIL.
-    model: a wacv23_tsnet_amd.model.TSNet on the GPU."""
+    model: a wacv23_tsnet_amd.model.TSNet on the GPU.
+
+    The runner OWNS an engine -- a second copy of the packed weights (~350 MB for the 67 M-parameter net) plus a batch-1 arena on the device.
+    Release it with `close()` or use the runner as a context manager (`with ClipRunner(...) as r:`); `__del__` is only a fallback (at
+    interpreter shutdown the library may already be gone)."""
 
     def __init__(self, model, src_img: Sequence[torch.Tensor], src_lbl: Sequence[torch.Tensor], src_bbox: Sequence[torch.Tensor]):
         self.model = model
@@ -152,6 +156,13 @@ class ClipRunner:
         if self.eng is not None:
             self.eng.close()
             self.eng = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
         try:
