@@ -23,3 +23,16 @@ def test_hot_kernels_do_not_spill_in_their_loops():
         r = hit[0]
         assert r["scratch"] <= limit, f"{name}: {r['scratch']} scratch operations in the main loop (limit {limit}), {r['vgpr']} VGPRs"
         assert r["vgpr"] <= (256 if ("4, 128" in name or ", 24>" in name) else 168), (name, r["vgpr"])
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
+def test_winograd_kernel_fits_fourteen_waves():
+    """conv_w1 runs fourteen waves per workgroup (eight MFMA waves + six transform waves): two SIMDs hold four of them, so every instantiation
+    must stay within 128 VGPRs -- and use no scratch at all."""
+    spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
+    ic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ic)
+    res = ic.kernel_resources(ic.compile_asm(unit="conv_w1_launch.cpp"), "conv_w1_kernel")
+    assert len(res) >= 8, res
+    for name, (vgpr, scratch) in res.items():
+        assert vgpr <= 128 and scratch == 0, (name, vgpr, scratch)

@@ -59,16 +59,27 @@ def analyse(asm_path, pattern=""):
     return rows
 
 
-def compile_asm(tools=False):
+def compile_asm(tools=False, unit="conv_h2_launch.cpp"):
     tmp = tempfile.mkdtemp(prefix="tsnet_isa_")
     sys.path.insert(0, ROOT)
     from wacv23_tsnet_amd import build as B          # the library's own flags: the ISA looked at is the ISA that ships
-    cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + B.UNIT_FLAGS.get("conv_h2_launch.cpp", []) + ["-save-temps", "-I" + os.path.join(ROOT, "include")]
+    cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + B.UNIT_FLAGS.get(unit, []) + ["-save-temps", "-I" + os.path.join(ROOT, "include")]
     if tools:
         cmd.append("-DTSNET_TOOLS")
-    cmd += ["-c", os.path.join(ROOT, "wacv23_tsnet_amd", "csrc", "conv_h2_launch.cpp"), "-o", os.path.join(tmp, "x.o")]
+    cmd += ["-c", os.path.join(ROOT, "wacv23_tsnet_amd", "csrc", unit), "-o", os.path.join(tmp, "x.o")]
     subprocess.run(cmd, cwd=tmp, check=True, capture_output=True)
-    return os.path.join(tmp, "conv_h2_launch-hip-amdgcn-amd-amdhsa-gfx950.s")
+    return os.path.join(tmp, unit.replace(".cpp", "") + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def kernel_resources(asm_path, pattern):
+    """{demangled kernel name: (vgpr_count, private_segment_fixed_size)} from the .amdhsa metadata (whole kernel: any scratch at all shows here)"""
+    s = open(asm_path).read()
+    out = {}
+    for m in re.finditer(r"\.name:\s+(_ZN5tsnet\w+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", s):
+        d = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        if pattern in d:
+            out[d] = (int(m.group(3)), int(m.group(2)))
+    return out
 
 
 def main():
