@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TSNET_ABI_VERSION 3
+#define TSNET_ABI_VERSION 4      /* 4: tsnet_cfg.operand_mode = 2 (bf16 storage); tsnet_op_conv2d kernel = 3 (Winograd-along-x form) */
 #define TSNET_MAX_SOURCES 8
 
 enum {
@@ -153,7 +153,9 @@ int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64
  *   nprod = 3 (lo*hi, hi*lo, hi*hi), 4 (+ lo*lo; 3x3 / stride-1 patch kernel only) or 1 (bf16 operands, tsnet_cfg.operand_mode = 1).
  *   kernel: 0 = the kernel the forward runs this layer on at this frame size (patch kernels of conv_h2.hpp where the output splits into
  *   4 x 32 rectangles: 3x3 / stride 1, 3x3 / stride 2 / zero pad, 7x7 stem with 8 input channels; the general implicit GEMM of conv_h2r.hpp
- *   elsewhere), 1 = the general kernel, 2 = the patch kernel (error if the layer has none).
+ *   elsewhere), 1 = the general kernel, 2 = the patch kernel (error if the layer has none), 3 = the Winograd F(2,3)-along-x form of a
+ *   3x3 / stride-1 / pad-1 layer on frames of whole 4 x 32 tiles (conv_w1.hpp: the kernel the forward runs its ResnetBlock / FuseNet / first
+ *   up-convolution layers on; the op packs the transformed filters itself; `tile` is ignored).
  *   tile: 0 = the launcher's choice; patch 3x3 / stride 1: 32, 64, 128 (4-row tiles), 2128 (2 rows x 128), 20032 / 20064 (the two-K-group
  *   tiles a single-frame forward runs); patch 3x3 / stride 2: 64, 128 (4 rows) or 2128 (2 rows x 128: the forward's shape); others: 64 or 128.
  *   All one-group tiles of one kernel produce identical bits, and so do the two two-group tiles among themselves (tested); the two-group

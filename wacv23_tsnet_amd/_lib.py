@@ -125,6 +125,6 @@ def load() -> C.CDLL:
         _cached = bind(C.CDLL(LIB_PATH))
     except OSError as e:  # pragma: no cover - depends on the machine
         raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
-    if _cached.tsnet_abi_version() != 3:
+    if _cached.tsnet_abi_version() != 4:
         raise RuntimeError("libtsnet_hip.so ABI version mismatch; rebuild")
     return _cached
