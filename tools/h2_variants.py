@@ -57,6 +57,8 @@ if SEL == "bf16":       # the bf16-operand kernels against the fp16 x 2 ones, la
                     ("res (512->512)", (24, 32, 32, 512, 512, 3, 1, 1, 1)), ("dec_up1 (256->128 @128^2)", (8, 128, 128, 256, 128, 3, 1, 1, 1)),
                     ("dec_up2 (128->64 @256^2)", (8, 256, 256, 128, 64, 3, 1, 1, 1))):
         vs = [("fp16x2, the layer's own", code(0)), ("bf16, the layer's own", code(0, bf16=True))]
+        if shp[5] == 3 and shp[6] == 1:
+            vs += [("bf16 w1 (winograd-x)", code(w1=True, bf16=True)), ("bf16 4x64", code(64, bf16=True)), ("bf16 2x128", code(2128, bf16=True))]
         if shp[6] == 2 and shp[3] >= 128:
             vs += [("bf16 h2d 4 waves x 64", code(64, patch=True, bf16=True)), ("bf16 h2d 8 waves x 128", code(128, patch=True, bf16=True)), ("bf16 general 128", code(128, general=True, bf16=True))]
         run(nm, shp, vs, norms=(0,) if shp[5] == 7 else (1,))
