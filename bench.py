@@ -370,11 +370,15 @@ def main(argv=None):
         q = ctx.SimpleQueue()
         pc = mp.start_processes(_spawned, args=(args.gpus, port, args, q), nprocs=args.gpus, join=False, start_method="spawn")
         try:
-            done = False
+            done, t_start = False, time.time()
             while not done:
                 done = pc.join(timeout=0.5)
                 while not q.empty():
                     line = q.get()
+                if not done and time.time() - t_start > 1800:           # a wedged rank must not hang the caller for ever
+                    for p in pc.processes:
+                        p.terminate()
+                    raise SystemExit("bench: the ranks did not finish within 30 minutes")
             while not q.empty():
                 line = q.get()
             break

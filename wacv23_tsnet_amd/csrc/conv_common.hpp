@@ -314,12 +314,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
             const int S = a.fin_S;
             const int img = (int)(stat_tile / (size_t)S);
             int* counter = a.fin_counter + (size_t)img * ((a.Npad + 31) / 32) + n0 / 32;   // 32 = narrowest tile
-            int* flag = reinterpret_cast<int*>(smem_raw + 8192);
-            TSNET_DRAIN_VMEM();
-            __syncthreads();
-            if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if (*flag == S - 1) {
+            auto finalize = [&]() __attribute__((always_inline)) {
                 if (tid < BN && n0 + tid < a.Cout) {
                     double gs[4] = {0, 0, 0, 0}, gq[4] = {0, 0, 0, 0};
                     for (int t = 0; t < S; ++t) {
@@ -337,6 +332,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
                     a.fin_beta[(size_t)img * a.Cout + n0 + tid] = -((float)mean) * al;
                 }
                 if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            };
+            if (BN <= 64) {
+                // One wave stored every partial of this tile (tid < BN): it drains its own stores, counts the workgroup and -- if it is the
+                // last to arrive -- finalises, all in program order and WITHOUT a workgroup barrier; the other waves go straight on to their
+                // output stores.  (On a CU that one workgroup owns -- conv_w1 -- nothing else hides the counter's round trip.)
+                if (tid < 64) {
+                    TSNET_DRAIN_VMEM();
+                    float arrived = 0.f;
+                    if (lane == 0) arrived = (float)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) arrived += __shfl_xor(arrived, off);      // lane 0's value to every lane (the others hold 0)
+                    if ((int)arrived == S - 1) finalize();
+                }
+            } else {
+                int* flag = reinterpret_cast<int*>(smem_raw + 8192);
+                TSNET_DRAIN_VMEM();
+                __syncthreads();
+                if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (*flag == S - 1) finalize();
             }
         }
     }

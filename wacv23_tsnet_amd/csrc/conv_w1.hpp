@@ -326,6 +326,8 @@ template <int NPROD, bool AFFINE, int OPT = 0>
 __global__ __launch_bounds__(64 * kW1Waves, 1)
 void conv_w1_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
+    // One tile per workgroup, the hardware's dynamic dispatch over the CUs.  (A persistent form -- 256 workgroups each walking three tiles
+    // -- measured 5 % slower: 156 against 148 us in the forward; the dispatcher balances the rounds better than a static assignment.)
     int tile_m, tile_n;
     tile_of_block(blockIdx.x, a.tiles_m, a.tiles_n, a.xcd_gn, tile_m, tile_n);
     w1_tile<NPROD, AFFINE, OPT>(a, smem_raw, tile_m, tile_n * 64);
