@@ -13,19 +13,25 @@
 // the running total are conv_h2's.  tools/probes/winograd_probe.py: error against fp64 0.96 x the direct kernel's at the ResnetBlock shape
 // (the 2-D transform: 1.11 x; both inside the 1.5 x line).
 //
-// A tile = 4 x 32 output pixels (64 column pairs) x 64 output channels, EIGHT waves: wave = (position p, 32-channel half), wave tile
-// 64 pairs x 32 channels of ONE position; acc + total = 64 VGPRs.  One workgroup per CU (two waves per SIMD): 768 tiles on the ResnetBlock
-// layers at the headline batch = three rounds.
-//   * the K loop runs in PERIODS of two 16-channel slabs (six steps, one barrier, one accumulation chain); V lives in LDS, three stages of
-//     [slab][position][plane][octet][6 rows x 16 pairs] x 16 B (48 KiB each): period s is consumed while period s+2 is produced, so the
-//     first A fragments of period s+1 are fetched BEFORE the barrier (no exposed LDS latency at a period's start);
-//   * waves 0..5 produce V, one input row each: a lane owns (pair, one of the period's four channel octets) -- 4 input pixels x 8 channels
-//     straight from global memory a whole period ahead (reflection / zero padding in the lane's offsets), IN + ReLU, then one position per
-//     step: transform, split, two ds_write_b128;
-//   * an A fragment = two consecutive V rows (32 pairs) of the wave's position: rows (ky, ky+1) and (ky+2, ky+3) for the two 32-pair halves:
-//     five distinct fragments serve the six (half, ky) uses of a slab; weight fragments five steps ahead (six register sets);
-//   * epilogue: the four positions of a tile meet through LDS (64 KiB over the V stages), wave (row, half) forms its 32 pixels x 32 channels
-//     and runs the shared conv_epilogue (bias, addend, fp64 statistics, in-kernel finalize, amax).
+// A tile = 4 x 32 output pixels (64 column pairs) x 64 output channels, FOURTEEN waves, one workgroup per CU (768 tiles on the ResnetBlock
+// layers at the headline batch = three rounds; the 192 tiles of a single frame = one):
+//   * eight CONSUMERS (waves 0..7): wave = (position p, 32-channel half), wave tile 64 pairs x 32 channels of ONE position, acc + total =
+//     64 VGPRs.  The K loop runs in PERIODS of two 16-channel slabs (six steps, one barrier, one accumulation chain); an A fragment = two
+//     consecutive V rows (32 pairs) of the wave's position: rows (ky, ky+1) and (ky+2, ky+3) for the two 32-pair halves -- five distinct
+//     fragments serve the six (half, ky) uses of a slab; weight fragments two steps ahead (three register sets); s_setprio 2;
+//   * six PRODUCERS (waves 8..13) turn the input patch into V: a period's V has 12 wave-sized items (input row, half of the pairs), two per
+//     producer; lane = (pair, channel quad): the 8 lanes of a pixel read its 32 channels as ONE 128-byte line (a lane per (pixel, octet)
+//     touched 32 - 64 lines per load, and the texture path -- shared with the weight fragments -- bound the first forms of this kernel);
+//     four input pixels per lane, fetched one item ahead (reflection / zero padding in the offsets); IN + ReLU; per position one add, the
+//     split, one ds_write_b64 per plane;
+//   * V lives in LDS, three stages of [slab][position][plane][octet][6 rows x 16 pairs] x 16 B (50 KiB each, region pitches padded so
+//     that a producer's 16-lane write group spans all banks): period s is consumed while period s+2 is produced, so the first A fragments
+//     of period s+1 are fetched BEFORE the barrier (no exposed LDS latency at a period's start);
+//   * epilogue: the four positions of a pair meet through LDS (64 KiB over the V stages), consumer (row, half) forms its 32 pixels x 32
+//     channels and runs the shared conv_epilogue (bias, addend, fp64 statistics, in-kernel finalize, amax); the producers keep the
+//     barriers company;
+//   * <= 128 VGPRs (two SIMDs carry four of the fourteen waves; tests/test_isa.py), 154 - 158 KiB of LDS.
+// How it got here, form by form with measurements: DESIGN.md section 4.4.
 #pragma once
 #include "conv_common.hpp"
 
@@ -33,7 +39,7 @@ namespace tsnet {
 
 constexpr int kW1Prod = 6;                                                        // producer waves (transform): two items of a period each
 constexpr int kW1Waves = 8 + kW1Prod;                                             // eight consumers (MFMA) + the producers
-constexpr int kW1Reg = 96 * 16 + 64;
+constexpr int kW1Reg = 96 * 16 + 64;                                              // one (slab, position, plane, octet) region of V + its bank pad
 constexpr int kW1Stage(int npl) { return 2 * (4 * npl * 2 * kW1Reg + 32); }       // bytes of one V stage: two slabs
 constexpr int w1_lds_bytes(int Cin, int npl = 2) {
     const int v = 3 * kW1Stage(npl), ex = 4 * 64 * 64 * 4 + 2048;                  // V stages | output exchange
@@ -97,9 +103,9 @@ __device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_r
         for (int r = 0; r < 16; ++r) tot[i][r] = 0.f;
 
     if (wave >= 8) {
-        // ================= producers (waves 8..11): V of period pp + 2 while the consumers run period pp =================
+        // ================= producers (waves 8..13): V of period pp + 2 while the consumers run period pp =================
         // A period's V has 6 rows x 16 pairs x 8 channel quads (32 channels) = 12 wave-sized items (row, half of the pairs); producer w owns
-        // items 3 w .. 3 w + 2.  lane -> (pair (lane >> 3) of the half, quad lane & 7): the 8 lanes of a pixel read its 32 channels as ONE
+        // items NIT w .. NIT w + NIT - 1 (NIT = 2).  lane -> (pair (lane >> 3) of the half, quad lane & 7): the 8 lanes of a pixel read its 32 channels as ONE
         // 128-byte line -- a wave's load touches 8 lines, all of them whole (a lane per (pixel, octet) touches 32+ lines for the same bytes, and
         // the texture path, shared with the consumers' weight fragments, was what bound the first forms of this kernel).  Per item: the four
         // input pixels of the pair (columns ox0 - 1 + 2 pair + q of input row oy0 - 1 + row; reflection / zero padding in the offsets), fetched

@@ -217,7 +217,9 @@ inline int h2_scale_log2(float bound) {
 enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3, K_W1 = 4 };
 // a layer packed in the Winograd-along-x form runs conv_w1 and nothing else: 3 x 3 / stride 1 / pad 1 on frames of whole 4 x 32 tiles
 inline bool w1_eligible(const ConvLayer& L, int H, int W) {
-    return L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H >= 4 && W >= 32 && H % kPatchRows == 0 && W % kPatchCols == 0;
+    // (the three V stages + the transform table of 2 Cin floats must fit the CU's 160 KiB beside the epilogue's 64 B of static LDS)
+    return L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H >= 4 && W >= 32 && H % kPatchRows == 0 && W % kPatchCols == 0 &&
+           3 * (size_t)(2 * (4 * 2 * 2 * (96 * 16 + 64) + 32)) + (size_t)2 * L.cin_pad * 4 + 256 <= 160 * 1024;
 }
 // eligible_only: what the layer CAN run on (an explicit request, op tests / tools); otherwise what the forward runs it on
 inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool transform, int rows = kPatchRows, bool eligible_only = false, bool bf16 = false) {
