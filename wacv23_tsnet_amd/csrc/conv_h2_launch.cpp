@@ -78,7 +78,13 @@ void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int o
     if (abl || opt) {
 #ifdef TSNET_TOOLS
         // experiment / ablation instantiations (tools/h2_variants.py): 3 products, raw or transformed input
-        if (nprod != 3) throw std::invalid_argument("conv(h2): experiment variants are built for three products");
+        if (nprod == 1) {               // bf16 operands: the ablations of the 4 x 128 tile (what binds the bf16 modes' 3 x 3 kernel)
+#define TSNET_H2_VAR1(A_) if (pr == 4 && bn == 128 && abl == A_ && opt == 0) { go_h2<4, 128, 2, 2, 1, A_, 0>(a, s); return; }
+            TSNET_H2_VAR1(1) TSNET_H2_VAR1(2) TSNET_H2_VAR1(4) TSNET_H2_VAR1(3) TSNET_H2_VAR1(7) TSNET_H2_VAR1(16)
+#undef TSNET_H2_VAR1
+            throw std::invalid_argument("conv(h2): this bf16 experiment variant is not instantiated");
+        }
+        if (nprod != 3) throw std::invalid_argument("conv(h2): experiment variants are built for one or three products");
 #define TSNET_H2_VAR(PR_, BN_, WM_, WN_, A_, O_) if (pr == PR_ && bn == BN_ && abl == A_ && opt == O_) { go_h2<PR_, BN_, WM_, WN_, 3, A_, O_>(a, s); return; }
         TSNET_H2_VAR(4, 64, 2, 2, 0, 2) TSNET_H2_VAR(4, 64, 2, 2, 0, 4) TSNET_H2_VAR(4, 64, 2, 2, 0, 8) TSNET_H2_VAR(4, 64, 2, 2, 0, 16)
         TSNET_H2_VAR(4, 128, 2, 2, 0, 2) TSNET_H2_VAR(4, 128, 2, 2, 0, 4) TSNET_H2_VAR(4, 128, 2, 2, 0, 16) TSNET_H2_VAR(4, 32, 4, 1, 0, 8)
