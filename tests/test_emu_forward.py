@@ -176,9 +176,10 @@ def test_bf16_operand_mode(emu_lib):
     cnt = (C.c_int64 * 4)()
     emu_lib.tsnet_debug_counters(cnt, 1)
     assert cnt[0] == 12 and cnt[1] == 8          # bf16 operands: the stride-2 layers take the general kernel (engine.cpp conv_class)
-    r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, 1, "cpu")
+    r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, 1, "cpu", flows=flows)
     print("[bf16 mode] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
     assert r["src_fea"] < 5e-2 and r["tar_fea"] < 2e-2 and r["sg"] < 8e-2          # bf16 flip noise on a +-18 range
+    assert r["flow_on_engine_features"] < 1e-4 and r["pg_on_engine_features"] < 4e-3   # the transformation branch on the engine's own features: fp32-class
     assert r["decoder_on_engine_features"] < 3e-2
     assert r["end_to_end_vs_fp32_oracle"] > 10 * r["decoder_on_engine_features"]    # it IS a bf16 computation
     eng.set_sources(inp[0], inp[1], inp[2])
@@ -198,9 +199,10 @@ def test_bf16_storage_mode(emu_lib):
     inp = O.synth_inputs(cfg, 1, 32, 256, seed=15, mask_mode="box")
     eng = Hh.make_engine(cfg, sd, 32, 256, 1, "cpu", lib=emu_lib, operands="bf16s")
     rec, flows = Hh.run_engine(eng, inp, "cpu")
-    r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, 1, "cpu", mode="bf16s")
+    r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, 1, "cpu", mode="bf16s", flows=flows)
     print("[bf16 storage mode] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
     assert r["src_fea"] < 5e-2 and r["tar_fea"] < 2e-2 and r["sg"] < 8e-2
+    assert r["flow_on_engine_features"] < 1e-4 and r["pg_on_engine_features"] < 4e-3
     assert r["decoder_on_engine_features"] < 3e-2
     e1 = Hh.make_engine(cfg, sd, 32, 256, 1, "cpu", lib=emu_lib, operands="bf16")
     rec1, _ = Hh.run_engine(e1, inp, "cpu")

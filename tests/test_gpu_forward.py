@@ -257,8 +257,8 @@ def _bf16_case(cfg, B, H, W, wseed, iseed, mask="box", mode="bf16"):
     inp = O.synth_inputs(cfg, B, H, W, seed=iseed, mask_mode=mask)
     torch.set_num_threads(min(16, torch.get_num_threads()))
     eng = Hh.make_engine(cfg, sd, H, W, B, DEV, operands=mode)
-    rec, _ = Hh.run_engine(eng, inp, DEV)
-    r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, B, DEV, mode=mode)
+    rec, flows = Hh.run_engine(eng, inp, DEV)
+    r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, B, DEV, mode=mode, flows=flows)
     eng.close()
     return r
 
@@ -285,6 +285,9 @@ def _gate(tag, r, gates=None):
     print(f"[{tag} bf16] " + " ".join(f"{k}={v:.3e}" for k, v in r.items()))
     for k, lim in (gates or BF16_GATES)[tag].items():
         assert r[k] <= lim, (tag, k, r[k], lim)
+    # the transformation branch fed the engine's OWN features is fp32-class arithmetic in every operand mode: the fp32 mode's tolerances
+    # (flows 1e-4, warped feature 4e-3) hold here too -- the chaos of the end-to-end figures enters through the features, not through it
+    assert r["flow_on_engine_features"] <= 1e-4 and r["pg_on_engine_features"] <= 4e-3, (tag, r["flow_on_engine_features"], r["pg_on_engine_features"])
 
 
 @pytest.mark.parametrize("wseed,iseed", [(21, 22), (31, 32), (41, 42)])
