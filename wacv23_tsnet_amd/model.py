@@ -114,8 +114,9 @@ class TSNet(nn.Module):
                  addcoords=True, ngf=64, n_downsampling=4, return_flow=False,
                  height=256, width=256, max_batch=None, operands="fp32"):
         super().__init__()
-        if operands not in ("fp32", "bf16"):
-            raise ValueError("operands must be 'fp32' (default, 1e-3 parity with the fp32 reference) or 'bf16' (BASELINE.json configs[2]/[4])")
+        if operands not in ("fp32", "bf16", "bf16s"):
+            raise ValueError("operands must be 'fp32' (default, 1e-3 parity with the fp32 reference), 'bf16' (BASELINE.json configs[2]/[4]: bf16 "
+                             "convolution operands) or 'bf16s' (the same + bf16 storage of the large activations)")
         self.operands = operands
         if is_train:
             raise NotImplementedError("training (GAN/VGG losses, optimisers) is outside the MI355X forward path; "
