@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TSNET_ABI_VERSION 4      /* 4: tsnet_cfg.operand_mode = 2 (bf16 storage); tsnet_op_conv2d kernel = 3 (Winograd-along-x form) */
+#define TSNET_ABI_VERSION 4      /* 4: tsnet_cfg.operand_mode = 2 (bf16 storage); tsnet_op_conv2d kernel = 3 (Winograd-along-x form); tsnet_op_flow_k, tsnet_flow_plan */
 #define TSNET_MAX_SOURCES 8
 
 enum {
@@ -172,6 +172,12 @@ int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64
  *   producer's InstanceNorm+ReLU fused on load when alpha/beta != NULL.
  * tsnet_op_flow       <- transformation branch up to the flow field (TSNet.py:319-323,339-365):
  *   tar_fea (B,h,w,C), src_fea (B,h,w,C) un-normalised NHWC; bboxes (B,H,W); flow (B,h,w,2).
+ * tsnet_op_flow_k     <- the same for K sources per driving frame, as the model's loop over sources runs it (TSNet.py:336-366): tar_fea /
+ *   tar_bbox hold B images, src_fea / src_bbox / flow K*B images (image k*B + b = source k of batch element b), 1 <= K <= 8.  Maps of
+ *   >= 2048 positions (configs[4]: 64 x 64) run flow_kernel_p -- a workgroup keeps its 64 target positions for all K sources.  variant: 0 =
+ *   as the forward runs it; 1 = flow_kernel whatever the plan says; 2 = flow_kernel_p without its exp pass (tools library only).  repeat > 1
+ *   launches the flow kernel that many times (identical results); ms_out (nullable) receives the average time of launches 2 .. repeat by
+ *   HIP events (tools/flow_bench.py), 0 when repeat <= 1.
  * tsnet_op_warp       <- F.grid_sample(bilinear, zeros, align_corners=False) (TSNet.py:366) on NHWC.
  */
 int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin,
@@ -190,6 +196,12 @@ int tsnet_op_upsample2x(const float* x, const float* alpha, const float* beta, i
                         int N, int H, int W, int C, float* y, void* stream);
 int tsnet_op_flow(const float* tar_fea, const float* src_fea, const float* tar_bbox, const float* src_bbox,
                   int B, int h, int w, int C, int H, int W, float* flow, void* stream);
+int tsnet_op_flow_k(const float* tar_fea, const float* src_fea, const float* tar_bbox, const float* src_bbox,
+                    int B, int K, int h, int w, int C, int H, int W, float* flow, int variant, int repeat, float* ms_out, void* stream);
+/* Which kernel tsnet_op_flow / tsnet_op_flow_k / the forward run on B driving frames of h x w positions, C channels: 0 = flow_kernel (a
+ * workgroup per (source, batch element, 64 targets)); G >= 1 = flow_kernel_p with G workgroups per target tile (csrc/flow_warp.hpp); -1 bad
+ * arguments.  Host logic only. */
+int tsnet_flow_plan(int B, int h, int w, int C);
 int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, int C, float* out, void* stream);
 const char* tsnet_op_last_error(void);
 

@@ -86,6 +86,8 @@ void syncthreads() {
     while (g_bar_gen == gen) yield();
 }
 
+void wave_sync() { wave_rendezvous(g_waves[g_cur / 64]); }
+
 float shfl_xor(float v, int mask) {
     WaveState& w = g_waves[g_cur / 64];
     const int lane = g_cur & 63, par = w.gen & 1;

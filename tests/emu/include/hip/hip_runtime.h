@@ -47,6 +47,7 @@ extern Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 extern unsigned char* g_dyn_smem;
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void syncthreads();
+void wave_sync();
 float shfl_xor(float v, int mask);
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 f32x16_t mfma_32x32x2(float a, float b, f32x16_t c);
@@ -106,6 +107,7 @@ static inline unsigned emu_bf16_rne(float f) { unsigned u; __builtin_memcpy(&u, 
 #define TSNET_SETPRIO(n) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define TSNET_DRAIN_VMEM() ((void)0)
+#define TSNET_WAVE_SYNC() emu::wave_sync()        // lanes are independent fibers here: a rendezvous where the hardware's lock-step is relied on
 // device-scope atomics of the statistics hand-off (conv_x3.hpp x3_epilogue): workgroups run one after another here
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))

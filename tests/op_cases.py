@@ -209,6 +209,41 @@ def flow_case(lib, dev, B, h, w, C, mask_mode="bernoulli", seed=0, spike=False):
     return (flow.cpu() - flow_ref).abs().max().item(), (nchw(warped.cpu()) - warped_ref).abs().max().item()
 
 
+def flow_k_case(lib, dev, B, K, h, w, C, mask_mode="bernoulli", seed=0, spike=True):
+    """K sources per driving frame (the model's loop, TSNet.py:336-366) through tsnet_op_flow_k vs the oracle's transformation_branch run
+    once per source.  Maps of >= 2048 positions take flow_kernel_p (csrc/flow_persist.hpp): a workgroup keeps its target tile for the K
+    sources, G workgroups share a (source, target tile) and the last to arrive merges their partial softmax states.  Both calls start from
+    fresh scratch memory: a partial state read before it is visible would show as a difference.  Returns max|d flow| over all sources."""
+    from oracle import tsnet_oracle as O
+    H, W = h * 8, w * 8
+    P = h * w
+    tar = F.relu(_rand(seed, "tar", (B, C, h, w), -1, 1))
+    mt = prng.bernoulli(seed, "mt", (B, H, W)) if mask_mode == "bernoulli" else prng.uniform01(seed, "mt", (B, H, W))
+    srcs, mss, refs = [], [], []
+    for k in range(K):
+        src = _rand(seed + 1 + k, "src", (B, C, h, w), -1, 1) * 3
+        if spike:                                                         # one dominant source per target, somewhere else for every k
+            perm = (torch.arange(P) * (2 * k + 3) + 7 * k) % P if P % (2 * k + 3) else torch.arange(P - 1, -1, -1)
+            srcf, tarf = src.view(B, C, P), tar.view(B, C, P)
+            srcf[:, :, perm] = srcf[:, :, perm] * 0.2 + 4.0 * tarf
+        ms = prng.bernoulli(seed + 1 + k, "ms", (B, H, W)) if mask_mode == "bernoulli" else prng.uniform01(seed + 1 + k, "ms", (B, H, W))
+        _, flow_ref = O.transformation_branch(tar, src, mt.unsqueeze(1), ms.unsqueeze(1))
+        srcs.append(nhwc(src)); mss.append(ms); refs.append(flow_ref)
+    tard, srcd = nhwc(tar).to(dev), torch.cat(srcs, 0).contiguous().to(dev)
+    mtd, msd = mt.to(dev), torch.cat(mss, 0).contiguous().to(dev)
+    flow = torch.empty((K * B, h, w, 2), device=dev)
+    rc = lib.tsnet_op_flow_k(tard.data_ptr(), srcd.data_ptr(), mtd.data_ptr(), msd.data_ptr(), B, K, h, w, C, H, W, flow.data_ptr(), 0, 1, None, None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    # a second call must give the same bits (arrival counters back at zero, merge order fixed)
+    flow2 = torch.empty_like(flow)
+    rc = lib.tsnet_op_flow_k(tard.data_ptr(), srcd.data_ptr(), mtd.data_ptr(), msd.data_ptr(), B, K, h, w, C, H, W, flow2.data_ptr(), 0, 2, None, None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    assert torch.equal(flow, flow2)
+    return (flow.cpu() - torch.cat(refs, 0)).abs().max().item()
+
+
 def warp_case(lib, dev, B, h, w, C, seed=0):
     """F.grid_sample(bilinear, zeros, align_corners=False) with flows that leave [-1,1] (zero padding
     and border blending exercised) vs tsnet_op_warp."""

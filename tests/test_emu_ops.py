@@ -133,6 +133,19 @@ def test_flow_ragged_positions_and_spike(emu_lib):
     assert df < 5e-5 and dw < 4e-3   # dw = flow error x feature gradient
 
 
+def test_flow_large_map_persistent_target_tiles(emu_lib):
+    """flow_kernel_p (maps of >= 2048 positions): 32 x 64 positions, one batch element -> 32 target tiles x G = 4 workgroups, every wave one
+    source pair per slice; K = 2 sources swept with the target tile kept; partial states merged by the last workgroup to arrive.  Second
+    case: four batch elements (G = 2, two pairs per wave and slice) with soft masks."""
+    assert emu_lib.tsnet_flow_plan(1, 32, 64, 16) == 4 and emu_lib.tsnet_flow_plan(4, 64, 32, 8) == 2
+    assert emu_lib.tsnet_flow_plan(4, 32, 32, 512) == 0            # configs[1]: flow_kernel fills the chip (192 workgroups, 2 pairs per wave)
+    assert emu_lib.tsnet_flow_plan(1, 64, 64, 512) == 4            # configs[4] shard: 64 target tiles x 4 = one workgroup per CU
+    assert emu_lib.tsnet_flow_plan(4, 64, 64, 512) == 1            # the target tiles alone fill the chip: no split, no cross-workgroup merge
+    assert emu_lib.tsnet_flow_plan(1, 64, 64, 1024) == 0 and emu_lib.tsnet_flow_plan(1, 60, 64, 512) == 0   # LDS; ragged
+    assert oc.flow_k_case(emu_lib, "cpu", 1, 2, 32, 64, 16, "bernoulli") < 5e-5
+    assert oc.flow_k_case(emu_lib, "cpu", 4, 1, 64, 32, 8, "soft") < 5e-5
+
+
 def test_flow_many_tiles(emu_lib):
     df, dw = oc.flow_case(emu_lib, "cpu", 1, 16, 16, 16, "ones", spike=True)   # 4 pairs of 32-source blocks: waves 0..3 sweep one each
     assert df < 5e-5 and dw < 4e-3   # dw = flow error x feature gradient

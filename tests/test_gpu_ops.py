@@ -77,6 +77,17 @@ def test_flow_full_size(lib):
     assert df < 5e-5 and dw < 4e-3   # dw = flow error x feature gradient
 
 
+def test_flow_configs4_form_persistent_target_tiles(lib):
+    """BASELINE.json configs[4] per GPU: one driving frame, five sources, 64 x 64 positions, 512 channels -> flow_kernel_p (64 target tiles
+    x G = 4 workgroups, one per CU; partial states merged across workgroups); then four driving frames (G = 1, no cross-workgroup merge)
+    and two at 32 x 64 positions (G = 4, one source pair per wave and slice).  Each case runs twice and must give the same bits: the
+    packed-arithmetic build of this kernel did not (csrc/flow_persist.hpp)."""
+    assert lib.tsnet_flow_plan(1, 64, 64, 512) == 4 and lib.tsnet_flow_plan(4, 64, 64, 512) == 1 and lib.tsnet_flow_plan(2, 32, 64, 512) == 4
+    assert oc.flow_k_case(lib, DEV, 1, 5, 64, 64, 512) < 5e-5
+    assert oc.flow_k_case(lib, DEV, 4, 2, 64, 64, 512, "soft") < 5e-5
+    assert oc.flow_k_case(lib, DEV, 2, 3, 32, 64, 512) < 5e-5
+
+
 def test_flow_ragged_positions(lib):
     df, dw = oc.flow_case(lib, DEV, 1, 7, 9, 32, "bernoulli", spike=True)
     assert df < 5e-5 and dw < 4e-3   # dw = flow error x feature gradient

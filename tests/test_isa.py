@@ -36,3 +36,23 @@ def test_winograd_kernel_fits_fourteen_waves():
     assert len(res) >= 8, res
     for name, (vgpr, scratch) in res.items():
         assert vgpr <= 128 and scratch == 0, (name, vgpr, scratch)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
+def test_large_map_flow_kernel_has_no_packed_fp32_arithmetic():
+    """flow_kernel_p built WITH the SLP vectorizer (96 v_pk_fma_f32, 114 v_pk_mul_f32, 79 v_pk_add_f32 in its softmax epilogue, beside the
+    other wave's MFMAs) returned different and wrong flows from run to run on the MI355X (csrc/flow_persist.hpp, profiles/round4_flow_cfg4.txt);
+    the scalar build is exact.  Its translation unit is compiled with -fno-slp-vectorize: this pins the flag, two waves per SIMD (<= 256
+    VGPRs) and no scratch."""
+    spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
+    ic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ic)
+    asm = ic.compile_asm(unit="flow_p_launch.cpp")
+    res = ic.kernel_resources(asm, "flow_kernel_p")
+    assert res, "flow_kernel_p is not in the product library"
+    for name, (vgpr, scratch) in res.items():
+        assert vgpr <= 256 and scratch == 0, (name, vgpr, scratch)
+    text = open(asm).read()
+    start = text.index("flow_kernel_p")
+    assert "v_mfma_f32_32x32x16_f16" in text[start:]
+    assert "v_pk_fma_f32" not in text and "v_pk_mul_f32" not in text and "v_pk_add_f32" not in text

@@ -33,6 +33,9 @@ __device__ __forceinline__ tsnet_brsrc_t tsnet_make_brsrc(const void* p, unsigne
 #ifndef TSNET_UNIFORM
 #define TSNET_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
+#ifndef TSNET_WAVE_SYNC
+#define TSNET_WAVE_SYNC() __builtin_amdgcn_wave_barrier()     // the lanes of a wave run in lock-step; the emulator's do not
+#endif
 #ifndef TSNET_DRAIN_VMEM
 #define TSNET_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif

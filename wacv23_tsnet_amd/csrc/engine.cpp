@@ -473,11 +473,23 @@ void run_l2norm_split(Ctx& ctx, const float* x, unsigned short* q, int N, int P,
     check_launch("l2norm_split");
 }
 
-void run_flow(Ctx& ctx, FlowArgs a, int NB) {
+// variant (tsnet_op_flow_k; the forward passes 0): 1 = flow_kernel whatever the plan says; 2 = flow_kernel_p without the exp pass (tools build)
+void run_flow(Ctx& ctx, FlowArgs a, int NB, int variant = 0) {
     if (a.C & 7) throw ArgError("flow: C must be a multiple of 8");
+    if (variant < 0 || variant > 2) throw ArgError("flow: variant 0, 1 or 2");
     TimeScope ts(ctx, TSNET_T_FLOW);
-    // 64 target positions per workgroup while their planes fit in LDS beside the mask row (C <= 512 at P <= 4096), else 32
     const size_t budget = 160 * 1024;
+    // large maps (a.part / a.cnt supplied): persistent target tiles, the K sources of a batch element swept in G slices (flow_persist.hpp)
+    const int G = (a.part && a.cnt && NB % a.B == 0 && NB / a.B <= 8 && variant != 1) ? flowp_plan(a.B, a.h, a.w, a.C) : 0;
+    if (G) {
+        a.K = NB / a.B; a.G = G;
+        try {
+            launch_flow_p(a, variant, ctx.stream);
+        } catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
+        check_launch("flow_p");
+        return;
+    }
+    // 64 target positions per workgroup while their planes fit in LDS beside the mask row (C <= 512 at P <= 4096), else 32
     const int NT = flow_lds_bytes(2, a.h, a.w, a.C) <= budget ? 2 : 1;
     const size_t lds = flow_lds_bytes(NT, a.h, a.w, a.C);
     if (lds > budget) throw ArgError("flow: feature width / position count exceed the LDS budget");
@@ -605,6 +617,8 @@ struct tsnet_engine {
     double* part_side = nullptr;       // statistics partials / arrival counters of the side lane
     int* fin_counter = nullptr;        // arrival counters of the in-kernel statistics finalize (conv_epilogue), all zero between launches
     int* fin_counter_side = nullptr;
+    int* flow_cnt = nullptr;           // arrival counters of flow_kernel_p (256 ints behind the two above), all zero between launches
+    float* flow_part = nullptr;        // its partial softmax states (large maps only)
     hipStream_t side_stream = nullptr; // target-label chain of a full forward runs here, concurrently with the source encoder
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
     float* train_ws = nullptr;         // workspace of tsnet_train_extras, allocated on first use
@@ -839,6 +853,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     for (int i = 0; i < 4; ++i) { want(&ab[i][0], NB * 2 * C); want(&ab[i][1], NB * 2 * C); }
     for (int i = 0; i < 2; ++i) { want(&ab_side[i][0], NB * 2 * C); want(&ab_side[i][1], NB * 2 * C); }
     want(&bbox_copy, NB * H * W);
+    if (P >= 2048) want(&flow_part, (size_t)K * 256 * 64 * 2 * 2);      // flow_kernel_p splits a source only while target tiles x G <= 256
     // InstanceNorm partials (doubles = 2 floats each): the stand-alone pass N*64*C*2, a conv epilogue N * tiles-per-image * Cout * 2
     // with tiles of at least 64 positions (ceil for ragged images), per lane
     size_t part_doubles = NB * 64 * 2 * C * 2;
@@ -860,9 +875,10 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     HIP_TRY(hipMemsetAsync(amax, 0, (size_t)(K + 3) * Bmax * sizeof(unsigned), s));
     // arrival counters: one per (image, 32-channel group) of a launch; launches with more (image, group) pairs than kFinCounterInts
     // fall back to the in_finalize2 kernel (run_conv checks the index range against this size)
-    HIP_TRY(hipMalloc((void**)&fin_counter, 2 * kFinCounterInts * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(fin_counter, 0, 2 * kFinCounterInts * sizeof(int), s));
+    HIP_TRY(hipMalloc((void**)&fin_counter, (2 * kFinCounterInts + 256) * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(fin_counter, 0, (2 * kFinCounterInts + 256) * sizeof(int), s));
     fin_counter_side = fin_counter + kFinCounterInts;
+    flow_cnt = fin_counter + 2 * kFinCounterInts;
     // side lane (tsnet_forward): own statistics scratch, counters, (alpha, beta) pairs (above), stream and events
     HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -977,6 +993,7 @@ void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb,
     fa.tq = reinterpret_cast<const unsigned short*>(that); fa.sq = reinterpret_cast<const unsigned short*>(shat); fa.tar_bbox = tar_bbox;
     for (int s = 0; s < K; ++s) fa.src_bbox[s] = bbox_copy + (size_t)s * Bmax * H * W;
     fa.gx = d_gx; fa.gy = d_gy; fa.flow = flow;
+    fa.part = reinterpret_cast<unsigned long long*>(flow_part); fa.cnt = flow_cnt;
     fa.B = B; fa.P = P; fa.C = C; fa.h = h; fa.w = w; fa.H = H; fa.W = W; fa.sy = H / h; fa.sx = W / w;
     run_flow(cx, fa, NB);
     if (out_flow)
@@ -1480,33 +1497,65 @@ int tsnet_op_upsample2x(const float* x, const float* alpha, const float* beta, i
     OP_END
 }
 
-int tsnet_op_flow(const float* tar_fea, const float* src_fea, const float* tar_bbox, const float* src_bbox,
-                  int B, int h, int w, int C, int H, int W, float* flow, void* stream) {
-    OP_BEGIN
+// tar_fea (B), src_fea / src_bbox / flow (K*B, image k*B + b).  repeat > 1 re-launches the flow kernel (identical results) for timing.
+static void op_flow_impl(const float* tar_fea, const float* src_fea, const float* tar_bbox, const float* src_bbox,
+                         int B, int K, int h, int w, int C, int H, int W, float* flow, int variant, int repeat, float* ms_out, hipStream_t stream) {
     if (!tar_fea || !src_fea || !tar_bbox || !src_bbox || !flow) throw ArgError("null tensor");
+    if (B < 1 || K < 1 || K > 8) throw ArgError("flow op: 1 <= K <= 8 sources, B >= 1");
     if (H % h || W % w) throw ArgError("flow op: bbox size must be a multiple of the feature size");
-    Ctx ctx; ctx.stream = (hipStream_t)stream;
-    const int P = h * w;
-    unsigned short *that = nullptr, *shat = nullptr;
-    float *gx = nullptr, *gy = nullptr;
-    HIP_TRY(hipMalloc((void**)&that, flow_plane_halves(B, P, C) * 2));
-    HIP_TRY(hipMalloc((void**)&shat, flow_plane_halves(B, P, C) * 2));
-    HIP_TRY(hipMalloc((void**)&gx, w * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&gy, h * sizeof(float)));
+    Ctx ctx; ctx.stream = stream;
+    const int P = h * w, NB = K * B;
+    DevBufs bufs;
+    auto* that = bufs.alloc<unsigned short>(flow_plane_halves(B, P, C) * 2);
+    auto* shat = bufs.alloc<unsigned short>(flow_plane_halves(NB, P, C) * 2);
+    auto* gx = bufs.alloc<float>(w * sizeof(float));
+    auto* gy = bufs.alloc<float>(h * sizeof(float));
     std::vector<float> hx(w), hy(h);
     linspace_pm1(w, hx.data()); linspace_pm1(h, hy.data());
     HIP_TRY(hipMemcpy(gx, hx.data(), w * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(gy, hy.data(), h * sizeof(float), hipMemcpyHostToDevice));
-    run_l2norm_split(ctx, tar_fea, that, B, P, C);
-    run_l2norm_split(ctx, src_fea, shat, B, P, C);
     FlowArgs fa{};
-    fa.tq = that; fa.sq = shat; fa.tar_bbox = tar_bbox; fa.src_bbox[0] = src_bbox; fa.gx = gx; fa.gy = gy; fa.flow = flow;
+    const int G = flowp_plan(B, h, w, C);
+    if (G) {
+        fa.part = bufs.alloc<unsigned long long>(flowp_part_words(NB, P, G) * 8);
+        fa.cnt = bufs.alloc<int>((size_t)B * (P / 64) * sizeof(int));
+        HIP_TRY(hipMemsetAsync(fa.cnt, 0, (size_t)B * (P / 64) * sizeof(int), ctx.stream));
+    }
+    run_l2norm_split(ctx, tar_fea, that, B, P, C);
+    run_l2norm_split(ctx, src_fea, shat, NB, P, C);
+    fa.tq = that; fa.sq = shat; fa.tar_bbox = tar_bbox; fa.gx = gx; fa.gy = gy; fa.flow = flow;
+    for (int k = 0; k < K; ++k) fa.src_bbox[k] = src_bbox + (size_t)k * B * H * W;
     fa.B = B; fa.P = P; fa.C = C; fa.h = h; fa.w = w; fa.H = H; fa.W = W; fa.sy = H / h; fa.sx = W / w;
-    run_flow(ctx, fa, B);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ms_out) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
+    run_flow(ctx, fa, NB, variant);
+    if (ms_out) HIP_TRY(hipEventRecord(e0, ctx.stream));
+    for (int r = 1; r < repeat; ++r) run_flow(ctx, fa, NB, variant);
+    if (ms_out) HIP_TRY(hipEventRecord(e1, ctx.stream));
     HIP_TRY(hipStreamSynchronize(ctx.stream));
-    (void)hipFree(that); (void)hipFree(shat); (void)hipFree(gx); (void)hipFree(gy);
+    if (ms_out) {
+        float ms = 0.f;
+        if (repeat > 1) { HIP_TRY(hipEventElapsedTime(&ms, e0, e1)); ms /= (float)(repeat - 1); }
+        *ms_out = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+}
+
+int tsnet_op_flow(const float* tar_fea, const float* src_fea, const float* tar_bbox, const float* src_bbox,
+                  int B, int h, int w, int C, int H, int W, float* flow, void* stream) {
+    OP_BEGIN
+    op_flow_impl(tar_fea, src_fea, tar_bbox, src_bbox, B, 1, h, w, C, H, W, flow, 0, 1, nullptr, (hipStream_t)stream);
     OP_END
 }
+
+int tsnet_op_flow_k(const float* tar_fea, const float* src_fea, const float* tar_bbox, const float* src_bbox,
+                    int B, int K, int h, int w, int C, int H, int W, float* flow, int variant, int repeat, float* ms_out, void* stream) {
+    OP_BEGIN
+    op_flow_impl(tar_fea, src_fea, tar_bbox, src_bbox, B, K, h, w, C, H, W, flow, variant, repeat, ms_out, (hipStream_t)stream);
+    OP_END
+}
+
+int tsnet_flow_plan(int B, int h, int w, int C) { return (B < 1 || h < 1 || w < 1 || C < 8 || (C & 7)) ? -1 : flowp_plan(B, h, w, C); }
 
 int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, int C, float* out, void* stream) {
     OP_BEGIN

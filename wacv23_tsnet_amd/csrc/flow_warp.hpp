@@ -18,27 +18,19 @@
 //                         over sources is in-lane; it keeps an online-softmax state per column whose "value" is the 2-vector grid
 //                         coordinate, and the 16 partial states of a column (8 waves x 2 half-waves) are merged in a fixed order.
 //
+//   flow_kernel_p         (flow_persist.hpp, its own translation unit) the same sweep for LARGE maps (P >= 2048: BASELINE.json configs[4] is
+//                         64 x 64 positions, five sources): a workgroup keeps its 64 target positions for all K sources of its batch element
+//                         and sweeps 1 / G of every source image; tiles x G workgroups = one per CU.
+//
 // Masks: corr = (T.S) * (mt*ms + (1-mt)*(1-ms)), which equals the reference's sum of two masked
 // products exactly for 0/1 masks and to rounding for soft masks; masked pairs stay at logit 0
 // (NOT -inf), as in the reference.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_common.hpp"
+#include "flow_args.hpp"
 
 namespace tsnet {
-
-constexpr int kFlowWaves = 8;
-constexpr float kFlowScale = 16384.0f;                       // 2^14: |v| <= 1 -> |hi| <= 2^14, lo keeps 11 more bits down to |v| ~ 2e-5
-constexpr float kFlowUnscale = 1.0f / (16384.0f * 16384.0f);
-inline int flow_ppad(int P) { return (P + 63) / 64 * 64; }
-inline int flow_ksteps(int C) { return (C + 31) / 32 * 2; }  // 16-channel steps, padded to an even count
-inline size_t flow_plane_halves(int N, int P, int C) { return (size_t)N * flow_ppad(P) * flow_ksteps(C) * 16 * 2; }
-// LDS bytes of flow_kernel<NT>: max(target planes, merge buffer) + the source-mask row
-inline size_t flow_lds_bytes(int NT, int P, int C) {
-    const size_t t = (size_t)NT * flow_ksteps(C) * 2048, r = (size_t)2 * kFlowWaves * NT * 32 * 16;
-    return (t > r ? t : r) + (size_t)flow_ppad(P) * 4;
-}
-inline size_t flow_lds_bytes(int NT, int h, int w, int C) { return flow_lds_bytes(NT, h * w, C) + (size_t)(((w + 3) & ~3) + ((h + 3) & ~3)) * 4; }
 
 // F.normalize(p=2, dim=channel, eps=1e-12) on NHWC rows -> fp16 (hi, lo) planes in fragment order.  grid = N * Ppad / 4 blocks of 4 waves.
 __global__ __launch_bounds__(256) void l2norm_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ q, int N, int P, int Ppad, int C, int KC) {
@@ -76,16 +68,6 @@ __global__ __launch_bounds__(256) void l2norm_split_kernel(const float* __restri
     }
 }
 
-struct FlowArgs {
-    const unsigned short* tq; // target planes of B images (l2norm_split_kernel)
-    const unsigned short* sq; // source planes of NB images, n = s*B + b
-    const float* tar_bbox;    // (B, H, W)
-    const float* src_bbox[8]; // per source (B, H, W)
-    const float* gx;          // (w) linspace(-1,1,w)
-    const float* gy;          // (h)
-    float* flow;              // (NB, P, 2)
-    int B, P, C, h, w, H, W, sy, sx;
-};
 
 // grid = Ppad / (32 NT) * NB (1-D), block = 512.  dyn LDS: target planes NT * KC * 2 KiB, then ms[Ppad], gx[w], gy[h]; the merge buffer
 // [16][NT * 32][4] floats aliases the target planes after the sweep.
