@@ -269,9 +269,11 @@ def _bf16_case(cfg, B, H, W, wseed, iseed, mask="box", mode="bf16"):
 # a few positions), the mean is not.
 BF16_GATES = {
     "cfg2": dict(src_fea=0.175, tar_fea=0.0095, sg=0.0553, decoder_on_engine_features=0.0315, end_to_end_vs_bf16_oracle_mean=0.128, decoder_on_engine_features_mean=0.0032),
-    # decoder_on_engine_features (a MAXIMUM over 786 k pixels of bf16 rounding flips) moves with any change of the decoder's input: 5.1 / 5.3 /
-    # 6.3e-3 on the three draws before flow_kernel_p changed the flows by <= 1e-5, 6.3 / 7.1e-3 after; its MEAN (1.8-1.9e-4) does not move
-    "cfg4": dict(src_fea=0.173, tar_fea=0.0088, sg=0.0426, decoder_on_engine_features=0.009, end_to_end_vs_bf16_oracle_mean=0.1415, decoder_on_engine_features_mean=0.00023),
+    # decoder_on_engine_features is a MAXIMUM over 786 k pixels of bf16 rounding flips: one pixel off a smooth tail (8.2e-3, then 6.5, 5.5,
+    # 5.4e-3 ...; 99.999 % of the pixels below 4.7e-3) that moves with any change of the decoder's input -- 5.1 / 5.3 / 6.3e-3 on the three
+    # draws before flow_kernel_p changed the flows by <= 1e-5, 6.3 / 7.1 / 8.2e-3 after (the forward is bit-deterministic; the MEAN,
+    # 1.8-1.9e-4, did not move).  1.33 x the worst.
+    "cfg4": dict(src_fea=0.173, tar_fea=0.0088, sg=0.0426, decoder_on_engine_features=0.011, end_to_end_vs_bf16_oracle_mean=0.1415, decoder_on_engine_features_mean=0.00023),
 }
 
 
