@@ -133,6 +133,18 @@ def test_flow_ragged_positions_and_spike(emu_lib):
     assert df < 5e-5 and dw < 4e-3   # dw = flow error x feature gradient
 
 
+def test_flow_k_small_map_and_argument_errors(emu_lib):
+    """tsnet_op_flow_k on a small map (flow_kernel: one workgroup per (source, batch element, 64 targets)) with K = 3 sources; bad arguments
+    are refused with a message, not run."""
+    import torch
+    assert oc.flow_k_case(emu_lib, "cpu", 2, 3, 6, 8, 16, "bernoulli") < 5e-5
+    z = torch.zeros(8 * 6 * 8 * 16)
+    for K, variant, word in ((9, 0, "sources"), (0, 0, "sources"), (1, 3, "variant")):
+        rc = emu_lib.tsnet_op_flow_k(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, K, 6, 8, 16, 48, 64, z.data_ptr(), variant, 1, None, None)
+        assert rc != 0 and word in emu_lib.tsnet_op_last_error().decode()
+    assert emu_lib.tsnet_flow_plan(0, 6, 8, 16) == -1 and emu_lib.tsnet_flow_plan(1, 6, 8, 12) == -1 and emu_lib.tsnet_flow_plan(1, 6, 8, 16) == 0
+
+
 def test_flow_large_map_persistent_target_tiles(emu_lib):
     """flow_kernel_p (maps of >= 2048 positions): 32 x 64 positions, one batch element -> 32 target tiles x G = 4 workgroups, every wave one
     source pair per slice; K = 2 sources swept with the target tile kept; partial states merged by the last workgroup to arrive.  Second
