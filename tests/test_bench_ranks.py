@@ -76,3 +76,34 @@ def test_bench_main_launches_its_own_ranks(emu_lib, capsys):
     assert len(out) == 1 and json.loads(out[0])["n_gpus"] == 2
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["global_batch"] == 2 and line["value"] > 0
     assert line["cpu_baseline"] is None and line["secondary_bf16_cfg2"] is None          # N > 1: neither leg runs
+
+
+def test_bench_config_switch_runs_every_baseline_config_multi_rank(emu_lib, capsys):
+    """`python bench.py --gpus 2 --config cfgN`: the multi-rank path runs every BASELINE.json workload, not only the headline.
+    World size 2 over gloo on the emulation build, tiny shapes; each configuration keeps what defines it -- configs[3] its 25 label channels
+    and decoder ResnetBlocks (TSNet_pose, demo_pose.py:120-124), configs[2] / [4] the bf16-operand mode, configs[4] its five sources."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from conftest import build_emu_lib
+    want = {"cfg2": (2, "bf16"), "cfg3": (3, "f32"), "cfg4": (4, "bf16")}
+    for name, (index, dt) in want.items():
+        line = bench.main(["--gpus", "2", "--steps", "1", "--warmup", "1", "--device", "cpu", "--lib", build_emu_lib(), "--tiny", "--config", name])
+        out = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+        assert len(out) == 1 and json.loads(out[0])["config"]["name"] == name
+        assert line["n_gpus"] == 2 and line["config"]["baseline_config_index"] == index and line["config"]["global_batch"] == 2
+        assert line["dtype"].startswith(dt) and "configs[%d]" % index in line["config"]["workload"] and line["value"] > 0
+        assert line["scaling"] == "weak" and line["metric"] != bench.CONFIGS["cfg1"]["metric"]
+
+
+def test_bench_configs_match_baseline_json():
+    """The four bench workloads are BASELINE.json's configs[1..4]: label count, decoder blocks, sources, frame size, per-GPU batch, operands."""
+    sys.path.insert(0, ROOT)
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    c = bench.CONFIGS
+    assert (c["cfg1"]["batch"], c["cfg1"]["size"], c["cfg1"]["model"]["n_source"], c["cfg1"]["operands"]) == (4, 256, 3, "fp32") and "fp32" in base[1]
+    assert (c["cfg2"]["batch"], c["cfg2"]["model"]["n_blocks"], c["cfg2"]["operands"]) == (8, 4, "bf16") and "bs=8 bf16" in base[2]
+    assert (c["cfg3"]["batch"] * 8, c["cfg3"]["model"]["label_nc"], c["cfg3"]["pose"], c["cfg3"]["operands"]) == (32, 25, True, "fp32") and "bs=32" in base[3]
+    assert (c["cfg4"]["size"], c["cfg4"]["model"]["n_source"], c["cfg4"]["operands"]) == (512, 5, "bf16") and "512" in base[4] and "n_source=5" in base[4]
+    for k, v in c.items():
+        assert "BASELINE.json configs[%d]" % v["index"] in v["workload"]

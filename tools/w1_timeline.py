@@ -1,0 +1,83 @@
+"""GPU box: where a conv_w1 workgroup's time goes (tools build).  One stamped launch (abl 30: raw input, 31: IN + ReLU input; statistics
+on) of the ResnetBlock layer; every wave records s_memrealtime (100 MHz) at: 0 entry, 1 before / 2 after the prologue barrier (V(0), V(1)
+complete), 3 end of the K loop (consumers) / of the item stream (producers), 4 after the barrier behind it, 5 after the exchange,
+6 after the output transform, 7 end.  Prints the median / p10 / p90 of each phase over the workgroups, per dispatch round, and the
+per-CU occupancy picture (how many workgroups a CU ran, when each started relative to the launch's first stamp).
+usage: w1_timeline.py [N images = 12] [norm = 0|1] [Cin = 512] [Cout = 512] [H = 32]"""
+import ctypes as C, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from wacv23_tsnet_amd import _lib
+lib = _lib.load_tools()
+torch.zeros(1, device="cuda")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+norm = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+Cin = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+Cout = int(sys.argv[4]) if len(sys.argv) > 4 else 512
+H = int(sys.argv[5]) if len(sys.argv) > 5 else 32
+W = H
+abl = 31 if norm else 30
+variant = 32768 | (abl << 16)
+ms = C.c_float()
+rc = lib.tsnet_bench_conv(N, H, W, Cin, Cout, 3, 1, 1, 1, (1 if norm else 0) | 2, variant, 4, C.byref(ms), None)
+if rc != 0:
+    raise SystemExit("bench_conv: " + lib.tsnet_op_last_error().decode())
+tiles = N * (H // 4) * (W // 32) * (Cout // 64)
+nt = min(tiles, 1024)
+WV, SL = 14, 16
+buf = np.zeros(nt * WV * SL, dtype=np.uint64)
+lib.tsnet_w1_prof_read.argtypes = [C.c_void_p, C.c_int]
+rc = lib.tsnet_w1_prof_read(buf.ctypes.data_as(C.c_void_p), nt)
+if rc != 0:
+    raise SystemExit("prof_read %d" % rc)
+t = buf.reshape(nt, WV, SL).astype(np.int64)
+t0 = t[:, :, 0].min()
+us = lambda x: x / 100.0            # 100 MHz ticks -> us
+print(f"conv_w1 N={N} {H}x{W} {Cin}->{Cout} norm={norm} stats=1: {ms.value*1e3:.1f} us per launch (4 launches timed), {tiles} tiles ({nt} stamped)")
+cons, prod = t[:, :8, :], t[:, 8:, :]
+start = t[:, :, 0].min(axis=1)
+end = t[:, :, 7].max(axis=1)
+dur = us(end - start)
+print(f"workgroup duration: median {np.median(dur):.2f} us  p10 {np.percentile(dur,10):.2f}  p90 {np.percentile(dur,90):.2f}; launch span (first stamp -> last stamp) {us(end.max()-t0):.1f} us")
+def ph(name, a):
+    a = us(a.reshape(-1).astype(np.float64))
+    print(f"   {name:58s} median {np.median(a):7.2f}  p10 {np.percentile(a,10):7.2f}  p90 {np.percentile(a,90):7.2f} us")
+print("consumers (waves 0..7):")
+ph("entry -> prologue barrier reached (table, first weights)", cons[:, :, 1] - cons[:, :, 0])
+ph("waiting at the prologue barrier (V(0), V(1) in production)", cons[:, :, 2] - cons[:, :, 1])
+ph("K loop", cons[:, :, 3] - cons[:, :, 2])
+ph("K loop end -> barrier passed", cons[:, :, 4] - cons[:, :, 3])
+ph("exchange write + barrier", cons[:, :, 5] - cons[:, :, 4])
+ph("output transform + barrier", cons[:, :, 6] - cons[:, :, 5])
+ph("conv_epilogue (bias, statistics, hand-off, stores)", cons[:, :, 7] - cons[:, :, 6])
+print("producers (waves 8..13):")
+ph("entry -> V(0), V(1) written", prod[:, :, 1] - prod[:, :, 0])
+ph("at the prologue barrier", prod[:, :, 2] - prod[:, :, 1])
+ph("item stream of the K loop", prod[:, :, 3] - prod[:, :, 2])
+ph("-> end", prod[:, :, 7] - prod[:, :, 3])
+# placement: HW_ID bits (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13 (gfx950: se in 15:13 + xcc separately)
+hw = (t[:, 0, 8] & 0xFFFFFFFF).astype(np.int64)
+xcc = (t[:, 0, 8] >> 32).astype(np.int64) & 0xF
+cu = (hw >> 8) & 0xF
+sh = (hw >> 12) & 1
+se = (hw >> 13) & 0x7
+key = xcc * 10000 + se * 100 + sh * 16 + cu
+uniq, cnt = np.unique(key, return_counts=True)
+print(f"placement: {len(uniq)} distinct (xcc, se, sh, cu) ran {nt} workgroups; workgroups per CU: min {cnt.min()} max {cnt.max()}  histogram {dict(zip(*np.unique(cnt, return_counts=True)))}")
+# rounds on a CU: order by start
+per_round = {}
+for k in uniq:
+    idx = np.where(key == k)[0]
+    idx = idx[np.argsort(start[idx])]
+    for r, i in enumerate(idx):
+        per_round.setdefault(r, []).append((us(start[i] - t0), us(end[i] - t0), dur[i]))
+        if r > 0:
+            per_round.setdefault(("gap", r), []).append(us(start[i] - end[idx[r - 1]]))
+for r in sorted(k for k in per_round if isinstance(k, int)):
+    a = np.array(per_round[r])
+    g = per_round.get(("gap", r))
+    print(f"   round {r}: {len(a):4d} workgroups  start median {np.median(a[:,0]):7.2f} us  end median {np.median(a[:,1]):7.2f}  duration median {np.median(a[:,2]):6.2f}" +
+          (f"  gap after the CU's previous workgroup: median {np.median(g):5.2f} p90 {np.percentile(g,90):5.2f}" if g else ""))
+# SIMD placement of the waves of workgroup 0
+print("waves of workgroup 0 -> simd:", [int((int(t[0, w, 8]) >> 4) & 3) for w in range(WV)])

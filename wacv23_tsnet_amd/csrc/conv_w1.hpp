@@ -46,6 +46,19 @@ constexpr int w1_lds_bytes(int Cin, int npl = 2) {
     return (v > ex ? v : ex) + 2 * Cin * 4;
 }
 
+#ifdef TSNET_TOOLS
+// tools build: per-wave time stamps of one launch (OPT bit 9), read back by tsnet_w1_prof_read (conv_w1_launch.cpp); 16 slots per wave
+constexpr int kW1ProfSlots = 16, kW1ProfTiles = 1024;
+static __device__ unsigned long long g_w1_prof[kW1ProfTiles * kW1Waves * kW1ProfSlots];
+#define TSNET_W1_STAMP(slot)                                                                                                   \
+    do {                                                                                                                        \
+        if ((OPT & 512) && (threadIdx.x & 63) == 0 && blockIdx.x < kW1ProfTiles)                                                \
+            g_w1_prof[((size_t)blockIdx.x * kW1Waves + (threadIdx.x >> 6)) * kW1ProfSlots + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define TSNET_W1_STAMP(slot) do { } while (0)
+#endif
+
 // OPT bit 0: the layer zero-pads an InstanceNorm-ed input (padded pixels re-zeroed after the affine transform); bit 1: raw input, no ReLU.  Tools build (ablations,
 // compute garbage): bit 4 no producer work in the loop, bit 5 weight fragments loaded once, bit 6 A fragments read once, bit 7 no barrier
 template <int NPROD, bool AFFINE, int OPT = 0>
@@ -67,6 +80,7 @@ __device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_r
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = TSNET_UNIFORM(tid >> 6);
+    TSNET_W1_STAMP(0);
     const int pos = wave >> 1, nt = wave & 1;                        // K loop: this wave's Winograd position and 32-channel half
     const int wn0 = nt * 32;
     const int li = lane & 31, lh = lane >> 5;
@@ -199,7 +213,9 @@ __device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_r
             v_load((u + 1) / NIT, (u + 1) % NIT, (u + 1) & 1);
             v_item(u / NIT, u % NIT, (u / NIT) * STAGE, u & 1);
         }
+        TSNET_W1_STAMP(1);
         __syncthreads();                                             // (the consumers' prologue barrier)
+        TSNET_W1_STAMP(2);
         int st_wr = 2 * STAGE;
         for (int pp = 0; pp < npp; ++pp) {
             if (!(OPT & 128)) __syncthreads();                       // every read of the stage produced next has been issued
@@ -212,6 +228,7 @@ __device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_r
             }
             st_wr = st_wr == 2 * STAGE ? 0 : st_wr + STAGE;
         }
+        TSNET_W1_STAMP(3);
     } else {
         // ================= consumers (waves 0..7): the K loop =================
         TSNET_SETPRIO(2);                                            // MFMA issue ahead of the producers' VALU streams on the same SIMD
@@ -279,7 +296,9 @@ __device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_r
         };
 #pragma unroll
         for (int i = 0; i < BD - 1; ++i) load_b(i, i / 3, i % 3);
+        TSNET_W1_STAMP(1);
         __syncthreads();                                             // V(0), V(1) complete
+        TSNET_W1_STAMP(2);
         load_f(0, 0, 0); load_f(0, 2, 0);
         if (OPT & 32) load_b(BD - 1, 1, 2);
         if (OPT & 64) {
@@ -295,11 +314,13 @@ __device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_r
         }
         if (ONE_LEVEL) { tot[0] = acc[0]; tot[1] = acc[1]; }
         TSNET_SETPRIO(0);
+        TSNET_W1_STAMP(3);
     }
 
     // ---- output transform: the four positions of a pair meet through LDS
     const float unscale = a.w_unscale ? in_unscale * a.w_unscale[0] : in_unscale;
     __syncthreads();                                                 // every stage has been read
+    TSNET_W1_STAMP(4);
     float* ex = reinterpret_cast<float*>(smem_raw);                  // [position][pair 64][channel 64]
     const bool consumer = wave < 8;
     if (consumer) {
@@ -312,6 +333,7 @@ __device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_r
             }
     }
     __syncthreads();
+    TSNET_W1_STAMP(5);
     const int mq = consumer ? wave >> 1 : 0;                         // epilogue role: output row mq of the tile, channel half nt
     f32x16 out[1][1];
 #pragma unroll
@@ -323,9 +345,19 @@ __device__ __forceinline__ void w1_tile(const ConvArgs& a, unsigned char* smem_r
         out[0][0][2 * r2 + 1] = (m1 - m2) - m3;
     }
     __syncthreads();                                                 // the shared epilogue reuses the region for its reductions
+    TSNET_W1_STAMP(6);
     const int m_img = img * a.Ho * a.Wo;
     conv_epilogue<64, 4, 2, 1, 1>(a, out, smem_raw, tid, consumer ? wave : nt, n0, (size_t)img * tper + tin,
                                   [&](int l) { return m_img + (oy0 + (l >> 5)) * a.Wo + ox0 + (l & 31); }, consumer);
+    TSNET_W1_STAMP(7);
+#ifdef TSNET_TOOLS
+    if ((OPT & 512) && (threadIdx.x & 63) == 0 && blockIdx.x < kW1ProfTiles) {     // where the workgroup ran: HW_ID (CU / SE), XCC_ID
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_w1_prof[((size_t)blockIdx.x * kW1Waves + (threadIdx.x >> 6)) * kW1ProfSlots + 8] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 template <int NPROD, bool AFFINE, int OPT = 0>

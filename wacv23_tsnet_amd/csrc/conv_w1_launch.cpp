@@ -29,8 +29,10 @@ void launch_conv_w1(const ConvArgs& a, int nprod, int abl, hipStream_t s) {
     if (abl) {
 #ifdef TSNET_TOOLS
         const size_t lds = (size_t)w1_lds_bytes(a.Cin, 2);
+        if (abl == 31 && nprod == 3 && a.in_alpha) { go_w1_k<3, true, 512>(a, lds, s); return; }   // time stamps, IN + ReLU input (reflect)
         if (nprod != 3 || a.in_alpha) throw std::invalid_argument("conv(w1): ablations are built for three products on a raw input");
 #define TSNET_W1_ABL(A_) if (abl == A_) { go_w1_k<3, false, ((A_) << 4) | 2>(a, lds, s); return; }
+        if (abl == 30) { go_w1_k<3, false, 512 | 2>(a, lds, s); return; }            // time stamps (tsnet_w1_prof_read), raw input
         TSNET_W1_ABL(1) TSNET_W1_ABL(2) TSNET_W1_ABL(4) TSNET_W1_ABL(3) TSNET_W1_ABL(7) TSNET_W1_ABL(8) TSNET_W1_ABL(15) TSNET_W1_ABL(16) TSNET_W1_ABL(17)
 #undef TSNET_W1_ABL
         throw std::invalid_argument("conv(w1): this ablation is not instantiated");
@@ -44,3 +46,13 @@ void launch_conv_w1(const ConvArgs& a, int nprod, int abl, hipStream_t s) {
 }
 
 }  // namespace tsnet
+
+#ifdef TSNET_TOOLS
+// tools build: the time stamps of the last stamped launch (abl 30 / 31): [tile][wave][16] of s_memrealtime ticks (100 MHz); slot 8 = XCC_ID << 32 | HW_ID
+extern "C" int tsnet_w1_prof_read(unsigned long long* out, int ntiles) {
+    using namespace tsnet;
+    if (!out || ntiles < 1 || ntiles > kW1ProfTiles) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w1_prof), (size_t)ntiles * kW1Waves * kW1ProfSlots * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -1756,10 +1756,17 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
         // big layers), as consecutive layers of a forward do; the default re-launches one layer, whose planes stay cache-resident
         std::vector<std::unique_ptr<OpLayer>> cold;
         if (v & (1 << 21)) for (int i = 0; i < 24; ++i) cold.emplace_back(new OpLayer(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s, form));
-        ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = norm ? 64.f : 1.f; c.nprod = nprod;
+        ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = (norm & 1) ? 64.f : 1.f; c.nprod = nprod;
         c.tile = form ? 0 : (v & 4095); c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 31; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0) | ((v & (1 << 22)) ? 32 : 0);
         { const int gx = (v >> 28) & 7; c.xcd_gn = gx == 0 ? -1 : (gx == 1 ? 0 : 1 << (gx - 2)); }          // bits 28-30: 0 default, 1 linear, 2..5 grid with 1, 2, 4, 8 columns
-        if (norm) { c.alpha = al; c.beta = be; c.relu = 1; }
+        if (norm & 1) { c.alpha = al; c.beta = be; c.relu = 1; }
+        if (norm & 2) {                                              // with the InstanceNorm statistics of the output, as the forward's layers run
+            const size_t tpi = ((size_t)Ho * Wo + 63) / 64;
+            c.stat_part = mem.alloc<double>((size_t)N * tpi * Cout * 2 * sizeof(double));
+            c.fin_alpha = mem.alloc<float>((size_t)N * Cout * 4); c.fin_beta = mem.alloc<float>((size_t)N * Cout * 4);
+            c.fin_counter = mem.alloc<int>(kFinCounterInts * sizeof(int));
+            HIP_TRY(hipMemset(c.fin_counter, 0, kFinCounterInts * sizeof(int)));
+        }
         for (int i = 0; i < 2; ++i) run_conv(ctx, op.L, c);
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
