@@ -105,6 +105,7 @@ static inline void emu_split_pair(float a, float b, unsigned& hw, unsigned& lw) 
 static inline unsigned emu_bf16_rne(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16; }
 #define TSNET_CVT_PK_BF16(a, b) ((emu_bf16_rne(a) & 0xFFFFu) | (emu_bf16_rne(b) << 16))
 #define TSNET_SETPRIO(n) ((void)0)
+#define TSNET_OPAQUE_V(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define TSNET_DRAIN_VMEM() ((void)0)
 #define TSNET_WAVE_SYNC() emu::wave_sync()        // lanes are independent fibers here: a rendezvous where the hardware's lock-step is relied on

@@ -73,9 +73,10 @@ def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, n
                      scale=scale, return_output=return_output)
 
 
-def conv_w1_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, nprod=3, seed=0, scale=1.0, relu=None, return_output=False):
-    """3x3 / stride 1 / pad 1 in the Winograd F(2,3)-along-x form (conv_w1.hpp; kernel = 3): same contract as conv_h2_case"""
-    return conv_case(lib, dev, N, H, W, Cin, Cout, 3, 1, 1, reflect, norm=norm, bias=bias, seed=seed, nprod=nprod, kernel=3, scale=scale,
+def conv_w1_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, nprod=3, seed=0, scale=1.0, relu=None, return_output=False, chunk=0):
+    """3x3 / stride 1 / pad 1 in the Winograd F(2,3)-along-x form (conv_w1.hpp; kernel = 3): same contract as conv_h2_case.  chunk: tiles per
+    workgroup (1, 2, 3; 0 = the launcher's choice)"""
+    return conv_case(lib, dev, N, H, W, Cin, Cout, 3, 1, 1, reflect, norm=norm, bias=bias, seed=seed, nprod=nprod, kernel=3, tile=chunk, scale=scale,
                      relu=relu, return_output=return_output)
 
 
@@ -258,8 +259,10 @@ def warp_case(lib, dev, B, h, w, C, seed=0):
     return (nchw(out.cpu()) - ref).abs().max().item()
 
 
-def conv_split_worstcase_case(lib, dev, N, H, W, Cin, Cout, tiers=(-12, -18, -24), weights_too=True, corner=False, seed=0):
-    """Adversarial dynamic range INSIDE one image for the fp16 x 2 operand split (conv_common.hpp): 1 % of the activations sit at the
+def conv_split_worstcase_case(lib, dev, N, H, W, Cin, Cout, tiers=(-12, -18, -24), weights_too=True, corner=False, seed=0, kernel=2):
+    """kernel: 2 = the direct patch kernel (conv_h2), 3 = the Winograd-along-x kernel (conv_w1: the forward's ResnetBlock / FuseNet layers --
+    one bit less operand head-room, |V| <= 2 max|x|, and the output transform's own cancellation M1 - M2 - M3).
+    Adversarial dynamic range INSIDE one image for the fp16 x 2 operand split (conv_common.hpp): 1 % of the activations sit at the
     image's maximum, the rest in equal shares at amax * 2^t for t in `tiers` (the operand scale is derived from amax alone, so the bulk
     lands deep in fp16's lower range, the last tier in its subnormals); the weights likewise.  corner=True confines the amax values to the
     top-left 8 x 8 pixels, so most outputs are sums of tiny terms only.
@@ -298,7 +301,7 @@ def conv_split_worstcase_case(lib, dev, N, H, W, Cin, Cout, tiers=(-12, -18, -24
     bound = float(x.abs().max()) * 1.0001
     xd, wd = nhwc(x).to(dev), w.to(dev)
     y = torch.full((N, H, W, Cout), float("nan"), device=dev)
-    rc = lib.tsnet_op_conv2d(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), None, Cout, 3, 1, 1, 1, None, None, 0, bound, 3, 2, 0, y.data_ptr(), None)
+    rc = lib.tsnet_op_conv2d(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), None, Cout, 3, 1, 1, 1, None, None, 0, bound, 3, kernel, 0, y.data_ptr(), None)
     assert rc == 0, lib.tsnet_op_last_error().decode()
     _sync(dev)
     yc = nchw(y.cpu()).double()
@@ -310,3 +313,38 @@ def conv_split_worstcase_case(lib, dev, N, H, W, Cin, Cout, tiers=(-12, -18, -24
     e_quiet = (yc - ref)[quiet].abs().max().item() if quiet.any() else 0.0
     r_quiet = ref[quiet].abs().max().item() if quiet.any() else 0.0
     return e_h2, e_32, e_quiet, r_quiet, float(x.abs().max()), float(w.abs().max())
+
+
+def conv_structured_filter_case(lib, dev, N, H, W, Cin, Cout, kind, kernel=3, norm=True, seed=0):
+    """STRUCTURED 3 x 3 filters, as a trained checkpoint holds them (the op tests' and the seed sweep's weights are i.i.d. N(0, 0.02) / uniform):
+    every (output, input, tap row) draws one amplitude a and the three taps along x follow a fixed profile --
+      "smooth"    a * (2^-8, 1, 2^-8):  g0 = g2, |g1| >> |g0|: the Winograd filters U1 = (g0+g1+g2)/2 and U2 = (g0-g1+g2)/2 are +-g1/2 to eight bits
+                  and the small taps live in their difference;
+      "binomial"  a * (1/2, 1, 1/2):    a low-pass filter, g0 = g2;
+      "sobel"     a * (-1, 0, 1):       antisymmetric: g0 + g2 = 0 and g1 = 0, so U1 = U2 = 0 and the whole output comes from M0 = V0 g0 and
+                  M3 = V3 g2;
+      "edge"      a * (1, -2, 1):       second difference: U1 = 0, U2 = 2 a -- out[2j+1] = M1 - M2 - M3 is all M2.
+    Input: relu(x * alpha + beta) with the fused transform when `norm` (the ResnetBlock's second convolution), zero-free uniform data
+    otherwise.  Returns (max|y - ref64|, max|conv_fp32 - ref64|, max|ref64|): the exact-fp32 chain (torch fp32 conv on the CPU) is the yardstick."""
+    prof = {"smooth": (2.0 ** -8, 1.0, 2.0 ** -8), "binomial": (0.5, 1.0, 0.5), "sobel": (-1.0, 0.0, 1.0), "edge": (1.0, -2.0, 1.0)}[kind]
+    a = _rand(seed, "wa", (Cout, Cin, 3, 1)) * (2.0 / (Cin * 9) ** 0.5)
+    w = (a * torch.tensor(prof, dtype=torch.float32).view(1, 1, 1, 3)).contiguous()
+    x = _rand(seed, "x", (N, Cin, H, W))
+    xin, al, be = x, None, None
+    if norm:
+        al = _rand(seed, "al", (N, Cin), 0.5, 1.5)
+        be = _rand(seed, "be", (N, Cin), -0.3, 0.3)
+        xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
+    xp = F.pad(xin, (1,) * 4, mode="reflect")
+    ref = F.conv2d(xp.double(), w.double())
+    y32 = F.conv2d(xp, w)
+    bound = float(xin.abs().max()) * 1.0001
+    xd, wd = nhwc(x).to(dev), w.to(dev)
+    ald = al.contiguous().to(dev) if norm else None
+    bed = be.contiguous().to(dev) if norm else None
+    y = torch.full((N, H, W, Cout), float("nan"), device=dev)
+    rc = lib.tsnet_op_conv2d(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), None, Cout, 3, 1, 1, 1, _p(ald), _p(bed), int(norm), bound, 3, kernel, 0, y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    yc = nchw(y.cpu()).double()
+    return (yc - ref).abs().max().item(), (y32.double() - ref).abs().max().item(), ref.abs().max().item()

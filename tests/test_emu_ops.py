@@ -185,11 +185,43 @@ def test_conv_split_worst_case_dynamic_range(emu_lib):
     assert e <= 3.0 * e32
 
 
+def test_conv_w1_chunks_of_tiles_bitwise(emu_lib):
+    """A conv_w1 workgroup runs a chunk of 1, 2 or 3 consecutive spatial tiles of one channel tile, the next tile's V(0), V(1) produced under the current tile's last two
+    periods and the epilogue of a tile with a successor confined to one stage (two exchange passes).  Same chains per output element: the
+    chunk size never changes a bit.  Cases: chunks that cross from one image into the next under a fused InstanceNorm (the second transform
+    table), zero padding (the per-tile padding masks), a raw input, an odd slab count (the all-zero last slab), a second channel tile."""
+    import torch
+    for args, kw, chunks in (((6, 16, 32, 96, 128, True), dict(norm=True), (1, 3)), ((4, 16, 32, 96, 128, False), dict(norm=True), (1, 2)),
+                             ((6, 16, 32, 112, 128, True), dict(), (1, 3)), ((4, 16, 32, 128, 64, False), dict(norm=True, relu=False), (1, 2))):
+        ys = [oc.conv_w1_case(emu_lib, "cpu", *args, chunk=c, return_output=True, **kw) for c in chunks]
+        assert all(torch.equal(ys[0], y) for y in ys[1:]), (args, kw)
+        assert oc.conv_w1_case(emu_lib, "cpu", *args, chunk=chunks[-1], **kw) < REL
+
+
+def test_conv_w1_worst_case_range_and_structured_filters(emu_lib):
+    """The kernel that runs 83 % of the forward's FLOPs (conv_w1, tsnet_op_conv2d(kernel = 3)) under the adversarial dynamic range of the test
+    above -- it has one bit less operand head-room than the direct kernel and its output transform subtracts -- and on STRUCTURED filters
+    (smooth g0 = g2 with |g1| >> |g0|, binomial, Sobel-like antisymmetric, second difference: what a trained checkpoint holds, where the
+    Winograd filters U1 / U2 differ most from the taps).  Same tiers and gates as the direct kernel: <= 3 x the exact-fp32 chain, >= 19 bits
+    on quiet outputs.  GPU tier: tests/test_gpu_ops.py at 512 -> 512."""
+    for corner in (False, True):
+        for wt in (True, False):
+            e, e32, eq, rq, _, _ = oc.conv_split_worstcase_case(emu_lib, "cpu", 1, 16, 32, 128, 64, corner=corner, weights_too=wt, kernel=3)
+            assert e <= 3.0 * e32, (corner, wt, e, e32)
+            assert eq <= rq * 2.0 ** -19, (corner, wt, eq, rq)
+    e, e32, _, _, _, _ = oc.conv_split_worstcase_case(emu_lib, "cpu", 1, 16, 32, 128, 64, tiers=(-6, -9, -12), kernel=3)
+    assert e <= 3.0 * e32
+    for kind in ("smooth", "binomial", "sobel", "edge"):
+        for norm in (True, False):
+            e, e32, rmax = oc.conv_structured_filter_case(emu_lib, "cpu", 1, 8, 32, 128, 64, kind, kernel=3, norm=norm)
+            assert e <= 3.0 * e32 and e <= REL * rmax, (kind, norm, e, e32, rmax)
+
+
 def test_conv_w1_winograd_x_form(emu_lib):
     """3x3 / stride 1 / pad 1 in the Winograd F(2,3)-along-x form (conv_w1.hpp, tsnet_op_conv2d(kernel = 3)): reflection and zero padding,
     with and without the fused IN + ReLU, one / three / five slabs (the odd counts end in an all-zero slab of the last period), two images
     and several tiles, a second 64-channel tile column, bf16 operands.  Accuracy: the direct kernel's class (the transform precedes the
-    split; tools/probes/winograd_probe.py).  The forward does not run this form -- DESIGN.md section 4.4 has the measurements."""
+    split; tools/probes/winograd_probe.py).  The forward runs its ResnetBlock / FuseNet / first up-convolution layers in this form."""
     assert oc.conv_w1_case(emu_lib, "cpu", 1, 4, 32, 16, 64, True) < REL
     assert oc.conv_w1_case(emu_lib, "cpu", 2, 8, 64, 48, 96, False, norm=True) < REL
     assert oc.conv_w1_case(emu_lib, "cpu", 1, 4, 32, 80, 64, True, norm=True, relu=False) < REL

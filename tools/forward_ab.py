@@ -1,0 +1,40 @@
+"""GPU box: same-box, same-process A/B of the whole forward under a tools-build knob (tsnet_tools_set; the product library has no knobs).
+Interleaved rounds, medians.  knob 0 = largest conv_w1 chunk the launcher may choose (3 = product behaviour, 1 = one tile per workgroup).
+    python tools/forward_ab.py [--batch 4] [--n-blocks 0] [--rounds 7] [--iters 20] [--knob 0] [--values 3,1]"""
+import argparse, os, statistics, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wacv23_tsnet_amd import _lib, synth
+from wacv23_tsnet_amd.engine import TSNetEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=4)
+ap.add_argument("--n-blocks", type=int, default=0)
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--knob", type=int, default=0)
+ap.add_argument("--values", default="3,1")
+a = ap.parse_args()
+lib = _lib.load_tools()
+vals = [int(v) for v in a.values.split(",")]
+eng = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=3, height=256, width=256, max_batch=a.batch, lib=lib)
+eng.load_state_dict(synth.state_dict(eng.param_shapes(), seed=0)); eng.finalize("cuda")
+inp = synth.inputs(3, 2, a.batch, 256, 256, seed=1)
+si, sl, sb, tl, tb = [[t.cuda() for t in x] if isinstance(x, list) else x.cuda() for x in inp]
+step = lambda: eng.forward(si, sl, sb, tl, tb)[0]
+outs, res = {}, {v: [] for v in vals}
+for r in range(a.rounds + 1):
+    for v in vals:
+        lib.tsnet_tools_set(a.knob, v)
+        for _ in range(3):
+            o = step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(a.iters):
+            o = step()
+        torch.cuda.synchronize()
+        if r:                                   # round 0 warms up
+            res[v].append((time.perf_counter() - t0) / a.iters * 1e3)
+        outs[v] = o.clone()
+for v in vals:
+    t = res[v]
+    print(f"knob {a.knob} = {v}: median {statistics.median(t):.3f} ms  (min {min(t):.3f} max {max(t):.3f})  {a.batch / statistics.median(t) * 1e3:.1f} frames/s   same bits as value {vals[0]}: {torch.equal(outs[v], outs[vals[0]])}")

@@ -38,7 +38,7 @@ def run(name, shape, variants, norms=(0, 1), iters=8):
     print(f"{name}: M={N*Ho*Wo} N={Cout} K={Cin*k*k} {flops/1e9:.1f} GFLOP")
     for (vn, nrm), t in res.items():
         med = statistics.median(t)
-        print(f"   {vn:28s} {'IN+ReLU' if nrm else 'raw    '}  {med*1e3:8.1f} us  {flops/med/1e9:7.1f} TF   (min {min(t)*1e3:.1f} max {max(t)*1e3:.1f})", flush=True)
+        print(f"   {vn:28s} {'IN+ReLU' if nrm & 1 else 'raw    '}{'+stats' if nrm & 2 else ''}  {med*1e3:8.1f} us  {flops/med/1e9:7.1f} TF   (min {min(t)*1e3:.1f} max {max(t)*1e3:.1f})", flush=True)
 
 
 SEL = sys.argv[2] if len(sys.argv) > 2 else "all"
@@ -85,6 +85,12 @@ if SEL == "w1":         # Winograd F(2,3) along x (conv_w1.hpp) against the dire
     run("dec_up0 (512->256 @64^2)", (4, 64, 64, 512, 256, 3, 1, 1, 1), [("4x128 direct", code(128)), W1], norms=(0,))
     run("dec_up1 (256->128 @128^2)", (4, 128, 128, 256, 128, 3, 1, 1, 1), [("the layer's own", code(0)), W1], norms=(0,))
     run("dec_up2 (128->64 @256^2)", (4, 256, 256, 128, 64, 3, 1, 1, 1), [("the layer's own", code(0)), W1], norms=(0,))
+    sys.exit(0)
+if SEL == "w1c":        # conv_w1: tiles per workgroup (tile code 1, 2, 3; 0 = the launcher's choice), with the output statistics (norm bit 1) as in the forward
+    for nm, shp in (("res (B=4: 12 images)", RES), ("res (B=8: 24 images)", (24, 32, 32, 512, 512, 3, 1, 1, 1)), ("fuse_c2 (1024->1024)", (12, 32, 32, 1024, 1024, 3, 1, 1, 1)),
+                    ("fuse_c1_src (512->1024)", (12, 32, 32, 512, 1024, 3, 1, 1, 1)), ("fuse_c1_tar (4 images)", (4, 32, 32, 512, 1024, 3, 1, 1, 1)),
+                    ("dec_up0 (512->256 @64^2)", (4, 64, 64, 512, 256, 3, 1, 1, 1)), ("dec_res (B=8: 8 images)", (8, 32, 32, 512, 512, 3, 1, 1, 1))):
+        run(nm, shp, [(f"w1 chunk {c}" if c else "w1 launcher's choice", code(c, w1=True)) for c in (1, 2, 3, 0)], norms=(2, 3), iters=18)
     sys.exit(0)
 if SEL == "chain":      # slabs per accumulation chain: 1, 2 (product), 4; and the ablations of the 4 x 64 tile
     run("res", RES, [("4x64 chain 2 (product)", code(64)), ("4x64 chain 1", code(64, opt=2)), ("4x64 chain 4", code(64, opt=4)),

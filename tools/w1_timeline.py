@@ -1,9 +1,10 @@
 """GPU box: where a conv_w1 workgroup's time goes (tools build).  One stamped launch (abl 30: raw input, 31: IN + ReLU input; statistics
 on) of the ResnetBlock layer; every wave records s_memrealtime (100 MHz) at: 0 entry, 1 before / 2 after the prologue barrier (V(0), V(1)
-complete), 3 end of the K loop (consumers) / of the item stream (producers), 4 after the barrier behind it, 5 after the exchange,
-6 after the output transform, 7 end.  Prints the median / p10 / p90 of each phase over the workgroups, per dispatch round, and the
+complete), then per tile of the workgroup's chunk the end of its K loop and of its epilogue.  Prints the median / p10 / p90 of each phase over the workgroups, per dispatch round, and the
 per-CU occupancy picture (how many workgroups a CU ran, when each started relative to the launch's first stamp).
-usage: w1_timeline.py [N images = 12] [norm = 0|1] [Cin = 512] [Cout = 512] [H = 32]"""
+Stamps (16 slots per wave): 0 entry, 1 before / 2 after the prologue barrier, 3 + 3 j end of tile j's K loop (producers: of its item stream),
+5 + 3 j end of tile j's epilogue, 14 end of the workgroup, 15 XCC_ID << 32 | HW_ID.
+usage: w1_timeline.py [N images = 12] [norm = 0|1] [Cin = 512] [Cout = 512] [H = 32] [chunk = 0 (the launcher's choice) | 1 | 2 | 3]"""
 import ctypes as C, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,27 +18,31 @@ Cin = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 Cout = int(sys.argv[4]) if len(sys.argv) > 4 else 512
 H = int(sys.argv[5]) if len(sys.argv) > 5 else 32
 W = H
+chunk = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 abl = 31 if norm else 30
-variant = 32768 | (abl << 16)
+variant = 32768 | (abl << 16) | chunk
 ms = C.c_float()
 rc = lib.tsnet_bench_conv(N, H, W, Cin, Cout, 3, 1, 1, 1, (1 if norm else 0) | 2, variant, 4, C.byref(ms), None)
 if rc != 0:
     raise SystemExit("bench_conv: " + lib.tsnet_op_last_error().decode())
 tiles = N * (H // 4) * (W // 32) * (Cout // 64)
-nt = min(tiles, 1024)
 WV, SL = 14, 16
-buf = np.zeros(nt * WV * SL, dtype=np.uint64)
+buf = np.zeros(1024 * WV * SL, dtype=np.uint64)
 lib.tsnet_w1_prof_read.argtypes = [C.c_void_p, C.c_int]
-rc = lib.tsnet_w1_prof_read(buf.ctypes.data_as(C.c_void_p), nt)
+rc = lib.tsnet_w1_prof_read(buf.ctypes.data_as(C.c_void_p), 1024)
 if rc != 0:
     raise SystemExit("prof_read %d" % rc)
-t = buf.reshape(nt, WV, SL).astype(np.int64)
+t = buf.reshape(1024, WV, SL).astype(np.int64)
+# how many tiles a workgroup ran: the last non-zero per-tile stamp of workgroup 0 (stamps are overwritten by every launch: same everywhere)
+c = max(1, sum(1 for j in range(3) if t[0, 0, 5 + 3 * j] > 0 and t[0, 0, 5 + 3 * j] >= t[0, 0, 0]))
+nwg = min(tiles // c, 1024)
+t = t[:nwg]
 t0 = t[:, :, 0].min()
 us = lambda x: x / 100.0            # 100 MHz ticks -> us
-print(f"conv_w1 N={N} {H}x{W} {Cin}->{Cout} norm={norm} stats=1: {ms.value*1e3:.1f} us per launch (4 launches timed), {tiles} tiles ({nt} stamped)")
+print(f"conv_w1 N={N} {H}x{W} {Cin}->{Cout} norm={norm} stats=1 chunk={c}: {ms.value*1e3:.1f} us per launch (4 launches timed), {tiles} tiles in {tiles // c} workgroups ({nwg} stamped)")
 cons, prod = t[:, :8, :], t[:, 8:, :]
 start = t[:, :, 0].min(axis=1)
-end = t[:, :, 7].max(axis=1)
+end = t[:, :, 14].max(axis=1)
 dur = us(end - start)
 print(f"workgroup duration: median {np.median(dur):.2f} us  p10 {np.percentile(dur,10):.2f}  p90 {np.percentile(dur,90):.2f}; launch span (first stamp -> last stamp) {us(end.max()-t0):.1f} us")
 def ph(name, a):
@@ -46,26 +51,24 @@ def ph(name, a):
 print("consumers (waves 0..7):")
 ph("entry -> prologue barrier reached (table, first weights)", cons[:, :, 1] - cons[:, :, 0])
 ph("waiting at the prologue barrier (V(0), V(1) in production)", cons[:, :, 2] - cons[:, :, 1])
-ph("K loop", cons[:, :, 3] - cons[:, :, 2])
-ph("K loop end -> barrier passed", cons[:, :, 4] - cons[:, :, 3])
-ph("exchange write + barrier", cons[:, :, 5] - cons[:, :, 4])
-ph("output transform + barrier", cons[:, :, 6] - cons[:, :, 5])
-ph("conv_epilogue (bias, statistics, hand-off, stores)", cons[:, :, 7] - cons[:, :, 6])
+prev = cons[:, :, 2]
+for j in range(c):
+    ph(f"tile {j}: K loop", cons[:, :, 3 + 3 * j] - prev)
+    ph(f"tile {j}: epilogue (exchange, transform, statistics, stores)", cons[:, :, 5 + 3 * j] - cons[:, :, 3 + 3 * j])
+    prev = cons[:, :, 5 + 3 * j]
 print("producers (waves 8..13):")
 ph("entry -> V(0), V(1) written", prod[:, :, 1] - prod[:, :, 0])
 ph("at the prologue barrier", prod[:, :, 2] - prod[:, :, 1])
-ph("item stream of the K loop", prod[:, :, 3] - prod[:, :, 2])
-ph("-> end", prod[:, :, 7] - prod[:, :, 3])
-# placement: HW_ID bits (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13 (gfx950: se in 15:13 + xcc separately)
-hw = (t[:, 0, 8] & 0xFFFFFFFF).astype(np.int64)
-xcc = (t[:, 0, 8] >> 32).astype(np.int64) & 0xF
-cu = (hw >> 8) & 0xF
-sh = (hw >> 12) & 1
-se = (hw >> 13) & 0x7
-key = xcc * 10000 + se * 100 + sh * 16 + cu
+prev = prod[:, :, 2]
+for j in range(c):
+    ph(f"tile {j}: item stream", prod[:, :, 3 + 3 * j] - prev)
+    ph(f"tile {j}: epilogue barriers", prod[:, :, 5 + 3 * j] - prod[:, :, 3 + 3 * j])
+    prev = prod[:, :, 5 + 3 * j]
+hw = (t[:, 0, 15] & 0xFFFFFFFF).astype(np.int64)
+xcc = (t[:, 0, 15] >> 32).astype(np.int64) & 0xF
+key = xcc * 10000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xF)
 uniq, cnt = np.unique(key, return_counts=True)
-print(f"placement: {len(uniq)} distinct (xcc, se, sh, cu) ran {nt} workgroups; workgroups per CU: min {cnt.min()} max {cnt.max()}  histogram {dict(zip(*np.unique(cnt, return_counts=True)))}")
-# rounds on a CU: order by start
+print(f"placement: {len(uniq)} distinct (xcc, se, sh, cu) ran {nwg} workgroups; workgroups per CU: min {cnt.min()} max {cnt.max()}")
 per_round = {}
 for k in uniq:
     idx = np.where(key == k)[0]
@@ -79,5 +82,3 @@ for r in sorted(k for k in per_round if isinstance(k, int)):
     g = per_round.get(("gap", r))
     print(f"   round {r}: {len(a):4d} workgroups  start median {np.median(a[:,0]):7.2f} us  end median {np.median(a[:,1]):7.2f}  duration median {np.median(a[:,2]):6.2f}" +
           (f"  gap after the CU's previous workgroup: median {np.median(g):5.2f} p90 {np.percentile(g,90):5.2f}" if g else ""))
-# SIMD placement of the waves of workgroup 0
-print("waves of workgroup 0 -> simd:", [int((int(t[0, w, 8]) >> 4) & 3) for w in range(WV)])

@@ -66,6 +66,11 @@ typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef TSNET_SETPRIO
 #define TSNET_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
+// The compiler may not assume it knows x beyond this point: what is computed from x stays where the source puts it (an epilogue inside a
+// tile loop: hoisted out of the loop, its lane-derived addresses would live -- and spill -- across the K loop).
+#ifndef TSNET_OPAQUE_V
+#define TSNET_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
 
 // XCD-aware block -> work item: consecutive items stay on one XCD (its L2 then holds their shared operands).  Bijective for any count.
 __device__ __forceinline__ int xcd_item(int bid, int nitems) {
@@ -150,6 +155,9 @@ struct ConvArgs {
     // bf16 STORAGE (tsnet_cfg.operand_mode = 2, bf16-operand kernels only): x / y hold bf16 instead of fp32 -- same shapes, half the bytes.
     // The statistics still come from the fp32 accumulators; the consumer widens exactly (bf16 -> fp32 is a shift).
     int x_bf16, y_bf16;
+    // conv_w1 only: tiles per workgroup (a chunk of consecutive tiles, the next tile's first periods produced under the current one's last:
+    // conv_w1.hpp), and whether the LDS holds two transform tables (a chunk may then cross from one image into the next)
+    int w1_chunk, w1_tab2;
 };
 
 // eight consecutive bf16 channels (one 16-byte vector) -> two float4, exactly
@@ -246,7 +254,9 @@ __device__ __forceinline__ void transform_octet(const F4 (&sx)[2], const float* 
 // ---------------------------------------------------------------------------------------------------------------
 // Shared epilogue: bias, optional per-pixel addend, fp64 InstanceNorm partial sums of the tile (fixed order: deterministic), fp32 store (last).
 // m_of(l) maps the local row l of the tile to the output position m (or -1: a row past the end of the image).
-template <int BN, int WARPS_M, int WARPS_N, int MT, int NTL, typename MOf>
+// STAT_WAVE: the wave that reduces the tile's statistics partials and hands them off (BN <= 64: one wave does it alone).  conv_w1 names a
+// producer wave -- idle in the epilogue -- so that no MFMA wave waits for the store drain and the arrival counter's round trip.
+template <int BN, int WARPS_M, int WARPS_N, int MT, int NTL, int STAT_WAVE = 0, typename MOf>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[MT][NTL], unsigned char* smem_raw, int tid, int wave, int n0,
                                               size_t stat_tile, MOf m_of, const bool active = true) {
     constexpr int WM = MT * 32, WN = NTL * 32;
@@ -296,11 +306,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
             }
         }
         __syncthreads();
-        if (tid < BN && n0 + tid < a.Cout) {
+        const int stid = tid - 64 * STAT_WAVE;                   // the reducing threads count from the statistics wave
+        if (stid >= 0 && stid < BN && n0 + stid < a.Cout) {
             double s = 0.0, q = 0.0;
 #pragma unroll
-            for (int wmi = 0; wmi < WARPS_M; ++wmi) { s += red[((size_t)wmi * BN + tid) * 2]; q += red[((size_t)wmi * BN + tid) * 2 + 1]; }
-            double* o = a.stat_part + (stat_tile * a.Cout + n0 + tid) * 2;
+            for (int wmi = 0; wmi < WARPS_M; ++wmi) { s += red[((size_t)wmi * BN + stid) * 2]; q += red[((size_t)wmi * BN + stid) * 2 + 1]; }
+            double* o = a.stat_part + (stat_tile * a.Cout + n0 + stid) * 2;
             if (a.fin_counter) {            // device-scope write-through: another XCD's workgroup may read them
                 __hip_atomic_store(o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(o + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -318,10 +329,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
             const int img = (int)(stat_tile / (size_t)S);
             int* counter = a.fin_counter + (size_t)img * ((a.Npad + 31) / 32) + n0 / 32;   // 32 = narrowest tile
             auto finalize = [&]() __attribute__((always_inline)) {
-                if (tid < BN && n0 + tid < a.Cout) {
+                if (stid >= 0 && stid < BN && n0 + stid < a.Cout) {
                     double gs[4] = {0, 0, 0, 0}, gq[4] = {0, 0, 0, 0};
                     for (int t = 0; t < S; ++t) {
-                        const double* p = a.stat_part + (((size_t)img * S + t) * a.Cout + n0 + tid) * 2;
+                        const double* p = a.stat_part + (((size_t)img * S + t) * a.Cout + n0 + stid) * 2;
                         gs[t & 3] += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         gq[t & 3] += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -331,16 +342,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
                     double var = sq / hw - mean * mean;
                     if (var < 0) var = 0;
                     const float al = 1.0f / sqrtf((float)var + a.fin_eps);
-                    a.fin_alpha[(size_t)img * a.Cout + n0 + tid] = al;
-                    a.fin_beta[(size_t)img * a.Cout + n0 + tid] = -((float)mean) * al;
+                    a.fin_alpha[(size_t)img * a.Cout + n0 + stid] = al;
+                    a.fin_beta[(size_t)img * a.Cout + n0 + stid] = -((float)mean) * al;
                 }
-                if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                if (stid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
             };
             if (BN <= 64) {
                 // One wave stored every partial of this tile (tid < BN): it drains its own stores, counts the workgroup and -- if it is the
                 // last to arrive -- finalises, all in program order and WITHOUT a workgroup barrier; the other waves go straight on to their
                 // output stores.  (On a CU that one workgroup owns -- conv_w1 -- nothing else hides the counter's round trip.)
-                if (tid < 64) {
+                if (stid >= 0 && stid < 64) {
                     TSNET_DRAIN_VMEM();
                     float arrived = 0.f;
                     if (lane == 0) arrived = (float)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -352,7 +363,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
                 int* flag = reinterpret_cast<int*>(smem_raw + 8192);
                 TSNET_DRAIN_VMEM();
                 __syncthreads();
-                if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (stid == 0) *flag = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
                 if (*flag == S - 1) finalize();
             }

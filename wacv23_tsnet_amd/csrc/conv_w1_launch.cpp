@@ -11,12 +11,16 @@ namespace {
 template <int NPROD, bool AFFINE, int OPT>
 void go_w1_k(const ConvArgs& a, size_t lds, hipStream_t s) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(conv_w1_kernel<NPROD, AFFINE, OPT>), lds);
-    hipLaunchKernelGGL((conv_w1_kernel<NPROD, AFFINE, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(64 * kW1Waves), lds, s, a);
+    const int c = a.w1_chunk > 1 ? a.w1_chunk : 1;
+    if (c > 1 && (a.tiles_m % ((a.xcd_gn > 0 ? 8 / a.xcd_gn : 8) * c) || (a.xcd_gn > 0 && a.tiles_n % a.xcd_gn)))
+        throw std::invalid_argument("conv(w1): the chunk size must divide every XCD's rows of the tile matrix");
+    hipLaunchKernelGGL((conv_w1_kernel<NPROD, AFFINE, OPT>), dim3(a.tiles_m * a.tiles_n / c), dim3(64 * kW1Waves), lds, s, a);
 }
 
 template <int NPROD>
 void go_w1(const ConvArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)w1_lds_bytes(a.Cin, NPROD == 1 ? 1 : 2);
+    const size_t lds = (size_t)w1_lds_bytes(a.Cin, NPROD == 1 ? 1 : 2, a.w1_tab2 ? 2 : 1);
+    if (NPROD == 1 && a.w1_chunk > 1) throw std::invalid_argument("conv(w1): chunks of several tiles need the two-plane stages");
     if (!a.in_alpha && !a.in_relu) go_w1_k<NPROD, false, 2>(a, lds, s);
     else if (!a.in_alpha) go_w1_k<NPROD, false, 0>(a, lds, s);
     else if (a.reflect) go_w1_k<NPROD, true, 0>(a, lds, s);
@@ -28,7 +32,7 @@ void go_w1(const ConvArgs& a, hipStream_t s) {
 void launch_conv_w1(const ConvArgs& a, int nprod, int abl, hipStream_t s) {
     if (abl) {
 #ifdef TSNET_TOOLS
-        const size_t lds = (size_t)w1_lds_bytes(a.Cin, 2);
+        const size_t lds = (size_t)w1_lds_bytes(a.Cin, 2, a.w1_tab2 ? 2 : 1);
         if (abl == 31 && nprod == 3 && a.in_alpha) { go_w1_k<3, true, 512>(a, lds, s); return; }   // time stamps, IN + ReLU input (reflect)
         if (nprod != 3 || a.in_alpha) throw std::invalid_argument("conv(w1): ablations are built for three products on a raw input");
 #define TSNET_W1_ABL(A_) if (abl == A_) { go_w1_k<3, false, ((A_) << 4) | 2>(a, lds, s); return; }

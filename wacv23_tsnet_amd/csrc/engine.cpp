@@ -64,6 +64,9 @@ std::string g_create_error;
         }                                                                                           \
     } while (0)
 
+#ifdef TSNET_TOOLS
+int g_tools_knob[8] = {3, 0, 0, 0, 0, 0, 0, 0};     // tools build only (tsnet_tools_set): [0] largest conv_w1 chunk the launcher may choose
+#endif
 struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
 struct WeightError : std::runtime_error { using std::runtime_error::runtime_error; };
 
@@ -216,10 +219,13 @@ inline int h2_scale_log2(float bound) {
 // layer and the geometry alone, never on the batch (a sample's result is the same bits in any batch of >= 2 frames; B = 1: see run_conv).
 enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3, K_W1 = 4 };
 // a layer packed in the Winograd-along-x form runs conv_w1 and nothing else: 3 x 3 / stride 1 / pad 1 on frames of whole 4 x 32 tiles
+inline size_t w1_lds_bytes_host(int Cin, int tables) {       // conv_w1.hpp w1_lds_bytes for the two-plane stages
+    return 3 * (size_t)(2 * (4 * 2 * 2 * (96 * 16 + 64) + 32)) + (size_t)tables * 2 * ((Cin + 31) / 32 * 32) * 4;
+}
 inline bool w1_eligible(const ConvLayer& L, int H, int W) {
     // (the three V stages + the transform table of 2 Cin floats must fit the CU's 160 KiB beside the epilogue's 64 B of static LDS)
     return L.ks == 3 && L.stride == 1 && L.pad == 1 && L.cin_pad >= 16 && (L.cin_pad & 15) == 0 && H >= 4 && W >= 32 && H % kPatchRows == 0 && W % kPatchCols == 0 &&
-           3 * (size_t)(2 * (4 * 2 * 2 * (96 * 16 + 64) + 32)) + (size_t)2 * L.cin_pad * 4 + 256 <= 160 * 1024;
+           w1_lds_bytes_host(L.cin_pad, 1) + 256 <= 160 * 1024;
 }
 // eligible_only: what the layer CAN run on (an explicit request, op tests / tools); otherwise what the forward runs it on
 inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool transform, int rows = kPatchRows, bool eligible_only = false, bool bf16 = false) {
@@ -302,6 +308,29 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
                 gn = 0;
             }
             g.xcd_gn = gn;
+            // Tiles per workgroup (conv_w1.hpp): chunks of 3 or 2 consecutive spatial tiles of one channel tile -- the prologue of every tile
+            // but a chunk's first disappears under its predecessor's last two periods.  Every XCD owns whole rows of the tile matrix (or its
+            // cell of the XCD grid) and the chunk size must divide their count.  A chunk that crosses into the next image needs the second
+            // transform table in LDS (it fits up to 512 input channels; a raw input has no table); without it chunks stay inside an image.
+            // Three periods per tile at least (the fetch stream runs one item past the next tile's V(1)).  Chosen where the chunks fill the
+            // 256 CUs in whole rounds; c.tile = 1, 2, 3 forces a size (op tests, tools).
+            {
+                const int n = g.tiles_m * g.tiles_n, npp = ((g.Cin >> 4) + 1) / 2;
+                const int rows = gn ? g.tiles_m / (8 / gn) : (g.tiles_m % 8 ? 0 : g.tiles_m / 8);
+                const bool tab2 = !c.alpha || w1_lds_bytes_host(g.Cin, 2) + 256 <= 160 * 1024;
+                auto fits = [&](int cc) { return cc == 1 || (c.nprod != 1 && npp >= 3 && rows > 0 && rows % cc == 0 && (tab2 || g.tpi % cc == 0)); };
+                int cc = 1;
+                if (c.tile >= 1 && c.tile <= 3) {
+                    if (!fits(c.tile)) throw ArgError("conv(w1): this chunk size does not fit the layer");
+                    cc = c.tile;
+                } else {
+                    for (int t : {3, 2}) if (fits(t) && n % (256 * t) == 0) { cc = t; break; }
+                }
+#ifdef TSNET_TOOLS
+                if (!c.tile && cc > g_tools_knob[0]) cc = 1;          // tools/forward_ab.py: the same forward with and without chunks, one process
+#endif
+                g.w1_chunk = cc; g.w1_tab2 = (c.alpha && tab2 && cc > 1) ? 1 : 0;
+            }
             launch_conv_w1(g, c.nprod, c.abl, ctx.stream);
             ++g_launch_counters[0];
             if (c.tclass == TSNET_T_CONV_RES) g_launch_counters[3] = 4064 + 30000;      // 4 x 32 pixels x 64 channels, Winograd form
@@ -1423,7 +1452,7 @@ int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w
     Ctx ctx; ctx.stream = s;
     OpLayer op(w_oihw, bias, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s, kernel == 3 ? 1 : 0);     // kernel 3: Winograd-along-x form (conv_w1.hpp)
     ConvCall c; c.x = x; c.alpha = in_alpha; c.beta = in_beta; c.relu = in_relu; c.bound = bound; c.N = N; c.H = H; c.W = W; c.y = y;
-    c.nprod = nprod; c.kernel = kernel == 3 ? 0 : kernel; c.tile = kernel == 3 ? 0 : tile;
+    c.nprod = nprod; c.kernel = kernel == 3 ? 0 : kernel; c.tile = tile;       // kernel 3: tile = tiles per workgroup (0 = the launcher's choice)
     run_conv(ctx, op.L, c);
     HIP_TRY(hipStreamSynchronize(s));
     OP_END
@@ -1757,7 +1786,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
         std::vector<std::unique_ptr<OpLayer>> cold;
         if (v & (1 << 21)) for (int i = 0; i < 24; ++i) cold.emplace_back(new OpLayer(hbuf.data(), nullptr, Cin, Cout, ksize, stride, pad, pad_mode, nprod, s, form));
         ConvCall c; c.x = x; c.N = N; c.H = H; c.W = W; c.y = y; c.bound = (norm & 1) ? 64.f : 1.f; c.nprod = nprod;
-        c.tile = form ? 0 : (v & 4095); c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 31; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0) | ((v & (1 << 22)) ? 32 : 0);
+        c.tile = v & 4095;          /* Winograd form: tiles per workgroup (0 = the launcher's choice) */ c.kernel = (v & 4096) ? 1 : ((v & 16384) ? 2 : 0); c.abl = (v >> 16) & 31; c.opt = ((v >> 24) & 15) | ((v & (1 << 23)) ? 16 : 0) | ((v & (1 << 22)) ? 32 : 0);
         { const int gx = (v >> 28) & 7; c.xcd_gn = gx == 0 ? -1 : (gx == 1 ? 0 : 1 << (gx - 2)); }          // bits 28-30: 0 default, 1 linear, 2..5 grid with 1, 2, 4, 8 columns
         if (norm & 1) { c.alpha = al; c.beta = be; c.relu = 1; }
         if (norm & 2) {                                              // with the InstanceNorm statistics of the output, as the forward's layers run
@@ -1782,6 +1811,9 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
     OP_END
 }
 
+#ifdef TSNET_TOOLS
+void tsnet_tools_set(int key, int value) { if (key >= 0 && key < 8) g_tools_knob[key] = value; }      // not in the product library / ABI header
+#endif
 void tsnet_debug_counters(int64_t out[4], int reset) {
     for (int i = 0; i < 4; ++i) { if (out) out[i] = g_launch_counters[i]; if (reset && i < 3) g_launch_counters[i] = 0; }
 }
