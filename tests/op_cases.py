@@ -203,6 +203,13 @@ def flow_case(lib, dev, B, h, w, C, mask_mode="bernoulli", seed=0, spike=False):
     flow = torch.empty((B, h, w, 2), device=dev)
     rc = lib.tsnet_op_flow(tard.data_ptr(), srcd.data_ptr(), mtd.data_ptr(), msd.data_ptr(), B, h, w, C, H, W, flow.data_ptr(), None)
     assert rc == 0, lib.tsnet_op_last_error().decode()
+    # a second run must give the same bits (the packed-fp32 build of the large-map kernel did not: csrc/flow_persist.hpp; both flow kernels
+    # are now compiled without the SLP vectorizer and both are held to this)
+    flow2 = torch.full((B, h, w, 2), float("nan"), device=dev)
+    rc = lib.tsnet_op_flow(tard.data_ptr(), srcd.data_ptr(), mtd.data_ptr(), msd.data_ptr(), B, h, w, C, H, W, flow2.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    assert torch.equal(flow, flow2)
     warped = torch.empty((B, h, w, C), device=dev)
     rc = lib.tsnet_op_warp(srcd.data_ptr(), flow.data_ptr(), B, h, w, C, warped.data_ptr(), None)
     assert rc == 0, lib.tsnet_op_last_error().decode()
@@ -243,6 +250,33 @@ def flow_k_case(lib, dev, B, K, h, w, C, mask_mode="bernoulli", seed=0, spike=Tr
     _sync(dev)
     assert torch.equal(flow, flow2)
     return (flow.cpu() - torch.cat(refs, 0)).abs().max().item()
+
+
+def flow_k_batch_independence_case(lib, dev, batches, K, h, w, C, seed=0):
+    """flow_kernel_p splits every source image into a number of slices that depends on the MAP alone and merges them in slice order; how
+    many workgroups share a target tile (G: 4, 2, 1 as the batch grows) only decides who computes which slice.  The flows of the first
+    batch element must therefore be the same BITS in every batch size (the tree used to be built on G).  Returns the list of
+    flows of element 0, one per batch size."""
+    H, W, P = h * 8, w * 8, h * w
+    Bmax = max(batches)
+    tar = F.relu(_rand(seed, "tar", (Bmax, C, h, w), -1, 1))
+    mt = prng.bernoulli(seed, "mt", (Bmax, H, W))
+    srcs = [_rand(seed + 1 + k, "src", (Bmax, C, h, w), -1, 1) * 3 for k in range(K)]
+    for k in range(K):
+        perm = (torch.arange(P) * (2 * k + 3) + 7 * k) % P if P % (2 * k + 3) else torch.arange(P - 1, -1, -1)
+        srcs[k].view(Bmax, C, P)[:, :, perm] = srcs[k].view(Bmax, C, P)[:, :, perm] * 0.2 + 4.0 * tar.view(Bmax, C, P)
+    mss = [prng.bernoulli(seed + 1 + k, "ms", (Bmax, H, W)) for k in range(K)]
+    out = []
+    for B in batches:
+        tard = nhwc(tar[:B]).to(dev)
+        srcd = torch.cat([nhwc(s[:B]) for s in srcs], 0).contiguous().to(dev)
+        mtd, msd = mt[:B].contiguous().to(dev), torch.cat([m[:B] for m in mss], 0).contiguous().to(dev)
+        flow = torch.empty((K * B, h, w, 2), device=dev)
+        rc = lib.tsnet_op_flow_k(tard.data_ptr(), srcd.data_ptr(), mtd.data_ptr(), msd.data_ptr(), B, K, h, w, C, H, W, flow.data_ptr(), 0, 1, None, None)
+        assert rc == 0, lib.tsnet_op_last_error().decode()
+        _sync(dev)
+        out.append(flow.cpu().view(K, B, h, w, 2)[:, 0].clone())
+    return out
 
 
 def warp_case(lib, dev, B, h, w, C, seed=0):

@@ -156,6 +156,10 @@ def test_flow_large_map_persistent_target_tiles(emu_lib):
     assert emu_lib.tsnet_flow_plan(1, 64, 64, 1024) == 0 and emu_lib.tsnet_flow_plan(1, 60, 64, 512) == 0   # LDS; ragged
     assert oc.flow_k_case(emu_lib, "cpu", 1, 2, 32, 64, 16, "bernoulli") < 5e-5
     assert oc.flow_k_case(emu_lib, "cpu", 4, 1, 64, 32, 8, "soft") < 5e-5
+    # the same frame alone (G = 4), in a batch of four (G = 2) and of eight (G = 1, no cross-workgroup merge): the same bits
+    import torch
+    f1, f4, f8 = oc.flow_k_batch_independence_case(emu_lib, "cpu", (1, 4, 8), 2, 32, 64, 8)
+    assert emu_lib.tsnet_flow_plan(8, 32, 64, 8) == 1 and torch.equal(f1, f4) and torch.equal(f1, f8)
 
 
 def test_flow_many_tiles(emu_lib):
@@ -191,7 +195,7 @@ def test_conv_w1_chunks_of_tiles_bitwise(emu_lib):
     chunk size never changes a bit.  Cases: chunks that cross from one image into the next under a fused InstanceNorm (the second transform
     table), zero padding (the per-tile padding masks), a raw input, an odd slab count (the all-zero last slab), a second channel tile."""
     import torch
-    for args, kw, chunks in (((6, 16, 32, 96, 128, True), dict(norm=True), (1, 3)), ((4, 16, 32, 96, 128, False), dict(norm=True), (1, 2)),
+    for args, kw, chunks in (((6, 16, 32, 128, 128, True), dict(norm=True), (1, 3)), ((4, 16, 32, 128, 128, False), dict(norm=True), (1, 2)),
                              ((6, 16, 32, 112, 128, True), dict(), (1, 3)), ((4, 16, 32, 128, 64, False), dict(norm=True, relu=False), (1, 2))):
         ys = [oc.conv_w1_case(emu_lib, "cpu", *args, chunk=c, return_output=True, **kw) for c in chunks]
         assert all(torch.equal(ys[0], y) for y in ys[1:]), (args, kw)

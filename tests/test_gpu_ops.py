@@ -88,6 +88,15 @@ def test_flow_configs4_form_persistent_target_tiles(lib):
     assert oc.flow_k_case(lib, DEV, 2, 3, 32, 64, 512) < 5e-5
 
 
+def test_flow_large_map_bits_do_not_depend_on_the_batch(lib):
+    """flow_kernel_p at the configs[4] map (64 x 64 positions, 512 channels): a frame alone (G = 4 workgroups per target tile), in a batch of
+    two (G = 2) and of four (G = 1): the slice tree is a function of the map alone, so the flows are the same bits."""
+    import torch
+    assert [lib.tsnet_flow_plan(b, 64, 64, 512) for b in (1, 2, 4)] == [4, 2, 1]
+    f1, f2, f4 = oc.flow_k_batch_independence_case(lib, DEV, (1, 2, 4), 3, 64, 64, 512)
+    assert torch.equal(f1, f2) and torch.equal(f1, f4)
+
+
 def test_flow_ragged_positions(lib):
     df, dw = oc.flow_case(lib, DEV, 1, 7, 9, 32, "bernoulli", spike=True)
     assert df < 5e-5 and dw < 4e-3   # dw = flow error x feature gradient

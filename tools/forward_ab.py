@@ -1,6 +1,8 @@
 """GPU box: same-box, same-process A/B of the whole forward under a tools-build knob (tsnet_tools_set; the product library has no knobs).
 Interleaved rounds, medians.  knob 0 = largest conv_w1 chunk the launcher may choose (3 = product behaviour, 1 = one tile per workgroup).
-    python tools/forward_ab.py [--batch 4] [--n-blocks 0] [--rounds 7] [--iters 20] [--knob 0] [--values 3,1]"""
+    python tools/forward_ab.py [--batch 4] [--n-blocks 0] [--rounds 7] [--iters 20] [--knob 0] [--values 3,1]
+--lib2 PATH: A/B of two BUILDS instead (this tree's tools library against another .so of the same ABI, e.g. the previous commit's, built
+into wacv23_tsnet_amd/lib/libtsnet_tools_prev.so): one engine per library, interleaved rounds in one process on one box."""
 import argparse, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,6 +16,7 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--knob", type=int, default=0)
 ap.add_argument("--values", default="3,1")
+ap.add_argument("--lib2", default=None)
 a = ap.parse_args()
 lib = _lib.load_tools()
 vals = [int(v) for v in a.values.split(",")]
@@ -35,6 +38,29 @@ for r in range(a.rounds + 1):
         if r:                                   # round 0 warms up
             res[v].append((time.perf_counter() - t0) / a.iters * 1e3)
         outs[v] = o.clone()
+if a.lib2:
+    import ctypes
+    lib2 = _lib.bind(ctypes.CDLL(a.lib2))
+    e2 = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=3, height=256, width=256, max_batch=a.batch, lib=lib2)
+    e2.load_state_dict(synth.state_dict(e2.param_shapes(), seed=0)); e2.finalize("cuda")
+    steps = {"this tree": step, os.path.basename(a.lib2): lambda: e2.forward(si, sl, sb, tl, tb)[0]}
+    r2, o2 = {k: [] for k in steps}, {}
+    for r in range(a.rounds + 1):
+        for k, f in steps.items():
+            for _ in range(3):
+                o = f()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(a.iters):
+                o = f()
+            torch.cuda.synchronize()
+            if r:
+                r2[k].append((time.perf_counter() - t0) / a.iters * 1e3)
+            o2[k] = o.clone()
+    ks = list(steps)
+    for k in ks:
+        t = r2[k]
+        print(f"{k:28s}: median {statistics.median(t):.3f} ms  (min {min(t):.3f} max {max(t):.3f})  {a.batch / statistics.median(t) * 1e3:.1f} frames/s   same bits as this tree: {torch.equal(o2[k], o2[ks[0]])}")
+    sys.exit(0)
 for v in vals:
     t = res[v]
     print(f"knob {a.knob} = {v}: median {statistics.median(t):.3f} ms  (min {min(t):.3f} max {max(t):.3f})  {a.batch / statistics.median(t) * 1e3:.1f} frames/s   same bits as value {vals[0]}: {torch.equal(outs[v], outs[vals[0]])}")

@@ -82,6 +82,27 @@ def kernel_resources(asm_path, pattern):
     return out
 
 
+def scratch_in_inner_loops(asm_path, pattern):
+    """{demangled kernel name: scratch (spill) instructions inside INNERMOST loops}: a spill in straight-line prologue / tile-boundary code costs
+    a few instructions per tile; one inside a period loop is paid every period beside the MFMAs."""
+    s = open(asm_path).read()
+    out = {}
+    for m in re.finditer(r"^(_ZN5tsnet\w+):\s*;", s, re.M):
+        d = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        if pattern not in d:
+            continue
+        L = s[m.start():s.index(".Lfunc_end", m.start())].split("\n")
+        labels = {mm.group(1): k for k, l in enumerate(L) for mm in [re.match(r"^(\.LBB\d+_\d+):", l)] if mm}
+        loops = []
+        for k, l in enumerate(L):
+            mm = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+            if mm and mm.group(1) in labels and labels[mm.group(1)] < k:
+                loops.append((labels[mm.group(1)], k))
+        inner = [(a, b) for a, b in loops if not any((c, e) != (a, b) and a <= c and e <= b for c, e in loops)]
+        out[d] = sum(1 for a, b in inner for l in L[a:b + 1] if l.strip().startswith("scratch_"))
+    return out
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     rows = analyse(compile_asm("--tools" in sys.argv), args[0] if args else "")

@@ -64,6 +64,12 @@ for j in range(c):
     ph(f"tile {j}: item stream", prod[:, :, 3 + 3 * j] - prev)
     ph(f"tile {j}: epilogue barriers", prod[:, :, 5 + 3 * j] - prod[:, :, 3 + 3 * j])
     prev = prod[:, :, 5 + 3 * j]
+print("time spent waiting at the K loop's barriers, per wave over its whole chunk (who waits for whom):")
+ph("consumers", cons[:, :, 12])
+ph("producers", prod[:, :, 12])
+simd = [int(np.median((t[:, w, 15].astype(np.int64) >> 4) & 3)) if False else None for w in range(WV)]
+print("   per wave (median over the workgroups; waves 0..7 consumers = (position, channel half), 8..13 producers):")
+print("   " + "  ".join(f"w{w}:{np.median(us(t[:, w, 12].astype(np.float64))):5.1f}" for w in range(WV)))
 hw = (t[:, 0, 15] & 0xFFFFFFFF).astype(np.int64)
 xcc = (t[:, 0, 15] >> 32).astype(np.int64) & 0xF
 key = xcc * 10000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xF)

@@ -60,6 +60,19 @@ typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
         asm("s_nop 0\n\tv_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw) : "v"(b), "v"(hw));           \
     } while (0)
 #endif
+// Two pairs at once, the six instructions interleaved so that each mixhi stands one instruction behind the mixlo of its register: the wait
+// state of the hazard without an s_nop (an issue slot beside MFMA waves: conv_w1's producers).  Same bits as two TSNET_SPLIT_PAIR.
+#ifndef TSNET_SPLIT_2PAIRS
+#define TSNET_SPLIT_2PAIRS(a0, b0, a1, b1, h0, l0, h1, l1)                                                       \
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"                                                                        \
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"                                                                        \
+        "v_fma_mixlo_f16 %2, %4, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"                                  \
+        "v_fma_mixlo_f16 %3, %6, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"                                  \
+        "v_fma_mixhi_f16 %2, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"                                  \
+        "v_fma_mixhi_f16 %3, %7, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"                                       \
+        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)                                                              \
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1))
+#endif
 #ifndef TSNET_FAST_EXP
 #define TSNET_FAST_EXP(x) __expf(x)
 #endif

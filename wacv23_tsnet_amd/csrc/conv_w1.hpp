@@ -33,6 +33,8 @@
 //   * <= 128 VGPRs (two SIMDs carry four of the fourteen waves; tests/test_isa.py), 154 - 158 KiB of LDS.
 // How it got here, form by form with measurements: DESIGN.md section 4.4.
 #pragma once
+#include <type_traits>
+
 #include "conv_common.hpp"
 
 namespace tsnet {
@@ -55,8 +57,26 @@ static __device__ unsigned long long g_w1_prof[kW1ProfTiles * kW1Waves * kW1Prof
         if ((OPT & 512) && (threadIdx.x & 63) == 0 && blockIdx.x < kW1ProfTiles)                                                \
             g_w1_prof[((size_t)blockIdx.x * kW1Waves + (threadIdx.x >> 6)) * kW1ProfSlots + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+// the K loop's barrier, with the time this wave spent waiting at it summed into `acc_` (tools build, OPT bit 9)
+#define TSNET_W1_LOOP_BARRIER(acc_)                                                        \
+    do {                                                                                    \
+        if (OPT & 512) {                                                                    \
+            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();                \
+            __syncthreads();                                                                \
+            acc_ += __builtin_amdgcn_s_memrealtime() - t0_;                                 \
+        } else {                                                                            \
+            __syncthreads();                                                                \
+        }                                                                                   \
+    } while (0)
+#define TSNET_W1_PUT(slot, v)                                                                                                   \
+    do {                                                                                                                        \
+        if ((OPT & 512) && (threadIdx.x & 63) == 0 && blockIdx.x < kW1ProfTiles)                                                \
+            g_w1_prof[((size_t)blockIdx.x * kW1Waves + (threadIdx.x >> 6)) * kW1ProfSlots + (slot)] = (v);                      \
+    } while (0)
 #else
 #define TSNET_W1_STAMP(slot) do { } while (0)
+#define TSNET_W1_LOOP_BARRIER(acc_) __syncthreads()
+#define TSNET_W1_PUT(slot, v) do { } while (0)
 #endif
 
 // A workgroup runs a CHUNK of a.w1_chunk consecutive tiles (1, 2 or 3: run_conv picks it so that the chunks fill the chip in whole rounds).
@@ -157,6 +177,7 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) tot[i][r] = 0.f;
+    unsigned long long bar_wait = 0;                                 // (tools build: time spent at the K loop's barriers)
     const bool consumer = wave < 8;
     const int mq = consumer ? wave >> 1 : 0;                         // epilogue role: output row mq of the tile, channel half nt
 
@@ -228,7 +249,7 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         static_assert(NIT * kW1Prod == 12 && (NIT & 1) == 0, "an even number of items per producer (the fetch buffers alternate)");
         const int pw = wave - 8, quad = lane & 7;
         const int psl = quad >> 2, poct = (quad >> 1) & 1, psub = quad & 1;
-        struct Offs { unsigned vP[NIT][4]; float vM[NIT][4]; };
+        struct Offs { unsigned vP[NIT][4]; };                       // byte offset of (pixel, channel quad), or kOOB for a padded pixel
         int ldst[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -258,7 +279,6 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
                         ok = ok && ix >= 0 && ix < a.W;
                     }
                     o.vP[it][q] = ok ? (unsigned)(((t.img * a.H * a.W + iy * a.W + ix) * a.Cin + quad * 4) * 4) : kOOB;
-                    o.vM[it][q] = ok ? 1.f : 0.f;
                 }
             }
         };
@@ -267,24 +287,36 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         bool has_next = nrun > 1;
         offsets(T, true, cur);
         offsets(T, false, nxt);                                      // (nothing behind this tile yet: zeros)
+        // the offsets of a tile's LAST period: with an odd slab count its second slab lies past Cin -- those lanes read zeros, like the weights
+        // of that slab (the transform table holds zeros there too)
+        unsigned curT[NIT][4];
+        auto tail_of = [&](const Offs& o) __attribute__((always_inline)) {
+            const bool cok = (npp - 1) * 32 + quad * 4 < a.Cin;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) curT[it][q] = cok ? o.vP[it][q] : kOOB;
+        };
+        tail_of(cur);
         const float* tab_cur = tab0;
         const float* tab_nxt = tab0;
         const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();
         F4 sx[2][4];                                                 // two items in turn: four pixels x four channels each
         struct alignas(8) U2 { unsigned x, y; };
-        // period pq of the current tile, or -- pq >= npp -- period pq - npp of the next one; channels past Cin (the second slab of an odd
-        // count) read zeros, like the weights of that slab
-        auto v_fetch = [&](int pq, int it, F4 (&b)[4]) __attribute__((always_inline)) {
-            const bool nx = pq >= npp;
-            const int pe = nx ? pq - npp : pq;
-            const bool cok = pe * 32 + quad * 4 < a.Cin;
+        // Which tile an item belongs to is decided where the loop is written, not per load: the period loop below is split at the tile
+        // boundary (every select, compare and branch in here is an issue slot taken from the MFMA waves of the same SIMD; the first form
+        // spent 71 scalar instructions and 27 s_nop per two items).  SRC: 0 = the current tile, 1 = its last period, 2 = the next tile.
+        using SrcCur = std::integral_constant<int, 0>;
+        using SrcTail = std::integral_constant<int, 1>;
+        using SrcNxt = std::integral_constant<int, 2>;
+        auto v_fetch = [&](auto SRC, int pe, int it, F4 (&b)[4]) __attribute__((always_inline)) {
+            constexpr int src = decltype(SRC)::value;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = TSNET_BUF_LOAD16(rsx, cok ? (nx ? nxt.vP[it][q] : cur.vP[it][q]) : kOOB, (unsigned)(pe * 128));
+            for (int q = 0; q < 4; ++q)
+                b[q] = TSNET_BUF_LOAD16(rsx, src == 2 ? nxt.vP[it][q] : (src == 1 ? curT[it][q] : cur.vP[it][q]), (unsigned)(pe * 128));
         };
-        auto v_load = [&](int pq, int it, int buf) __attribute__((always_inline)) { v_fetch(pq, it, sx[buf]); };
-        auto v_put = [&](int pq, int it, int st, const F4 (&b)[4]) __attribute__((always_inline)) {   // transform + split + store of a fetched item into the stage at st
-            const bool nx = pq >= npp;
-            const int pe = nx ? pq - npp : pq;
+        auto v_put = [&](auto SRC, int pe, int it, int st, const F4 (&b)[4]) __attribute__((always_inline)) {   // transform + split + store of a fetched item into the stage at st
+            constexpr bool nx = decltype(SRC)::value == 2;
             const int c0 = pe * 32 + quad * 4;
             const float scale = nx ? Tn.in_scale : T.in_scale;
             F4 d[4];
@@ -296,7 +328,7 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v = __builtin_fmaxf(__builtin_fmaf(b[q].v[e], al.v[e], be.v[e]), relu_floor);
-                        d[q].v[e] = ZPAD_KEEP ? v * (nx ? nxt.vM[it][q] : cur.vM[it][q]) : v;
+                        d[q].v[e] = (ZPAD_KEEP && (nx ? nxt.vP[it][q] : cur.vP[it][q]) == kOOB) ? 0.f : v;     // a padded pixel is zero, not beta
                     }
             } else {
 #pragma unroll
@@ -320,41 +352,56 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
                     *reinterpret_cast<U2*>(dst + p * POSB) = h;
                 } else {
                     U2 h, l;
-                    TSNET_SPLIT_PAIR(v[0], v[1], h.x, l.x);
-                    TSNET_SPLIT_PAIR(v[2], v[3], h.y, l.y);
+                    TSNET_SPLIT_2PAIRS(v[0], v[1], v[2], v[3], h.x, l.x, h.y, l.y);
                     *reinterpret_cast<U2*>(dst + p * POSB) = h;
                     *reinterpret_cast<U2*>(dst + p * POSB + PLANE_V) = l;
                 }
             }
         };
-        auto v_item = [&](int pq, int it, int st, int buf) __attribute__((always_inline)) { v_put(pq, it, st, sx[buf]); };
+        // an item by its period pq counted from the current tile (pq >= npp: the next tile's), the source picked by branches: the prologue
+        // and tiles of fewer than five periods (the hot layers have 16 and 32)
+        auto fetch_any = [&](int pq, int it, F4 (&b)[4]) __attribute__((always_inline)) {
+            if (pq >= npp) v_fetch(SrcNxt{}, pq - npp, it, b);
+            else if (pq == npp - 1) v_fetch(SrcTail{}, pq, it, b);
+            else v_fetch(SrcCur{}, pq, it, b);
+        };
+        auto put_any = [&](int pq, int it, int st, const F4 (&b)[4]) __attribute__((always_inline)) {
+            if (pq >= npp) v_put(SrcNxt{}, pq - npp, it, st, b);
+            else v_put(SrcCur{}, pq, it, st, b);
+        };
         // the item stream (period, item): each item is fetched while its predecessor is transformed; two buffers in turn.  The chunk's
         // prologue -- V(0), V(1) of its first tile, the only ones the consumers wait for -- fetches its four items at once (one exposed
         // memory latency instead of two).
+        static_assert(NIT == 2, "the prologue and the period loop are written for two items per producer");
         {
-            constexpr int G = ZPAD_KEEP ? 2 : 2 * NIT;               // (the zero-padding form carries its masks: two items at a time keep it in 128 VGPRs)
-            F4 sp[G][4];
-#pragma unroll
-            for (int u = 0; u < G; ++u) v_fetch(u / NIT, u % NIT, sp[u]);
+            F4 sp[2][4];                                             // with sx: four buffers, the prologue's four items in flight at once
+            fetch_any(0, 0, sx[0]); fetch_any(0, 1, sx[1]); fetch_any(1, 0, sp[0]); fetch_any(1, 1, sp[1]);
             if (AFFINE) {
                 tab_fill(tab0, T, tid, 64 * kW1Waves);
                 __syncthreads();                                     // the first tile's table (the consumers fill their share)
             }
             if (has_next) { Tn = tile_at(1); offsets(Tn, true, nxt); }
-#pragma unroll
-            for (int g0 = 0; g0 < 2 * NIT; g0 += G) {
-                if (g0 + G >= 2 * NIT) v_load(2, 0, 0);             // item 0 of period 2 stays in flight in buffer 0
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    v_put((g0 + u) / NIT, (g0 + u) % NIT, ((g0 + u) / NIT) * STAGE, sp[u]);
-                    if (g0 + G + u < 2 * NIT) v_fetch((g0 + G + u) / NIT, (g0 + G + u) % NIT, sp[u]);
-                }
-            }
+            put_any(0, 0, 0, sx[0]);
+            fetch_any(2, 0, sx[0]);                                  // item 0 of period 2 stays in flight in buffer 0
+            put_any(0, 1, 0, sx[1]);
+            if (1 < npp || has_next) { put_any(1, 0, STAGE, sp[0]); put_any(1, 1, STAGE, sp[1]); }
         }
         TSNET_W1_STAMP(1);
         __syncthreads();                                             // (the consumers' prologue barrier)
         TSNET_W1_STAMP(2);
         int st_wr = 2 * STAGE;
+        // consumer period pp: item (pp + 2, 1) fetched, (pp + 2, 0) written, (pp + 3, 0) fetched, (pp + 2, 1) written.  L1 / L2: where the
+        // two fetched items live; PUT: where the written period lives; pe*: their period numbers inside their own tile
+        auto iter = [&](auto L1, auto L2, auto PUT, int pe1, int pe2, int pep, bool put_ok) __attribute__((always_inline)) {
+            if (!(OPT & 128)) TSNET_W1_LOOP_BARRIER(bar_wait);       // every read of the stage produced next has been issued
+            if (!(OPT & 16)) {
+                v_fetch(L1, pe1, 1, sx[1]);
+                if (put_ok) v_put(PUT, pep, 0, st_wr, sx[0]);
+                v_fetch(L2, pe2, 0, sx[0]);
+                if (put_ok) v_put(PUT, pep, 1, st_wr, sx[1]);
+            }
+            st_wr = st_wr == 2 * STAGE ? 0 : st_wr + STAGE;
+        };
         for (int j = 0; j < nrun; ++j) {
             if (AFFINE && a.w1_tab2 && has_next && Tn.img != T.img) {
                 // the next tile lies in another image: its table into the buffer the current tile does not use -- last read (two tiles ago at
@@ -363,16 +410,23 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
                 tab_fill(tb, Tn, tid - 64 * 8, 64 * kW1Prod);
                 tab_nxt = tb;
             }
-            for (int pp = 0; pp < npp; ++pp) {
-                if (!(OPT & 128)) __syncthreads();                   // every read of the stage produced next has been issued
-                if (!(OPT & 16)) {
-#pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        v_load(it == NIT - 1 ? pp + 3 : pp + 2, it == NIT - 1 ? 0 : it + 1, (it & 1) ^ 1);
-                        if (pp + 2 < npp || has_next) v_item(pp + 2, it, st_wr, it & 1);
+            if (npp >= 5) {
+                for (int pp = 0; pp < npp - 4; ++pp) iter(SrcCur{}, SrcCur{}, SrcCur{}, pp + 2, pp + 3, pp + 2, true);
+                iter(SrcCur{}, SrcTail{}, SrcCur{}, npp - 2, npp - 1, npp - 2, true);
+                iter(SrcTail{}, SrcNxt{}, SrcCur{}, npp - 1, 0, npp - 1, true);
+                iter(SrcNxt{}, SrcNxt{}, SrcNxt{}, 0, 1, 0, has_next);
+                iter(SrcNxt{}, SrcNxt{}, SrcNxt{}, 1, 2, 1, has_next);
+            } else {
+                for (int pp = 0; pp < npp; ++pp) {
+                    if (!(OPT & 128)) TSNET_W1_LOOP_BARRIER(bar_wait);
+                    if (!(OPT & 16)) {
+                        fetch_any(pp + 2, 1, sx[1]);
+                        if (pp + 2 < npp || has_next) put_any(pp + 2, 0, st_wr, sx[0]);
+                        fetch_any(pp + 3, 0, sx[0]);
+                        if (pp + 2 < npp || has_next) put_any(pp + 2, 1, st_wr, sx[1]);
                     }
+                    st_wr = st_wr == 2 * STAGE ? 0 : st_wr + STAGE;
                 }
-                st_wr = st_wr == 2 * STAGE ? 0 : st_wr + STAGE;
             }
             if (j < 3) TSNET_W1_STAMP(3 + 3 * j);
             // the stage of the tile's last period: the one written three periods back = the one about to be written
@@ -380,6 +434,7 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
             if (j < 3) TSNET_W1_STAMP(5 + 3 * j);
             // on to the next tile: its offsets become the current ones
             T = Tn; cur = nxt; tab_cur = tab_nxt;
+            tail_of(cur);
             has_next = j + 2 < nrun;
             if (has_next) Tn = tile_at(j + 2);
             offsets(Tn, has_next, nxt);
@@ -392,20 +447,19 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         }
         const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
         F4 af[2][5][NPL], bf[BD][NPL];                               // [slab of the period][first row of the row pair][plane], [step % BD][plane]
-        // slab s of the current tile, or -- s >= 2 npp -- slab s - 2 npp of the chunk's next tile (channel tile n0x); a slab past the last
-        // one, or behind the chunk's last tile: zeros
-        int n0_cur = T.n0, n0_nxt = T.n0;
+        // Weight fragment of (tap row ky, slab cc) of this wave's position: byte offset ((ky * 4 + pos) * ncc + cc) * Npad + n0) * 32 =
+        // ky * wA + cc * wB + wtile.  The K loop keeps the running offset of the period's first slab (`wsp`, + 2 wB per period) and adds
+        // compile-time multiples of wA / wB per step: the loop was SALU-heavy (62 scalar instructions per period beside 36 MFMAs; the SIMD
+        // hides ~5 issue slots per MFMA, MI355X_MICROARCH.md) -- every instruction here is an issue slot the matrix pipe does not get.
         bool has_next = nrun > 1;
         W1Tile Tn = T;
-        if (has_next) { Tn = tile_at(1); n0_nxt = Tn.n0; }
-        auto load_b = [&](int set, int s, int ky) __attribute__((always_inline)) {
-            const bool nx = s >= 2 * npp;
-            const int cc = nx ? s - 2 * npp : s;
-            const int kc = (ky * 4 + pos) * ncc + cc;
-            const unsigned vo = (cc < ncc && (!nx || has_next)) ? vB : kOOB;
-            const int n0x = nx ? n0_nxt : n0_cur;
+        if (has_next) Tn = tile_at(1);
+        const int wB = a.Npad * 32, wA = 4 * ncc * wB;
+        auto wtile = [&](const W1Tile& t) __attribute__((always_inline)) { return pos * ncc * wB + t.n0 * 32; };
+        int wsp = wtile(T), wnext = wtile(Tn);                      // first slab of the current period; first slab of the chunk's next tile
+        auto load_bs = [&](int set, unsigned vo, int soff) __attribute__((always_inline)) {
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) bf[set][p] = TSNET_BUF_LOAD16(rsw[p], vo, (unsigned)((kc * a.Npad + n0x) * 32));
+            for (int p = 0; p < NPL; ++p) bf[set][p] = TSNET_BUF_LOAD16(rsw[p], vo, (unsigned)soff);
         };
         const unsigned char* abase = smem_raw + pos * POSB + lh * REG + li * 16;
         auto load_f = [&](int sl, int f, int st) __attribute__((always_inline)) { // rows (f, f + 1) of slab sl of the stage at byte offset st
@@ -433,11 +487,22 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         // now, st_nxt = the next period (complete before this period's barrier: its first fragments are fetched at the last step).  Step
         // (sl, ky) uses fragments ky and ky + 2 of slab sl; weights BD - 1 steps ahead.
         auto period = [&](int pp, int st_cur, int st_nxt, bool first) __attribute__((always_inline)) {
-            if (!(OPT & 128)) __syncthreads();                       // the next period's V complete
+            if (!(OPT & 128)) TSNET_W1_LOOP_BARRIER(bar_wait);       // the next period's V complete
+            // the fragments fetched in this period: steps 2..5 of it (slab 0: tap row 2; slab 1 -- all zeros when the slab count is odd and this
+            // is the last period) and steps 0, 1 of the next period (the chunk's next tile behind the last period; nothing behind the last tile)
+            const bool last = pp == npp - 1;
+            const unsigned vo1 = 2 * pp + 1 < ncc ? vB : kOOB, von = (!last || has_next) ? vB : kOOB;
+            const int wsn = last ? wnext : wsp + 2 * wB;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const int sl = t / 3, ky = t % 3;
-                if (!(OPT & 32)) load_b((t + BD - 1) % BD, 2 * pp + (t + BD - 1) / 3, (t + BD - 1) % 3);
+                if (!(OPT & 32)) {
+                    static_assert(BD == 3, "fragments two steps ahead");
+                    const int t2 = t + 2, ky2 = t2 % 3;             // the step fetched for: slab t2 / 3 of this period (2: the next period's first)
+                    if (t2 < 3) load_bs(t2 % BD, vB, wsp + ky2 * wA);
+                    else if (t2 < 6) load_bs(t2 % BD, vo1, wsp + wB + ky2 * wA);
+                    else load_bs(t2 % BD, von, wsn + ky2 * wA);
+                }
                 if (!(OPT & 64)) {
                     if (ky == 0) { load_f(sl, 1, st_cur); load_f(sl, 3, st_cur); }
                     if (ky == 1) load_f(sl, 4, st_cur);
@@ -461,13 +526,12 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
                     for (int r = 0; r < 16; ++r) tot[i][r] += acc[i][r];
             }
         };
-#pragma unroll
-        for (int i = 0; i < BD - 1; ++i) load_b(i, i / 3, i % 3);
+        load_bs(0, vB, wsp); load_bs(1, vB, wsp + wA);            // steps 0, 1 of the first period
         TSNET_W1_STAMP(1);
         __syncthreads();                                             // V(0), V(1) complete
         TSNET_W1_STAMP(2);
         load_f(0, 0, 0); load_f(0, 2, 0);
-        if (OPT & 32) load_b(BD - 1, 1, 2);
+        if (OPT & 32) load_bs(BD - 1, vB, wsp + wB + 2 * wA);
         if (OPT & 64) {
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl)
@@ -480,6 +544,7 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
             for (int pp = 0; pp < npp; ++pp) {
                 period(pp, st0, st1, pp == 0);
                 st0 = st1; st1 = st1 == 2 * STAGE ? 0 : st1 + STAGE;
+                wsp += 2 * wB;
             }
             if (ONE_LEVEL) { tot[0] = acc[0]; tot[1] = acc[1]; }
             TSNET_SETPRIO(0);
@@ -487,9 +552,9 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
             // the stage the last period was read from: two behind the one the next period will be read from
             epilogue(T, st1 == 2 * STAGE ? 0 : st1 + STAGE, has_next);
             if (j < 3) TSNET_W1_STAMP(5 + 3 * j);
-            T = Tn; n0_cur = n0_nxt;
+            T = Tn; wsp = wnext;
             has_next = j + 2 < nrun;
-            if (has_next) { Tn = tile_at(j + 2); n0_nxt = Tn.n0; }
+            if (has_next) { Tn = tile_at(j + 2); wnext = wtile(Tn); }
             if (!ONE_LEVEL) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -499,6 +564,7 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         }
     }
     TSNET_W1_STAMP(14);
+    TSNET_W1_PUT(12, bar_wait);
 #ifdef TSNET_TOOLS
     if ((OPT & 512) && (threadIdx.x & 63) == 0 && blockIdx.x < kW1ProfTiles) {     // where the workgroup ran: HW_ID (CU / SE), XCC_ID
         unsigned hw, xcc;

@@ -511,7 +511,7 @@ void run_flow(Ctx& ctx, FlowArgs a, int NB, int variant = 0) {
     // large maps (a.part / a.cnt supplied): persistent target tiles, the K sources of a batch element swept in G slices (flow_persist.hpp)
     const int G = (a.part && a.cnt && NB % a.B == 0 && NB / a.B <= 8 && variant != 1) ? flowp_plan(a.B, a.h, a.w, a.C) : 0;
     if (G) {
-        a.K = NB / a.B; a.G = G;
+        a.K = NB / a.B; a.G = G; a.S = flowp_slices(a.h, a.w);
         try {
             launch_flow_p(a, variant, ctx.stream);
         } catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
@@ -522,14 +522,9 @@ void run_flow(Ctx& ctx, FlowArgs a, int NB, int variant = 0) {
     const int NT = flow_lds_bytes(2, a.h, a.w, a.C) <= budget ? 2 : 1;
     const size_t lds = flow_lds_bytes(NT, a.h, a.w, a.C);
     if (lds > budget) throw ArgError("flow: feature width / position count exceed the LDS budget");
-    const dim3 grid(flow_ppad(a.P) / (32 * NT) * NB);
-    if (NT == 2) {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(flow_kernel<2>), lds);
-        hipLaunchKernelGGL(flow_kernel<2>, grid, dim3(64 * kFlowWaves), lds, ctx.stream, a);
-    } else {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(flow_kernel<1>), lds);
-        hipLaunchKernelGGL(flow_kernel<1>, grid, dim3(64 * kFlowWaves), lds, ctx.stream, a);
-    }
+    try {
+        launch_flow(a, NT, lds, (unsigned)(flow_ppad(a.P) / (32 * NT) * NB), ctx.stream);
+    } catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
     check_launch("flow");
 }
 
@@ -882,7 +877,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     for (int i = 0; i < 4; ++i) { want(&ab[i][0], NB * 2 * C); want(&ab[i][1], NB * 2 * C); }
     for (int i = 0; i < 2; ++i) { want(&ab_side[i][0], NB * 2 * C); want(&ab_side[i][1], NB * 2 * C); }
     want(&bbox_copy, NB * H * W);
-    if (P >= 2048) want(&flow_part, (size_t)K * 256 * 64 * 2 * 2);      // flow_kernel_p splits a source only while target tiles x G <= 256
+    if (P >= 2048 && P % 64 == 0) want(&flow_part, 2 * flowp_part_words((int)NB, P, flowp_slices(h, w)));   // flow_kernel_p: one softmax state per (image, target tile, slice, column), 8-byte words
     // InstanceNorm partials (doubles = 2 floats each): the stand-alone pass N*64*C*2, a conv epilogue N * tiles-per-image * Cout * 2
     // with tiles of at least 64 positions (ceil for ragged images), per lane
     size_t part_doubles = NB * 64 * 2 * C * 2;
@@ -1546,7 +1541,7 @@ static void op_flow_impl(const float* tar_fea, const float* src_fea, const float
     FlowArgs fa{};
     const int G = flowp_plan(B, h, w, C);
     if (G) {
-        fa.part = bufs.alloc<unsigned long long>(flowp_part_words(NB, P, G) * 8);
+        fa.part = bufs.alloc<unsigned long long>(flowp_part_words(NB, P, flowp_slices(h, w)) * 8);
         fa.cnt = bufs.alloc<int>((size_t)B * (P / 64) * sizeof(int));
         HIP_TRY(hipMemsetAsync(fa.cnt, 0, (size_t)B * (P / 64) * sizeof(int), ctx.stream));
     }

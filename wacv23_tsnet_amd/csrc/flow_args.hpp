@@ -29,9 +29,9 @@ struct FlowArgs {
     float* flow;              // (NB, P, 2)
     int B, P, C, h, w, H, W, sy, sx;
     // flow_kernel_p only
-    unsigned long long* part; // [NB][tiles][G][64][2]: (max, sum) and (x, y) of a partial softmax state, two floats per 8-byte word
+    unsigned long long* part; // [NB][tiles][S][64][2]: (max, sum) and (x, y) of a slice's softmax state, two floats per 8-byte word
     int* cnt;                 // [B][tiles] arrival counters, zero between launches
-    int K, G;                 // sources per batch element; workgroups per target tile
+    int K, G, S;              // sources per batch element; workgroups per target tile; slices per source image (flowp_slices: S % G == 0)
 };
 
 // LDS bytes of flow_kernel_p (64 targets per workgroup): target planes, two merge buffers [kFlowWaves][64][4] floats, a 64-float mask row
@@ -39,17 +39,26 @@ struct FlowArgs {
 inline size_t flowp_lds_bytes(int h, int w, int C) {
     return (size_t)2 * flow_ksteps(C) * 2048 + (size_t)2 * kFlowWaves * 64 * 16 + (size_t)kFlowWaves * 256 + (size_t)(((w + 3) & ~3) + ((h + 3) & ~3)) * 4;
 }
-// Workgroups per target tile of flow_kernel_p (one workgroup per CU when the target tiles alone do not fill the chip; every wave keeps >= 1
-// source pair per slice), or 0 where the form does not apply: small maps (flow_kernel fills the chip there), ragged maps, LDS.
+// SLICES of a source image in flow_kernel_p: a function of the MAP alone (the largest power of two <= 8 that leaves every wave a whole
+// source pair per slice).  The reduction tree of a target column -- waves of a slice in wave order, then the slices in slice order -- is
+// built on them, so a frame's flow is the same bits in any batch (it used to be built on G, which depends on the batch).
+inline int flowp_slices(int h, int w) {
+    const int npair = (h * w) / 64;
+    int S = 1;
+    while (S < 8 && npair % (S * 2 * kFlowWaves) == 0) S *= 2;
+    return S;
+}
+// Workgroups per target tile of flow_kernel_p (one workgroup per CU when the target tiles alone do not fill the chip; a workgroup sweeps
+// S / G slices of every source), or 0 where the form does not apply: small maps (flow_kernel fills the chip there), ragged maps, LDS.
 inline int flowp_plan(int B, int h, int w, int C) {
     const int P = h * w;
     if (P < 2048 || P % 64 || w % 4) return 0;
-    const int npair = P / 64, tiles = B * npair;
+    const int npair = P / 64, tiles = B * npair, S = flowp_slices(h, w);
     int G = 1;
-    while (G < 8 && tiles * G * 2 <= 256 && npair % (G * 2 * kFlowWaves) == 0) G *= 2;
-    if ((npair / G) % kFlowWaves || flowp_lds_bytes(h, w, C) > (size_t)160 * 1024) return 0;
+    while (G < S && tiles * G * 2 <= 256) G *= 2;
+    if ((npair / S) % kFlowWaves || flowp_lds_bytes(h, w, C) > (size_t)160 * 1024) return 0;
     return G;
 }
-inline size_t flowp_part_words(int NB, int P, int G) { return (size_t)NB * (P / 64) * G * 64 * 2; }   // 8-byte words
+inline size_t flowp_part_words(int NB, int P, int S) { return (size_t)NB * (P / 64) * S * 64 * 2; }   // 8-byte words: one state per (image, tile, slice, column)
 
 }  // namespace tsnet

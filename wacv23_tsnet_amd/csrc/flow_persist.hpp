@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * kFlowWaves) void flow_kernel_p(FlowArgs a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     const int KC = (a.C + 31) / 32 * 2;
     const int TBYTES = NT * KC * 2048;
-    const int npair = a.P >> 6, npc = npair / a.G, tiles = npair;
+    const int npair = a.P >> 6, nps = npair / a.S, spg = a.S / a.G, tiles = npair;       // pairs per slice; slices per workgroup
     F4* sRed = reinterpret_cast<F4*>(smem_raw + TBYTES);                                   // [2][kFlowWaves][64]
     float* sMw = reinterpret_cast<float*>(smem_raw + TBYTES + 2 * kFlowWaves * 64 * 16);   // [kFlowWaves][64]
     float* sGx = sMw + kFlowWaves * 64;
@@ -63,7 +63,6 @@ __global__ __launch_bounds__(64 * kFlowWaves) void flow_kernel_p(FlowArgs a) {
     const int t = item % tiles, gb = item / tiles;
     const int b = gb % a.B, g = gb / a.B;
     const int tb0 = t * NT;
-    const int sp_base = g * npc;
 
     {   // the workgroup's target fragments: one contiguous region of the plane buffer
         const F4* gp = reinterpret_cast<const F4*>(a.tq + ((size_t)(b * (a.P >> 5) + tb0) * KC) * 1024);
@@ -94,15 +93,18 @@ __global__ __launch_bounds__(64 * kFlowWaves) void flow_kernel_p(FlowArgs a) {
     const unsigned char* tbase = smem_raw + lane * 16;
     float* ms_w = sMw + wave * 64;
 
-    for (int s_idx = 0; s_idx < a.K; ++s_idx) {
+    // (source, slice) items: every slice is a complete reduction of its own -- waves in wave order -- whatever G is
+    for (int it = 0; it < a.K * spg; ++it) {
+        const int s_idx = it / spg, slice = g * spg + (it - s_idx * spg);
         const int n = s_idx * a.B + b;
-        const int buf = s_idx & 1;
+        const int buf = it & 1;
+        const int sp_base = slice * nps;
         const float* sb = a.src_bbox[s_idx] + (size_t)b * a.H * a.W;
         float m_run[NT], l_run[NT], ax[NT], ay[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) { m_run[j] = -3.0e38f; l_run[j] = 0.f; ax[j] = 0.f; ay[j] = 0.f; }
         const unsigned char* sbase = reinterpret_cast<const unsigned char*>(a.sq) + ((size_t)n * (a.P >> 5) * KC) * 2048 + lane * 16;
-        for (int sp = sp_base + wave; sp < sp_base + npc; sp += kFlowWaves) {
+        for (int sp = sp_base + wave; sp < sp_base + nps; sp += kFlowWaves) {
             // this lane's share of the pair's source mask (F.interpolate(nearest)): source sp * 64 + lane; lands under the MFMA sweep
             float msl;
             {
@@ -245,36 +247,37 @@ __global__ __launch_bounds__(64 * kFlowWaves) void flow_kernel_p(FlowArgs a) {
                 const float sc = expf(pr.v[0] - M);
                 L += pr.v[1] * sc; X += pr.v[2] * sc; Y += pr.v[3] * sc;
             }
-            if (a.G == 1) {
-                float* f = a.flow + ((size_t)n * a.P + t * 64 + tid) * 2;
-                f[0] = X / L;
-                f[1] = Y / L;
-            } else {                          // device-scope write-through: a workgroup of another XCD may read them
-                unsigned long long* o = a.part + ((((size_t)n * tiles + t) * a.G + g) * 64 + tid) * 2;
-                __hip_atomic_store(o, flow_pack2(M, L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(o + 1, flow_pack2(X, Y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            // the slice's state, device-scope write-through: the workgroup that merges may sit on another XCD
+            unsigned long long* o = a.part + ((((size_t)n * tiles + t) * a.S + slice) * 64 + tid) * 2;
+            __hip_atomic_store(o, flow_pack2(M, L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 1, flow_pack2(X, Y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (a.G > 1 && tid < 64) {
+    if (tid < 64) {
+        // every slice state this workgroup owes is stored and drained; with G > 1 the workgroups of a target tile count themselves and the
+        // last one merges (conv_epilogue's hand-off: 8-byte agent-scope atomics on both sides).  The merge runs over the S slices in slice
+        // order, whoever computed them: the same association for every G
         TSNET_DRAIN_VMEM();
         int* counter = a.cnt + b * tiles + t;
-        float arrived = 0.f;
-        if (lane == 0) arrived = (float)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float arrived = (float)(a.G - 1);
+        if (a.G > 1) {
+            arrived = 0.f;
+            if (lane == 0) arrived = (float)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) arrived += __shfl_xor(arrived, off);
+            for (int off = 32; off > 0; off >>= 1) arrived += __shfl_xor(arrived, off);
+        }
         if ((int)arrived == a.G - 1) {
             for (int s_idx = 0; s_idx < a.K; ++s_idx) {
                 const int n = s_idx * a.B + b;
-                const unsigned long long* pp = a.part + (((size_t)n * tiles + t) * a.G * 64 + tid) * 2;
+                const unsigned long long* pp = a.part + (((size_t)n * tiles + t) * a.S * 64 + tid) * 2;
                 float M = -3.0e38f;
-                for (int q = 0; q < a.G; ++q) {
+                for (int q = 0; q < a.S; ++q) {
                     float pm, pl;
                     flow_unpack2(__hip_atomic_load(pp + (size_t)q * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pm, pl);
                     M = pm > M ? pm : M;
                 }
                 float L = 0.f, X = 0.f, Y = 0.f;
-                for (int q = 0; q < a.G; ++q) {
+                for (int q = 0; q < a.S; ++q) {
                     float pm, pl, px, py;
                     flow_unpack2(__hip_atomic_load(pp + (size_t)q * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pm, pl);
                     flow_unpack2(__hip_atomic_load(pp + (size_t)q * 128 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), px, py);
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(64 * kFlowWaves) void flow_kernel_p(FlowArgs a) {
                 f[0] = X / L;
                 f[1] = Y / L;
             }
-            if (lane == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.G > 1 && lane == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

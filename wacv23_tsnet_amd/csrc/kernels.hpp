@@ -25,6 +25,8 @@ void launch_conv_h2r(const ConvArgs& a, int ks, int bn, int nprod, hipStream_t s
 
 // flow_persist.hpp -- flow_kernel_p: a.K, a.G (flowp_plan), a.part, a.cnt set by the caller; variant: tools build only
 void launch_flow_p(const FlowArgs& a, int variant, hipStream_t s);
+// flow_sweep.hpp -- flow_kernel<NT>: NT = 1 or 2 target blocks per workgroup, `grid` workgroups, `lds` = flow_lds_bytes(NT, h, w, C)
+void launch_flow(const FlowArgs& a, int NT, size_t lds, unsigned grid, hipStream_t s);
 
 // dynamic LDS above the default limit needs hipFuncAttributeMaxDynamicSharedMemorySize: set once per (kernel, device), not per launch
 void ensure_dynamic_lds(const void* kernel, size_t bytes);
