@@ -382,3 +382,28 @@ def conv_structured_filter_case(lib, dev, N, H, W, Cin, Cout, kind, kernel=3, no
     _sync(dev)
     yc = nchw(y.cpu()).double()
     return (yc - ref).abs().max().item(), (y32.double() - ref).abs().max().item(), ref.abs().max().item()
+
+
+def conv_w1_odd_slab_case(lib, dev, N=1, H=4, W=32, Cin=48, Cout=64, seed=0):
+    """conv_w1 with an ODD number of 16-channel slabs and a fused InstanceNorm: the last period stages 16 channels past Cin.  They
+    used to be the next pixel's channels 0..15 transformed with the affine of channels 0..3 -- not bounded by the operand bound; beyond
+    fp16's range they became inf, and inf x (zero weights) = NaN reached real outputs.  Here channels 0..3 carry a gain of 1e3 on tiny
+    values (so the layer's bound stays ~1) while the next pixel's channels 16..19 are O(1): the old staging saw 1e3.  Now the lanes past Cin
+    read zeros and the table holds zeros there.  Returns max|d| relative to max|fp64 reference| (NaN-safe: a NaN fails the comparison)."""
+    x = _rand(seed, "x", (N, Cin, H, W))
+    x[:, :4] *= 1e-3
+    al = _rand(seed, "al", (N, Cin), 0.5, 1.5)
+    al[:, :4] = 1e3
+    be = _rand(seed, "be", (N, Cin), -0.3, 0.3)
+    w = _rand(seed, "w", (Cout, Cin, 3, 3)) * (2.0 / (Cin * 9) ** 0.5)
+    xin = F.relu(x * al[:, :, None, None] + be[:, :, None, None])
+    ref = F.conv2d(F.pad(xin.double(), (1,) * 4, mode="reflect"), w.double())
+    bound = float(xin.abs().max()) * 1.0001
+    xd, wd, ald, bed = nhwc(x).to(dev), w.to(dev), al.contiguous().to(dev), be.contiguous().to(dev)
+    y = torch.full((N, H, W, Cout), float("nan"), device=dev)
+    rc = lib.tsnet_op_conv2d(xd.data_ptr(), N, H, W, Cin, wd.data_ptr(), None, Cout, 3, 1, 1, 1, ald.data_ptr(), bed.data_ptr(), 1, bound, 3, 3, 0, y.data_ptr(), None)
+    assert rc == 0, lib.tsnet_op_last_error().decode()
+    _sync(dev)
+    yc = nchw(y.cpu()).double()
+    assert torch.isfinite(yc).all(), "non-finite outputs"
+    return ((yc - ref).abs().max() / ref.abs().max()).item()

@@ -158,8 +158,9 @@ def test_h2_samples_do_not_see_their_batch(emu_lib):
     calm[0][0][1] /= 40.0                                    # the same first sample next to an ordinary neighbour
     rec2b, _ = Hh.run_engine(eng, calm, "cpu", return_flow=False)
     assert torch.equal(rec2[:1], rec2b[:1]) and not torch.equal(rec2[1:], rec2b[1:])
-    # (alone, B = 1, the single-frame tiles run -- two K groups per tile, another association of the same chains: agreement to fp32
-    # rounding, not bit for bit; tests/test_gpu_forward.py::test_single_frame_forward and test_emu_ops.py hold that)
+    # alone (B = 1) too: the forward takes the same kernel, tile and accumulation order in every batch (round 5)
+    one, _ = Hh.run_engine(eng, [[t[:1] for t in x] if isinstance(x, list) else x[:1] for x in calm], "cpu", return_flow=False)
+    assert torch.equal(one, rec2b[:1])
     eng.close()
 
 
@@ -236,6 +237,6 @@ def test_wide_frame_runs_the_feature_resolution_kernels(emu_lib):
     sub = ([x[1:2] for x in inp[0]], [x[1:2] for x in inp[1]], [x[1:2] for x in inp[2]], inp[3][1:2], inp[4][1:2])
     one, _ = Hh.run_engine(eng, sub, "cpu")
     src_one = Hh.nhwc_to_nchw(eng.stage("src_fea", "cpu").cpu())
-    assert (one - rec[1:2]).abs().max().item() < 5e-4
+    assert torch.equal(one, rec[1:2])                     # a frame alone = the same frame in a batch, bit for bit
     assert torch.equal(src_one[0], src_batch[1]) and torch.equal(src_one[1], src_batch[3])       # image index s * B + b
     eng.close()

@@ -202,6 +202,13 @@ def test_conv_w1_chunks_of_tiles_bitwise(emu_lib):
         assert oc.conv_w1_case(emu_lib, "cpu", *args, chunk=chunks[-1], **kw) < REL
 
 
+def test_conv_w1_odd_slab_count_stages_zeros_past_cin(emu_lib):
+    """an odd slab count (Cin = 48, 80) under a fused InstanceNorm whose first channels carry a large gain -- the staging past
+    Cin must be zeros, not another pixel's channels under the wrong affine (inf x 0 = NaN in the MFMA)."""
+    assert oc.conv_w1_odd_slab_case(emu_lib, "cpu", 1, 4, 32, 48, 64) < REL
+    assert oc.conv_w1_odd_slab_case(emu_lib, "cpu", 2, 8, 32, 80, 64, seed=3) < REL
+
+
 def test_conv_w1_worst_case_range_and_structured_filters(emu_lib):
     """The kernel that runs 83 % of the forward's FLOPs (conv_w1, tsnet_op_conv2d(kernel = 3)) under the adversarial dynamic range of the test
     above -- it has one bit less operand head-room than the direct kernel and its output transform subtracts -- and on STRUCTURED filters

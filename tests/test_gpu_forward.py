@@ -113,10 +113,9 @@ def test_cfg0_batch_items_independent(cfg0):
 
 
 def test_single_frame_forward(cfg0):
-    """B = 1, the reference demo's own call (demo_face.py:185-192).  The ResnetBlock / FuseNet layers run the Winograd-along-x kernel in every
-    batch (one packed form per layer: the same bits alone or in a batch); the layers left on the direct kernel take its two-K-group tiles
-    when a launch has at most one tile per CU (total = P0 + P1: another association of the same chains), so a frame run alone agrees
-    with its copy inside a batch to fp32 rounding amplified by the network -- bounded here; run-to-run it is bit-identical."""
+    """B = 1, the reference demo's own call (demo_face.py:185-192).  Every layer runs the same kernel, tile and accumulation order in every
+    batch (round 5: the decoder's second up-convolution moved to the Winograd-along-x kernel and the forward dropped the two-K-group tiles
+    of single-frame launches): a frame run alone is the same BITS as its copy inside a batch, and run-to-run identical."""
     import ctypes
     from wacv23_tsnet_amd import _lib
     eng, inputs, rec, z = cfg0["eng"], cfg0["inputs"], cfg0["rec"], cfg0["z"]
@@ -133,7 +132,7 @@ def test_single_frame_forward(cfg0):
     d_batch = (r1 - rec[sl]).abs().max().item()
     print(f"[cfg0, B=1] d_crop={d_crop:.2e} d_flow={d_flow:.2e} vs the same frame in the batch of 4: {d_batch:.2e}")
     assert d_crop <= TOL_REC and d_flow <= TOL_FLOW
-    assert d_batch <= 5e-4
+    assert torch.equal(r1, rec[sl]) and d_batch == 0.0
     Hh.run_engine(eng, inputs, DEV)                 # leave the engine as the other tests expect it (last_B = 4)
 
 
@@ -273,8 +272,11 @@ BF16_GATES = {
     # 5.4e-3 ...; 99.999 % of the pixels below 4.7e-3) that moves with any change of the decoder's input -- 5.1 / 5.3 / 6.3e-3 on the three
     # draws before flow_kernel_p changed the flows by <= 1e-5, 6.3 / 7.1 / 8.2e-3 after (the forward is bit-deterministic; the MEAN,
     # 1.8-1.9e-4, did not move).  1.33 x the worst.
-    "cfg4": dict(src_fea=0.173, tar_fea=0.0088, sg=0.0426, decoder_on_engine_features=0.011, end_to_end_vs_bf16_oracle_mean=0.1415, decoder_on_engine_features_mean=0.00023),
+    "cfg4": dict(src_fea=0.173, tar_fea=0.0088, sg=0.0426, decoder_on_engine_features=0.011, end_to_end_vs_bf16_oracle_mean=0.1415, decoder_on_engine_features_mean=0.00023,
+                 # the robust form of the decoder gate: 1.25 x the documented 4.7e-3 tail; the maximum above stays as it was frozen in round 4
+                 decoder_on_engine_features_p99999=0.0059),
 }
+# FROZEN: these limits are not re-fitted when a kernel changes.  Widening one needs >= 5 draws and an entry in DESIGN.md section 3.2.
 
 
 # bf16 STORAGE mode (operand_mode 2): against the oracle that rounds operands AND the stored activations at the same points; 1.3 x the worst

@@ -217,6 +217,12 @@ def test_conv_w1_chunks_of_tiles_bitwise(lib):
     assert oc.conv_w1_case(lib, DEV, 12, 32, 32, 512, 512, True, norm=True, chunk=3) < REL
 
 
+def test_conv_w1_odd_slab_count_stages_zeros_past_cin(lib):
+    """odd slab counts under a fused InstanceNorm with a large gain on the first channels: finite, fp32-class results"""
+    assert oc.conv_w1_odd_slab_case(lib, DEV, 1, 4, 32, 48, 64) < REL
+    assert oc.conv_w1_odd_slab_case(lib, DEV, 2, 32, 64, 80, 128, seed=3) < REL
+
+
 def test_conv_w1_worst_case_range_and_structured_filters(lib):
     """conv_w1 -- the kernel of the forward's ResnetBlock / FuseNet / first up-convolution layers, 83 % of its FLOPs -- under the adversarial
     dynamic range of the test above (one bit less operand head-room: |V| <= 2 max|x|; the output transform out[2j+1] = M1 - M2 - M3 forms

@@ -92,6 +92,15 @@ if SEL == "w1c":        # conv_w1: tiles per workgroup (tile code 1, 2, 3; 0 = t
                     ("dec_up0 (512->256 @64^2)", (4, 64, 64, 512, 256, 3, 1, 1, 1)), ("dec_res (B=8: 8 images)", (8, 32, 32, 512, 512, 3, 1, 1, 1))):
         run(nm, shp, [(f"w1 chunk {c}" if c else "w1 launcher's choice", code(c, w1=True)) for c in (1, 2, 3, 0)], norms=(2, 3), iters=18)
     sys.exit(0)
+if SEL == "w1dec":      # the decoder's second and third up-convolutions: direct kernel (the forward's choice in round 4) against conv_w1, B = 4 and one frame
+    for nm, shp in (("dec_up1 (256->128 @128^2) B=4", (4, 128, 128, 256, 128, 3, 1, 1, 1)), ("dec_up2 (128->64 @256^2) B=4", (4, 256, 256, 128, 64, 3, 1, 1, 1)),
+                    ("dec_up1 B=1", (1, 128, 128, 256, 128, 3, 1, 1, 1)), ("dec_up2 B=1", (1, 256, 256, 128, 64, 3, 1, 1, 1)),
+                    ("dec_up1 B=8", (8, 128, 128, 256, 128, 3, 1, 1, 1)), ("dec_up2 B=8", (8, 256, 256, 128, 64, 3, 1, 1, 1))):
+        vs = [("direct, the launcher's tile", code(0, patch=True)), ("w1", code(0, w1=True)), ("w1 chunk 1", code(1, w1=True)), ("w1 chunk 2", code(2, w1=True))]
+        if shp[0] == 1:
+            vs.append(("direct 4x64 deep kg2 (B=1 form)", code(64, opt=24)))
+        run(nm, shp, vs, norms=(2,), iters=12)
+    sys.exit(0)
 if SEL == "chain":      # slabs per accumulation chain: 1, 2 (product), 4; and the ablations of the 4 x 64 tile
     run("res", RES, [("4x64 chain 2 (product)", code(64)), ("4x64 chain 1", code(64, opt=2)), ("4x64 chain 4", code(64, opt=4)),
                      ("4x64 weights 5 ahead", code(64, opt=32)), ("4x64 chain 4 + 5 ahead", code(64, opt=36)), ("2x128 weights 5 ahead", code(2128, opt=32)),

@@ -16,16 +16,23 @@ a = ap.parse_args()
 libs = {"this tree": _lib.load_tools(), os.path.basename(a.lib2): _lib.bind(C.CDLL(a.lib2))}
 torch.zeros(1, device="cuda")
 W1 = 32768
+# (name, (N, H, W, Cin, Cout), norm | stats, variant, launches[, ksize, stride, pad, reflect])
+OTHER = [("stem 7x7 8->64 (12 images)", (12, 256, 256, 8, 64), 2, 0, 8, 7, 1, 3, 1), ("stem 7x7 8->64 (4 images)", (4, 256, 256, 8, 64), 2, 0, 8, 7, 1, 3, 1),
+         ("down1 64->128 s2 (12)", (12, 256, 256, 64, 128), 3, 0, 8, 3, 2, 1, 0), ("down2 128->256 s2 (12)", (12, 128, 128, 128, 256), 3, 0, 8, 3, 2, 1, 0),
+         ("down3 256->512 s2 (12)", (12, 64, 64, 256, 512), 3, 0, 8, 3, 2, 1, 0), ("dec_up2 128->64 @256^2 (4)", (4, 256, 256, 128, 64), 2, 0, 8, 3, 1, 1, 1),
+         ("1x1 1024->512 (4)", (4, 32, 32, 1024, 512), 0, 0, 8, 1, 1, 0, 0)]
 cases = [("res IN+ReLU+stats, 8 launches", (12, 32, 32, 512, 512), 3, W1, 8), ("res IN+ReLU+stats, 24 launches", (12, 32, 32, 512, 512), 3, W1, 24),
          ("res IN+ReLU+stats, 24 launches, cold weights", (12, 32, 32, 512, 512), 3, W1 | (1 << 21), 24),
          ("res raw+stats, 24 launches, cold weights", (12, 32, 32, 512, 512), 2, W1 | (1 << 21), 24),
          ("fuse_c2 IN+ReLU+stats, 8 launches", (12, 32, 32, 1024, 1024), 3, W1, 8)]
-for name, (N, H, W, Ci, Co), nrm, var, iters in cases:
+for case in cases + OTHER:
+    name, (N, H, W, Ci, Co), nrm, var, iters = case[:5]
+    ks, st, pd, rf = case[5:] if len(case) > 5 else (3, 1, 1, 1)
     res = {k: [] for k in libs}
     for r in range(a.rounds):
         for k, lib in libs.items():
             ms = C.c_float()
-            rc = lib.tsnet_bench_conv(N, H, W, Ci, Co, 3, 1, 1, 1, nrm, var, iters, C.byref(ms), None)
+            rc = lib.tsnet_bench_conv(N, H, W, Ci, Co, ks, st, pd, rf, nrm, var, iters, C.byref(ms), None)
             res[k].append(ms.value * 1e3 if rc == 0 else float("nan"))
     print(f"{name:50s} " + "   ".join(f"{k}: {statistics.median(v):7.1f} us" for k, v in res.items()), flush=True)
 inp = synth.inputs(3, 2, 4, 256, 256, seed=1)

@@ -4,7 +4,8 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch; on gfx950 FETCH_SIZE u
 2x (MI355X_MICROARCH.md, HBM section): fetch_MB_corrected = 2 x raw.  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES /
 (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); the wait/active columns are fractions of SQ_WAVE_CYCLES.
 clock_GHz = (GRBM_GUI_ACTIVE / 8 XCDs) / the kernel's average duration in the kernel-trace pass of the same command (<prof_dir>/trace):
-the effective shader clock while the kernel runs (DVFS: MI355X_MICROARCH.md, "DVFS give-back")."""
+the effective shader clock while the kernel runs (DVFS: MI355X_MICROARCH.md, "DVFS give-back").  Printed only for kernels of >= 30 us: below
+that GRBM_GUI_ACTIVE also counts the dispatch's ramp and drain and the quotient is meaningless (3 - 7 "GHz" on 5 us kernels: VERDICT r4)."""
 import collections, glob, os, re, sqlite3, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from src_digest import digest
@@ -40,6 +41,7 @@ def durations(dbdir):
 
 d = sys.argv[1]
 fetch, write, sq = load(os.path.join(d, "fetch")), load(os.path.join(d, "write")), load(os.path.join(d, "sq"))
+sq2 = load(os.path.join(d, "sq2"))
 dur = durations(os.path.join(d, "trace"))
 print("# source_digest: %s" % digest())
 avg = lambda v: sum(v) / len(v) if v else 0.0
@@ -56,6 +58,17 @@ for k in sorted(sq, key=lambda k: -sum(sq[k].get("GRBM_GUI_ACTIVE", [0]))):
     c = sq[k]; g = avg(c.get("GRBM_GUI_ACTIVE", [])); wc = avg(c.get("SQ_WAVE_CYCLES", [])) or 1.0
     if g <= 0: continue
     t = dur.get(k, 0.0)
-    print("%-36s %8d %10.3f %10.3f %10.3f %10.3f %12.0f %10.1f %10.2f" % (k, len(c.get("GRBM_GUI_ACTIVE", [])), avg(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [])) / (1024.0 * g / 8.0),
+    print("%-36s %8d %10.3f %10.3f %10.3f %10.3f %12.0f %10.1f %10s" % (k, len(c.get("GRBM_GUI_ACTIVE", [])), avg(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [])) / (1024.0 * g / 8.0),
           avg(c.get("SQ_WAIT_ANY", [])) / wc, avg(c.get("SQ_WAIT_INST_ANY", [])) / wc, avg(c.get("SQ_ACTIVE_INST_ANY", [])) / wc, avg(c.get("SQ_LDS_BANK_CONFLICT", [])),
-          t / 1e3, (g / 8.0) / t if t > 0 else 0.0))
+          t / 1e3, ("%.2f" % ((g / 8.0) / t)) if t >= 30e3 else "-"))
+
+if sq2:
+    # instruction mix per launch (the second SQ pass): conv_w1's K loop is bound by instruction ISSUE -- the SIMD hides ~5 issue slots behind an
+    # MFMA (MI355X_MICROARCH.md) -- so the non-MFMA instructions per MFMA are the figure to watch, not only mfma_util
+    print()
+    print("%-36s %8s %12s %12s %12s %12s %12s %14s" % ("kernel", "launches", "insts_mfma", "insts_valu", "insts_salu", "insts_lds", "insts_vmem", "non-mfma/mfma"))
+    for k in sorted(sq2, key=lambda k: -sum(sq2[k].get("SQ_INSTS_MFMA", [0]))):
+        c = sq2[k]; m = avg(c.get("SQ_INSTS_MFMA", []))
+        if m <= 0: continue
+        v = avg(sq.get(k, {}).get("SQ_INSTS_VALU", [])); sa = avg(c.get("SQ_INSTS_SALU", [])); l = avg(c.get("SQ_INSTS_LDS", [])); vm = avg(c.get("SQ_INSTS_VMEM", []))
+        print("%-36s %8d %12.0f %12.0f %12.0f %12.0f %12.0f %14.2f" % (k, len(c.get("SQ_INSTS_MFMA", [])), m, v - m if v > m else v, sa, l, vm, ((v - m if v > m else v) + sa + l + vm) / m))

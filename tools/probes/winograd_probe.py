@@ -134,6 +134,48 @@ def run(seed, C=512, Co=64, H=32, W=32):
         y = np.stack([y0, y1], axis=-1).reshape(H, tw, Co, 2).transpose(2, 0, 1, 3).reshape(Co, H, W)
         e = np.abs(y.astype(f64) - ref)
         out[nm] = (e.mean() / rmax, e.max() / rmax)
+    # ---- Winograd F(4, 3) along x: six products per four outputs = HALF the direct form's, 3/4 of F(2,3)'s.  Interpolation
+    # points 0, +-1, +-2, inf (Lavin & Gray): B^T has entries up to 5, A^T up to 8, G down to 1/24 -- the transform's own conditioning is what
+    # is being measured.  Same rules as the 1-D form above: input transform on the fp32 activation BEFORE the split (three adds / multiplies
+    # per value, each rounded to fp32), filter transform in fp64 at pack time, chains of two slabs, output transform in fp32.
+    Bt4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], f64)
+    G4 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], f64)
+    At4 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], f64)
+    tq = W // 4
+    dx4 = np.stack([xp[:, :, j:j + 4 * tq:4] for j in range(6)], axis=-1)                                          # [C, H+2, tq, 6]: columns 4 q - 1 + j
+    # every entry of B^T d is a sum of up to four terms: evaluated left to right in fp32 (each partial sum rounded), as a kernel would
+    V4 = np.zeros(dx4.shape[:3] + (6,), f32)
+    for p_ in range(6):
+        acc4 = np.zeros(dx4.shape[:3], f32)
+        for i in range(6):
+            if Bt4[p_, i]:
+                acc4 = (acc4.astype(f64) + Bt4[p_, i] * dx4[..., i].astype(f64)).astype(f32)
+        V4[..., p_] = acc4
+    U4 = np.einsum("pj,ocyj->ocyp", G4, w.astype(f64))
+    sv, su = scale_for(np.abs(V4).max()), scale_for(np.abs(U4).max())
+    Vh, Vl = split16((V4 * f32(sv)).astype(f32))
+    Uh, Ul = split16((U4 * su).astype(f32))
+    for nm, cg in (("winograd F(4,3) along x, chains of 2 slabs", 6), ("winograd F(4,3) along x, one chain", 0)):
+        M4 = np.zeros((H * tq, Co, 6), f32)
+        for p_ in range(6):
+            Ah = np.concatenate([Vh[:, ky:ky + H, :, p_].reshape(C, -1).T for ky in range(3)], axis=1)
+            Al = np.concatenate([Vl[:, ky:ky + H, :, p_].reshape(C, -1).T for ky in range(3)], axis=1)
+            Bh = np.concatenate([Uh[:, :, ky, p_].T for ky in range(3)], axis=0)
+            Bl = np.concatenate([Ul[:, :, ky, p_].T for ky in range(3)], axis=0)
+            g1 = [np.arange(ky * C + s * 16, ky * C + s * 16 + 16) for s in range(C // 16) for ky in range(3)]
+            M4[:, :, p_] = mfma_chain(Ah, Al, Bh, Bl, g1, cg)
+        M4 = (M4.astype(f64) / (sv * su)).astype(f32)
+        ys = []
+        for o_ in range(4):
+            acc4 = np.zeros(M4.shape[:2], f32)
+            for p_ in range(6):
+                if At4[o_, p_]:
+                    acc4 = (acc4.astype(f64) + At4[o_, p_] * M4[:, :, p_].astype(f64)).astype(f32)
+            ys.append(acc4)
+        y = np.stack(ys, axis=-1).reshape(H, tq, Co, 4).transpose(2, 0, 1, 3).reshape(Co, H, W)
+        e = np.abs(y.astype(f64) - ref)
+        out[nm] = (e.mean() / rmax, e.max() / rmax)
+    out["(operand range: max|V| / max|x|  F(2,3) / F(4,3))"] = (float(np.abs(V1).max() / np.abs(x).max()), float(np.abs(V4).max() / np.abs(x).max()))
     return out
 
 
@@ -146,5 +188,8 @@ if __name__ == "__main__":
     base = np.mean([m for m, _ in rows["direct, chains of 2 slabs (product)"]])
     print(f"{'variant':44s} {'mean|err|/max|ref|':>20s} {'max|err|/max|ref|':>20s}   x direct(mean)")
     for k, v in rows.items():
+        if k.startswith("("):
+            print(f"{k:44s} {np.mean([a for a, _ in v]):20.3f} {np.mean([b for _, b in v]):20.3f}")
+            continue
         m, x = np.mean([a for a, _ in v]), np.max([b for _, b in v])
         print(f"{k:44s} {m:20.3e} {x:20.3e}   {m / base:6.2f}")

@@ -217,11 +217,10 @@ __device__ __forceinline__ void split_h2(float v, unsigned& hi, unsigned& lo) {
 // eight consecutive channels (two float4, already scaled) -> one 16-byte octet per plane
 __device__ __forceinline__ void split_h2_octet(const F4& x0, const F4& x1, F4& H, F4& L) {
     unsigned hw[4], lw[4];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        TSNET_SPLIT_PAIR(x0.v[2 * e], x0.v[2 * e + 1], hw[e], lw[e]);
-        TSNET_SPLIT_PAIR(x1.v[2 * e], x1.v[2 * e + 1], hw[2 + e], lw[2 + e]);
-    }
+    // two pairs per statement: six instructions, no wait state (the per-pair form costs an s_nop each -- four issue slots per octet in the
+    // staging code of every MFMA wave: 20 - 38 s_nop per K-loop iteration of conv_h2 / conv_h2d, tools/isa_mix.py)
+    TSNET_SPLIT_2PAIRS(x0.v[0], x0.v[1], x0.v[2], x0.v[3], hw[0], lw[0], hw[1], lw[1]);
+    TSNET_SPLIT_2PAIRS(x1.v[0], x1.v[1], x1.v[2], x1.v[3], hw[2], lw[2], hw[3], lw[3]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { H.v[e] = __builtin_bit_cast(float, hw[e]); L.v[e] = __builtin_bit_cast(float, lw[e]); }
 }

@@ -410,10 +410,21 @@ __device__ __forceinline__ void h2s_tile(const ConvArgs& a, unsigned char* smem_
     // per-lane address of step st: slot of tap 2 st for lh = 0; for lh = 1 the next tap = one slot right, or the first slot of the next patch
     // row when tap 2 st ends its row, or (last step: the 50th tap does not exist, its weights are zero) the same slot again
     const int base = (wrow * MT * PC + li) * 16;
+    // (slot offset of tap 2 st, and how far its partner tap 2 st + 1 lies) per step: a table in constant memory, read with scalar loads --
+    // the loop over the chains is rolled, and deriving tap row and column of a runtime step (t0 / 7, t0 % 7) cost 84 scalar instructions per
+    // iteration beside 36 MFMAs (tools/isa_mix.py): every one an issue slot the MFMAs did not get
+    struct StepTab { int off[25], delta[25]; };
+    static constexpr StepTab kStep = [] {
+        StepTab t{};
+        for (int st = 0; st < 25; ++st) {
+            const int t0 = 2 * st, ky = t0 / 7, kx = t0 - ky * 7;
+            t.off[st] = (ky * PC + kx) * 16;
+            t.delta[st] = st >= 24 ? 0 : (kx == 6 ? (PC - 6) * 16 : 16);
+        }
+        return t;
+    }();
     auto load_a = [&](int set, int st) __attribute__((always_inline)) {
-        const int t0 = 2 * st, ky = t0 / 7, kx = t0 - ky * 7;        // wave-uniform
-        const int delta = st >= 24 ? 0 : (kx == 6 ? (PC - 6) * 16 : 16);
-        const unsigned char* b = smem_raw + base + (ky * PC + kx) * 16 + lh * delta;
+        const unsigned char* b = smem_raw + base + kStep.off[st] + lh * kStep.delta[st];      // st: wave-uniform
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll

@@ -13,12 +13,10 @@
 //   dec map 1x1 (cat on load) -> ResnetBlocks -> 3x (upsample, conv) -> 7x7+tanh [A8, A9]
 // Every convolution reads the producer's RAW fp32 output and applies that producer's InstanceNorm + ReLU while it stages its operand
 // tile; operands enter the matrix pipe as fp16 x 2 splits (three products) or, with tsnet_cfg.operand_mode = 1, as one bf16 plane.
-// Which kernel a layer runs on (the Winograd-along-x kernel of conv_w1.hpp for the ResnetBlock / FuseNet / first up-convolution layers and
-// the patch kernels of conv_h2.hpp where the output splits into 4 x 32 rectangles, the general implicit GEMM of conv_h2r.hpp elsewhere)
-// depends on the layer and the frame size only -- never on the batch, never on the environment.  The TILE a direct patch kernel takes
-// does depend on the batch in one case: a forward of ONE frame (B = 1) runs launches of at most a tile per CU as two K groups, another
-// association of the same chains -- a frame run alone agrees with its copy inside a batch to fp32 rounding on those layers, bit for bit
-// on every other one and in any two batches of >= 2 frames (tests/test_gpu_forward.py::test_single_frame_forward).
+// Which kernel a layer runs on (the Winograd-along-x kernel of conv_w1.hpp for the ResnetBlock / FuseNet layers and the first two
+// up-convolutions, the patch kernels of conv_h2.hpp where the output splits into 4 x 32 rectangles, the general implicit GEMM of
+// conv_h2r.hpp elsewhere) and which tile it takes depend on the layer and the frame size only -- never on the batch, never on the
+// environment: a frame's result is the same bits alone (B = 1) and in any batch (tests/test_gpu_forward.py::test_single_frame_forward).
 // InstanceNorm statistics: fp64 partial sums in the producing conv's epilogue, finalised there by the last-arriving workgroup
 // (or by in_finalize2 when an image has many tiles).
 #include <hip/hip_runtime.h>
@@ -199,7 +197,6 @@ struct ConvCall {
     int tile = 0;               // 0 = heuristic; else rows * 1000 + width of the patch tile (32, 64, 128 = 4 rows; 2128 = 2 x 128; + 20000 = its
                                 // two-K-group form, 4 x 32 and 4 x 64 only), or 64 / 128 for the others
     int abl = 0, opt = 0;       // tools build: ablation / experiment masks of h2_tile
-    bool single_frame = false;  // the forward runs ONE frame (B = 1): launches of at most a tile per CU take the two-K-group tiles
     int xcd_gn = -1;            // -1 = the launcher's choice; 0 = consecutive tiles per XCD; 1, 2, 4, 8 = XCD grid columns over the N tiles (tile_of_block)
     int tclass = TSNET_T_CONV;
 };
@@ -346,19 +343,17 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
                 // fused transform, 1.03x with it; the 384-tile ResnetBlock layers at batch 4 are the case where 768 64-wide tiles = exactly
                 // three per CU win.  Small M (one driving frame: the decoder's ResnetBlocks are 64 tiles of 128 x 64 on 256 CUs): 32-wide
                 // tiles double the number of workgroups; each stages the same patch but runs half the MFMA chain.
-                const long tm = (long)c.N * (hw / 128), t64 = tm * ((g.Cout + 63) / 64);
+                const long tm = (long)c.N * (hw / 128);
                 bn = wide_pays(tm, c.alpha ? 1.03 : 1.10) ? 128 : 64;
                 // bf16 operands: one product per step -- the 64-wide tile is latency-bound (mfma_util 0.19, 81 % of the wave cycles
                 // waiting at configs[4]); the 128-wide one runs three workgroups per CU as well (no second accumulator level) and wins
                 // whenever it still fills the chip
                 if (bf16 && g.Npad % 128 == 0 && g.Cout > 64 && tm * ((g.Cout + 127) / 128) >= 256) bn = 128;
-                // A forward of ONE frame (B = 1), launches of at most one 64-wide tile per CU: no co-resident workgroup hides a load.  The
-                // tile then runs as eight waves -- two K groups of four, each folding the chains of every other slab, weights eight steps
-                // ahead -- and, up to 128 tiles, in its 32-wide shape, which doubles the workgroups: 67 -> 54 us on the 192-tile ResnetBlock
-                // layers, 60 -> 38 us on the decoder's ResnetBlocks of one frame (profiles/round3_small_batch.txt).  total = P0 + P1 is
-                // another association of the same chains: results agree with the one-group tiles to fp32 rounding, not bit for bit -- a
-                // frame run alone and the same frame inside a batch differ in the last bits; any two batches of >= 2 frames do not.
-                if (c.single_frame && t64 <= 256 && c.nprod != 4 && !c.abl && !opt && (L.cin_pad >> 4) % 2 == 0) { opt = 24; bn = t64 <= 128 ? 32 : 64; }
+                // (Round 3 gave a forward of ONE frame two-K-group tiles here -- eight waves, total = P0 + P1: another association of the same
+                // chains, so a frame run alone differed from its copy inside a batch in the last bits.  Since round 5 every layer that form
+                // paid on runs conv_w1 in every batch (the decoder's second up-convolution included: 29.7 against 34.0 us for one frame, equal
+                // at B = 4), and the forward no longer takes it: a frame's bits do not depend on its batch, B = 1 included.  The tile codes
+                // 20032 / 20064 stay available to tsnet_op_conv2d.)
             }
             if ((pr != 2 && pr != 4) || g.Ho % pr) throw ArgError("conv(h2): the output height must be a multiple of the tile's rows (2 or 4)");
             if (g.Npad % bn) throw ArgError("conv(h2): the tile width must divide the padded output width");
@@ -651,6 +646,7 @@ struct tsnet_engine {
     int cached_B = 0;
     float* bbox_copy = nullptr;     // (K, Bmax, H, W) device copies of the source bboxes
     int last_B = 0;
+    hipStream_t last_stream = nullptr;    // the caller's stream of the last forward (tsnet_stage_ptr orders its widening pass behind it)
     int cur_B = 0;                        // batch of the forward being enqueued
     float src_div[TSNET_MAX_SOURCES];  // per-source image divisor (255; 1 for use_prev sources), tsnet_set_source_divisors
 
@@ -679,7 +675,7 @@ struct tsnet_engine {
     }
     float enc_bound() const { return (float)(cfg.enc_blocks + 1) * std::sqrt((float)P); }  // bound of the source features: |relu(IN)| <= sqrt(P), + one IN output per block
     // every convolution of the forward goes through here: the engine's operand mode, the lane's statistics scratch, the finalize
-    void conv(Ctx& ctx, const ConvLayer& L, ConvCall& c) { c.nprod = np; c.single_frame = cur_B == 1; run_conv(ctx, L, c); }
+    void conv(Ctx& ctx, const ConvLayer& L, ConvCall& c) { c.nprod = np; run_conv(ctx, L, c); }
     void conv_stats(Ctx& ctx, const ConvLayer& L, ConvCall& c, int N, int HW, float* alpha, float* beta) {
         double* pt = ctx.lane ? part_side : part;
         c.stat_part = pt;
@@ -759,6 +755,7 @@ void tsnet_engine::build_layers() {
     to_w1(fuse_c1_src, h, w); to_w1(fuse_c1_tar, h, w); to_w1(fuse_c2, h, w);
     for (auto& L : dec_res) to_w1(L, h, w);
     if (!dec_up.empty()) to_w1(dec_up[0], 2 * h, 2 * w);
+    if (dec_up.size() > 1) to_w1(dec_up[1], 4 * h, 4 * w);      // equal at B = 4 (102.7 against 103.4 us), 29.7 against 34 us for one frame; the third (256^2 x 128 -> 64) stays direct: 118 against 140 us
     for (auto& L : img_enc) all_layers.push_back(&L);
     for (auto& L : lbl_enc) all_layers.push_back(&L);
     all_layers.push_back(&fuse_c1_src); all_layers.push_back(&fuse_c1_tar);
@@ -1088,7 +1085,7 @@ void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb,
         for (int c = 0; c < 3; ++c) ha.bg[c] = (-cfg.pose_mean[c]) / 255.0f;             // TSNet_pose.py:276
         launch_head(ha, hh, ww, B, ctx.stream);
     }
-    last_B = B;
+    last_B = B; last_stream = ctx.stream;
 }
 
 // ================================================================================================
@@ -1335,9 +1332,11 @@ int tsnet_stage_ptr(tsnet_handle h, const char* name, const float** dev_ptr, siz
         const int i = n[6] - '0';        // raw output of the i-th decoder up-convolution (before its InstanceNorm)
         p = h->R[i]; c = B * ((size_t)(h->h << (i + 1)) * (h->w << (i + 1)) * (h->C >> (i + 1)));
         if (h->st16) {                   // stored as bf16: widened into the (now idle, twice as large) upsampled-input buffer of the same level
-            hipLaunchKernelGGL(bf16_widen_kernel, dim3(ew_grid(c)), dim3(256), 0, nullptr, reinterpret_cast<const unsigned short*>(h->R[i]), h->U[i], c);
+            // on the stream of the last forward: ordered behind it, and ahead of a forward started next on that stream -- the engine's
+            // streams are non-blocking, the NULL stream orders nothing against them
+            hipLaunchKernelGGL(bf16_widen_kernel, dim3(ew_grid(c)), dim3(256), 0, h->last_stream, reinterpret_cast<const unsigned short*>(h->R[i]), h->U[i], c);
             check_launch("bf16_widen");
-            HIP_TRY(hipStreamSynchronize(nullptr));
+            HIP_TRY(hipStreamSynchronize(h->last_stream));
             p = h->U[i];
         }
     }

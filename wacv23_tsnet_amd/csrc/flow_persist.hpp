@@ -166,9 +166,17 @@ __global__ __launch_bounds__(64 * kFlowWaves) void flow_kernel_p(FlowArgs a) {
             for (; gg + 3 <= ngrp; gg += 3) { group(gg, 0); group(gg + 1, 1); group(gg + 2, 2); }
             if (gg < ngrp) group(gg, 0);
             if (gg + 1 < ngrp) group(gg + 1, 1);
+#if defined(TSNET_FLOWP_PROBE) && (TSNET_FLOWP_PROBE & 1)
+            // tools/probes/slp_probe_*.py: idle states between the last MFMA and the first VALU read of its accumulators
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
 
             ms_w[lane] = msl;                 // the wave's own row: the LDS operations of one wave execute in order
             TSNET_WAVE_SYNC();
+#if defined(TSNET_FLOWP_PROBE) && (TSNET_FLOWP_PROBE & 2)
+            // ... or: everything outstanding (LDS, memory) landed, then idle states, before the packed arithmetic of the epilogue
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
             // D[row = source][col = target]: lane owns target li of each block, source rows i*32 + 8*q + e + 4*lh (r = 4 q + e): four
             // consecutive sources per (i, q)
             float mx[NT];
