@@ -101,6 +101,11 @@ if SEL == "w1dec":      # the decoder's second and third up-convolutions: direct
             vs.append(("direct 4x64 deep kg2 (B=1 form)", code(64, opt=24)))
         run(nm, shp, vs, norms=(2,), iters=12)
     sys.exit(0)
+if SEL == "w1x":        # conv_w1 on the ResnetBlock layer: XCD grids over the tile matrix, warm and cold weights (a fresh copy of the planes per launch)
+    for cold in (False, True):
+        run("res (12 images)" + (", cold weights" if cold else ""), RES, [("w1 linear", code(0, w1=True, xcd=0, cold=cold))] + [(f"w1 grid x{g}", code(0, w1=True, xcd=g, cold=cold)) for g in (2, 4, 8)], norms=(2, 3), iters=24)
+    run("fuse_c1_src (512->1024)", (12, 32, 32, 512, 1024, 3, 1, 1, 1), [("w1 launcher", code(0, w1=True))] + [(f"w1 grid x{g}", code(0, w1=True, xcd=g)) for g in (0, 2, 4, 8)], norms=(2,), iters=12)
+    sys.exit(0)
 if SEL == "chain":      # slabs per accumulation chain: 1, 2 (product), 4; and the ablations of the 4 x 64 tile
     run("res", RES, [("4x64 chain 2 (product)", code(64)), ("4x64 chain 1", code(64, opt=2)), ("4x64 chain 4", code(64, opt=4)),
                      ("4x64 weights 5 ahead", code(64, opt=32)), ("4x64 chain 4 + 5 ahead", code(64, opt=36)), ("2x128 weights 5 ahead", code(2128, opt=32)),

@@ -119,7 +119,7 @@ def run(seed, C=512, Co=64, H=32, W=32):
     sv, su = scale_for(np.abs(V1).max()), scale_for(np.abs(U1).max())
     Vh, Vl = split16((V1 * f32(sv)).astype(f32))
     Uh, Ul = split16((U1 * su).astype(f32))
-    for nm, cg in (("winograd 1-D (x), chains of 2 slabs", 6), ("winograd 1-D (x), one chain", 0)):
+    for nm, cg in (("winograd 1-D (x), chains of 2 slabs", 6), ("winograd 1-D (x), chains of 4 slabs", 12), ("winograd 1-D (x), one chain", 0)):
         M1 = np.zeros((H * tw, Co, 4), f32)
         for p_ in range(4):
             Ah = np.concatenate([Vh[:, ky:ky + H, :, p_].reshape(C, -1).T for ky in range(3)], axis=1)             # [H*tw, 3C]

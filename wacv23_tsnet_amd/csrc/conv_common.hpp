@@ -335,8 +335,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
             // Arrival counter per (image, channel tile).  Hand-off form (MI355X_MICROARCH.md, "valid forms"): 8-byte agent-scope atomics
             // on BOTH sides (write-through sc1 stores above, sc1 loads below: never served from a stale L1 / another XCD's L2), every
             // storing wave's stores drained before the workgroup counts itself.  The drain is inline asm on purpose: the compiler may drop
-            // a builtin s_waitcnt it can prove redundant.  The workgroup that reads fin_S - 1 sums the partials in in_finalize2_kernel's
-            // order (four interleaved groups, then g0+g1+g2+g3): bit-identical to the separate kernel, run-to-run deterministic.
+            // a builtin s_waitcnt it can prove redundant.  The workgroup that reads fin_S - 1 sums the partials in a fixed order
+            // (four interleaved groups, then g0+g1+g2+g3): run-to-run deterministic.  (Which of the two finalize paths a layer takes depends on
+            // its tiles per image alone, never on the batch.)
             const int S = a.fin_S;
             const int img = (int)(stat_tile / (size_t)S);
             int* counter = a.fin_counter + (size_t)img * ((a.Npad + 31) / 32) + n0 / 32;   // 32 = narrowest tile
