@@ -146,10 +146,9 @@ __global__ void in_finalize_kernel(const double* __restrict__ part, float* __res
 }
 
 // stage 2 for many partials (conv-epilogue statistics: S = tiles per image, up to 1024):
-// block = (image n, 4 channels); 64 thread groups split the S partials (group g takes s = g, g + 64, ...: at most 8 of the 512 of a 256^2
-// layer, all in flight at once), fixed-order LDS combine.  (Round 4 ran 16 groups of 16 channels: 32 dependent rounds of loads per thread and
-// only 48 workgroups on the 7 x 7 stem -- 13.8 us per launch in the trace, nine launches per forward, for a few hundred KB of partials.)
-constexpr int kFin2Ch = 4, kFin2Groups = 64;
+// block = (image n, 16 channels); 16 thread groups split the S partials (group g takes s = g, g + 16, ...), fixed-order LDS combine.
+// (Four groups of 64 channels left 12 workgroups walking 128 dependent additions each on the 7 x 7 stem: 16 us of latency per launch.)
+constexpr int kFin2Ch = 16, kFin2Groups = 16;
 __global__ __launch_bounds__(256) void in_finalize2_kernel(const double* __restrict__ part, float* __restrict__ alpha,
                                                             float* __restrict__ beta, int C, int S, int HW, float eps) {
     __shared__ double red[256 * 2];
