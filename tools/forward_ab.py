@@ -16,6 +16,7 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--knob", type=int, default=0)
 ap.add_argument("--values", default="3,1")
+ap.add_argument("--operands", default="fp32", help="fp32 | bf16 | bf16s (tsnet_cfg.operand_mode)")
 ap.add_argument("--lib2", default=None)
 ap.add_argument("--reps", type=int, default=6, help="engine instantiations per build (--lib2)")
 a = ap.parse_args()
@@ -24,7 +25,7 @@ vals = [int(v) for v in a.values.split(",")]
 inp = synth.inputs(3, 2, a.batch, 256, 256, seed=1)
 si, sl, sb, tl, tb = [[t.cuda() for t in x] if isinstance(x, list) else x.cuda() for x in inp]
 if not a.lib2:
-    eng = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=3, height=256, width=256, max_batch=a.batch, lib=lib)
+    eng = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=3, height=256, width=256, max_batch=a.batch, operands=a.operands, lib=lib)
     eng.load_state_dict(synth.state_dict(eng.param_shapes(), seed=0)); eng.finalize("cuda")
     step = lambda: eng.forward(si, sl, sb, tl, tb)[0]
 outs, res = {}, {v: [] for v in vals}
@@ -53,7 +54,7 @@ if a.lib2:
         order = names if rep % 2 == 0 else names[::-1]
         es = {}
         for k in order:
-            e = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=3, height=256, width=256, max_batch=a.batch, lib=libs2[k])
+            e = TSNetEngine(label_nc=2, n_blocks=a.n_blocks, n_downsampling=3, n_source=3, height=256, width=256, max_batch=a.batch, operands=a.operands, lib=libs2[k])
             e.load_state_dict(synth.state_dict(e.param_shapes(), seed=0)); e.finalize("cuda")
             es[k] = e
         r2 = {k: [] for k in names}

@@ -20,7 +20,9 @@ W1 = 32768
 OTHER = [("stem 7x7 8->64 (12 images)", (12, 256, 256, 8, 64), 2, 0, 8, 7, 1, 3, 1), ("stem 7x7 8->64 (4 images)", (4, 256, 256, 8, 64), 2, 0, 8, 7, 1, 3, 1),
          ("down1 64->128 s2 (12)", (12, 256, 256, 64, 128), 3, 0, 8, 3, 2, 1, 0), ("down2 128->256 s2 (12)", (12, 128, 128, 128, 256), 3, 0, 8, 3, 2, 1, 0),
          ("down3 256->512 s2 (12)", (12, 64, 64, 256, 512), 3, 0, 8, 3, 2, 1, 0), ("dec_up2 128->64 @256^2 (4)", (4, 256, 256, 128, 64), 2, 0, 8, 3, 1, 1, 1),
-         ("1x1 1024->512 (4)", (4, 32, 32, 1024, 512), 0, 0, 8, 1, 1, 0, 0)]
+         ("1x1 1024->512 (4)", (4, 32, 32, 1024, 512), 0, 0, 8, 1, 1, 0, 0),
+         ("bf16: res 512->512 (24 images)", (24, 32, 32, 512, 512), 3, 8192, 8, 3, 1, 1, 1), ("bf16: dec_up1 256->128 @128^2 (8)", (8, 128, 128, 256, 128), 2, 8192, 8, 3, 1, 1, 1),
+         ("bf16: dec_up2 128->64 @256^2 (8)", (8, 256, 256, 128, 64), 2, 8192, 8, 3, 1, 1, 1), ("bf16: down2 128->256 s2 (24)", (24, 128, 128, 128, 256), 3, 8192, 8, 3, 2, 1, 0)]
 cases = [("res IN+ReLU+stats, 8 launches", (12, 32, 32, 512, 512), 3, W1, 8), ("res IN+ReLU+stats, 24 launches", (12, 32, 32, 512, 512), 3, W1, 24),
          ("res IN+ReLU+stats, 24 launches, cold weights", (12, 32, 32, 512, 512), 3, W1 | (1 << 21), 24),
          ("res raw+stats, 24 launches, cold weights", (12, 32, 32, 512, 512), 2, W1 | (1 << 21), 24),

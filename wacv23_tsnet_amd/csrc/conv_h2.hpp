@@ -157,12 +157,18 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
     F4 ar[NRW][NPL], bf[BD][NPL][NTL];                               // [patch row][plane], [register set][plane][tile]
     auto tap_of = [](int s) __attribute__((always_inline)) { return (s % 3) * 3 + s / 3; };
-    auto load_b = [&](int set, int cc, int s) __attribute__((always_inline)) {     // past the end of K the descriptor returns zeros
-        const int kc = tap_of(s) * ncc + slab_of(cc);
+    // Weight fragment of (tap, slab): byte offset ((tap * ncc + slab) * Npad + n0 + 32 j) * 32 = tap * wT + slab * wB + n0 * 32 + 1024 j.  The K
+    // loop keeps the running offset of its current slab (`wsl`, + KG slabs per iteration) and adds compile-time multiples of wT / wB per
+    // step: re-deriving it per step cost ~5 scalar instructions each -- 96 SALU beside the 72 MFMAs of a bf16 slab pair (tools/isa_mix.py),
+    // in a loop that is bound by instruction issue.
+    const int wB = a.Npad * 32, wT = ncc * wB;
+    int wsl = slab_of(0) * wB + n0 * 32;
+    auto load_b = [&](int set, int dslab, int s) __attribute__((always_inline)) {     // dslab: 0 = the loop's current slab, 1 = the one behind it; past the end of K the descriptor returns zeros
+        const int soff = wsl + dslab * KG * wB + tap_of(s) * wT;
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0 + j * 32) * 32));
+            for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB + j * 1024u, (unsigned)soff);      // (+ 1024 j rides in the instruction's immediate offset)
     };
     const unsigned char* abase = gbase + lh * REGION + (wrow * MT * PC + li) * 16;
     auto load_row = [&](int r, int par, int kx) __attribute__((always_inline)) {
@@ -200,7 +206,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
         const int kx = s / 3, ky = s % 3;
         const bool fresh = !ONE_LEVEL && first;
         const int s2 = (s + BD - 1) % 9;
-        if (!(HABL & 2)) load_b((par * 9 + s + BD - 1) % BD, cc + (s + BD - 1 >= 9 ? 1 : 0), s2);
+        if (!(HABL & 2)) load_b((par * 9 + s + BD - 1) % BD, s + BD - 1 >= 9 ? 1 : 0, s2);
         if (!(HABL & 4)) {
             if (ky < 2) load_row(ky + MT, par, kx);
             if (kx < 2 && ky == 1) {
@@ -247,6 +253,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
         }
 #pragma unroll
         for (int s = 0; s < 9; ++s) step(cc, par, s, open && s == 0, close && s == 8);
+        wsl += KG * wB;
     };
 
     // prologue: patch of slab 0, weight fragments of the first BD - 1 steps
@@ -612,12 +619,14 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     // ---- fragments
     const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
     F4 af[2][NPL][MT], bf[3][NPL][NTL];
-    auto load_b = [&](int set, int cc, int t) __attribute__((always_inline)) {
-        const int kc = t * ncc + cc;
+    const int wB = a.Npad * 32, wT = ncc * wB;                       // (the running weight offset of h2_tile: one add per step instead of a re-derivation)
+    int wsl = n0 * 32;
+    auto load_b = [&](int set, int dslab, int t) __attribute__((always_inline)) {
+        const int soff = wsl + dslab * wB + t * wT;
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB, (unsigned)((kc * a.Npad + n0 + j * 32) * 32));
+            for (int j = 0; j < NTL; ++j) bf[set][p][j] = TSNET_BUF_LOAD16(rsw[p], vB + j * 1024u, (unsigned)soff);      // (+ 1024 j rides in the instruction's immediate offset)
     };
     const unsigned char* abase = smem_raw + lh * REGION + (2 * wrow * MT * RP + li) * 16;
     auto load_a = [&](int set, int cc, int t) __attribute__((always_inline)) {
@@ -657,7 +666,7 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     auto step = [&](int cc, int t, int SA) __attribute__((always_inline)) {
         const bool fresh = t == 0 || t == 4;
         const int t2 = (t + 2) % 9;
-        load_b(t2 % 3, cc + (t + 2 >= 9 ? 1 : 0), t2);
+        load_b(t2 % 3, t + 2 >= 9 ? 1 : 0, t2);
         if (t < 8) load_a(SA ^ 1, cc, t + 1);
         if (NR == 5) {
             if (t == 1) stage_store(cc + 1, 0);
@@ -702,6 +711,7 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
         step(cc, 0, S0); step(cc, 1, S0 ^ 1); step(cc, 2, S0);
         step(cc, 3, S0 ^ 1); step(cc, 4, S0); step(cc, 5, S0 ^ 1);
         step(cc, 6, S0); step(cc, 7, S0 ^ 1); step(cc, 8, S0);
+        wsl += wB;
     };
 
     // prologue: patch of slab 0, weight fragments of steps (0,0) and (0,1)
