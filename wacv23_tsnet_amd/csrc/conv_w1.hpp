@@ -171,6 +171,22 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
             tb[cp32 + c] = ok ? a.in_beta[(size_t)t.img * a.Cin + c] * t.in_scale : 0.f;
         }
     };
+    // the first tile's table in two halves -- its loads, then (behind whatever the caller puts in flight meanwhile) its stores: loads return in
+    // order, so the table must be REQUESTED before the prologue's items, or its stores wait for them too.  Two entries per thread cover 2 x 896
+    // channels (run_conv admits nothing wider)
+    struct TabRegs { float a0, b0, a1, b1; };
+    auto tab_request = [&](const W1Tile& t) __attribute__((always_inline)) {
+        const int c0 = tid, c1 = tid + 64 * kW1Waves;
+        TabRegs r;
+        r.a0 = c0 < a.Cin ? a.in_alpha[(size_t)t.img * a.Cin + c0] : 0.f; r.b0 = c0 < a.Cin ? a.in_beta[(size_t)t.img * a.Cin + c0] : 0.f;
+        r.a1 = c1 < a.Cin ? a.in_alpha[(size_t)t.img * a.Cin + c1] : 0.f; r.b1 = c1 < a.Cin ? a.in_beta[(size_t)t.img * a.Cin + c1] : 0.f;
+        return r;
+    };
+    auto tab_store = [&](float* tb, const W1Tile& t, const TabRegs& r) __attribute__((always_inline)) {
+        const int c0 = tid, c1 = tid + 64 * kW1Waves;
+        if (c0 < cp32) { tb[c0] = r.a0 * t.in_scale; tb[cp32 + c0] = r.b0 * t.in_scale; }
+        if (c1 < cp32) { tb[c1] = r.a1 * t.in_scale; tb[cp32 + c1] = r.b1 * t.in_scale; }
+    };
     // (the first tile's table is filled by every thread, inside the two roles below: the producers put their first fetches in flight before it)
     f32x16 tot[2];
 #pragma unroll
@@ -375,9 +391,11 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         static_assert(NIT == 2, "the prologue and the period loop are written for two items per producer");
         {
             F4 sp[2][4];                                             // with sx: four buffers, the prologue's four items in flight at once
+            TabRegs tr{};
+            if (AFFINE) tr = tab_request(T);
             fetch_any(0, 0, sx[0]); fetch_any(0, 1, sx[1]); fetch_any(1, 0, sp[0]); fetch_any(1, 1, sp[1]);
             if (AFFINE) {
-                tab_fill(tab0, T, tid, 64 * kW1Waves);
+                tab_store(tab0, T, tr);
                 __syncthreads();                                     // the first tile's table (the consumers fill their share)
             }
             if (has_next) { Tn = tile_at(1); offsets(Tn, true, nxt); }
@@ -441,10 +459,8 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         }
     } else {
         // ================= consumers (waves 0..7): the K loop =================
-        if (AFFINE) {
-            tab_fill(tab0, T, tid, 64 * kW1Waves);
-            __syncthreads();
-        }
+        TabRegs tr{};
+        if (AFFINE) tr = tab_request(T);
         const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
         F4 af[2][5][NPL], bf[BD][NPL];                               // [slab of the period][first row of the row pair][plane], [step % BD][plane]
         // Weight fragment of (tap row ky, slab cc) of this wave's position: byte offset ((ky * 4 + pos) * ncc + cc) * Npad + n0) * 32 =
@@ -526,7 +542,13 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
                     for (int r = 0; r < 16; ++r) tot[i][r] += acc[i][r];
             }
         };
-        load_bs(0, vB, wsp); load_bs(1, vB, wsp + wA);            // steps 0, 1 of the first period
+        load_bs(0, vB, wsp); load_bs(1, vB, wsp + wA);            // steps 0, 1 of the first period: requested BEFORE the table barrier -- cold from
+                                                                     // HBM they need the whole prologue to arrive (behind it they cost a single-round
+                                                                     // launch on cold weights 7 us: 54.8 against 47.4 us for one frame's layer)
+        if (AFFINE) {
+            tab_store(tab0, T, tr);
+            __syncthreads();                                         // the first tile's table
+        }
         TSNET_W1_STAMP(1);
         __syncthreads();                                             // V(0), V(1) complete
         TSNET_W1_STAMP(2);

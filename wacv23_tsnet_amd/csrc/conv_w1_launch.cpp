@@ -30,6 +30,7 @@ void go_w1(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 void launch_conv_w1(const ConvArgs& a, int nprod, int abl, hipStream_t s) {
+    if (a.Cin > 2 * 64 * kW1Waves) throw std::invalid_argument("conv(w1): the prologue's table request covers two channels per thread");      // (the LDS budget stops at ~1200)
     if (abl) {
 #ifdef TSNET_TOOLS
         const size_t lds = (size_t)w1_lds_bytes(a.Cin, 2, a.w1_tab2 ? 2 : 1);
