@@ -39,6 +39,11 @@ def test_winograd_kernel_fits_fourteen_waves():
     assert len(res) >= 8, res
     for name, (vgpr, scratch) in res.items():
         assert vgpr <= 128 and scratch <= (128 if ", 1>" in name else 64), (name, vgpr, scratch)
+    # the one-tile path (conv_w1_one.hpp: launches of a single round) is round 4's kernel: 128 VGPRs, no scratch at all in the forward's forms
+    one = ic.kernel_resources(asm, "conv_w1_one_kernel")
+    assert len(one) >= 8, one
+    for name, (vgpr, scratch) in one.items():
+        assert vgpr <= 128 and (scratch == 0 or "<1," in name), (name, vgpr, scratch)
     inner = ic.scratch_in_inner_loops(asm, "conv_w1_kernel")
     assert len(inner) == len(res) and all(v == 0 for v in inner.values()), inner
 

@@ -2,11 +2,20 @@
 #include <stdexcept>
 
 #include "conv_w1.hpp"
+#include "conv_w1_one.hpp"
 #include "kernels.hpp"
 
 namespace tsnet {
 
 namespace {
+
+// a launch of one tile per workgroup runs the one-tile kernel (conv_w1_one.hpp: round 4's, shorter prologue); chunks run conv_w1.hpp's
+template <int NPROD, bool AFFINE, int OPT>
+void go_w1_one(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)w1_lds_bytes(a.Cin, NPROD == 1 ? 1 : 2, 1);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv_w1_one_kernel<NPROD, AFFINE, OPT>), lds);
+    hipLaunchKernelGGL((conv_w1_one_kernel<NPROD, AFFINE, OPT>), dim3(a.tiles_m * a.tiles_n), dim3(64 * kW1Waves), lds, s, a);
+}
 
 template <int NPROD, bool AFFINE, int OPT>
 void go_w1_k(const ConvArgs& a, size_t lds, hipStream_t s) {
@@ -21,6 +30,13 @@ template <int NPROD>
 void go_w1(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)w1_lds_bytes(a.Cin, NPROD == 1 ? 1 : 2, a.w1_tab2 ? 2 : 1);
     if (NPROD == 1 && a.w1_chunk > 1) throw std::invalid_argument("conv(w1): chunks of several tiles need the two-plane stages");
+    if (a.w1_chunk <= 1) {
+        if (!a.in_alpha && !a.in_relu) go_w1_one<NPROD, false, 2>(a, s);
+        else if (!a.in_alpha) go_w1_one<NPROD, false, 0>(a, s);
+        else if (a.reflect) go_w1_one<NPROD, true, 0>(a, s);
+        else go_w1_one<NPROD, true, 1>(a, s);
+        return;
+    }
     if (!a.in_alpha && !a.in_relu) go_w1_k<NPROD, false, 2>(a, lds, s);
     else if (!a.in_alpha) go_w1_k<NPROD, false, 0>(a, lds, s);
     else if (a.reflect) go_w1_k<NPROD, true, 0>(a, lds, s);
