@@ -12,6 +12,11 @@ HOT = [("conv_h2_kernel<4, 64, 2, 2, 3, true, 0, 0>", 0), ("conv_h2_kernel<4, 64
        ("conv_h2_kernel<4, 128, 2, 2, 3, false, 0, 0>", 0), ("conv_h2_kernel<4, 128, 2, 2, 3, true, 0, 0>", 4),
        ("conv_h2_kernel<4, 64, 2, 2, 1, true, 0, 0>", 0), ("conv_h2_kernel<4, 64, 2, 2, 1, false, 0, 0>", 0),
        ("conv_h2_kernel<4, 64, 2, 2, 3, true, 0, 24>", 0), ("conv_h2_kernel<4, 32, 4, 1, 3, true, 0, 24>", 0)]
+# the encoder front end of the headline forward: the stride-2 patch kernel from 128 channels on, the 7 x 7 stem.  The IN + ReLU form of the
+# stride-2 tile holds 2 spill operations per slab pair at its 168 VGPRs (three workgroups per CU): measured, tolerated, pinned so that it cannot grow unseen.
+HOT_FRONT = [("conv_h2d_kernel<128, 4, 3, true, 2>", 2), ("conv_h2d_kernel<128, 4, 3, false, 2>", 0), ("conv_h2s_kernel<3>", 0)]
+# ... and of the general kernel's unit (conv_h2r_launch.cpp): the 64 -> 128 stride-2 layer and the two 1 x 1 convolutions
+HOT_GENERAL = [("conv_h2r_kernel<3, 128, 2, 2, 3, true, false>", 0), ("conv_h2r_kernel<1, 64, 2, 2, 3, false, false>", 0)]
 
 
 def loops_of(body):
