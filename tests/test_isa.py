@@ -9,13 +9,23 @@ import shutil
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_IC = []
+
+
+def _isa_check():
+    """tools/isa_check.py, loaded once; the four translation units the tests look at are compiled side by side on first use"""
+    if not _IC:
+        spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
+        ic = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ic)
+        ic.compile_all(["conv_h2_launch.cpp", "conv_h2r_launch.cpp", "conv_w1_launch.cpp", "flow_p_launch.cpp"])
+        _IC.append(ic)
+    return _IC[0]
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
 def test_hot_kernels_do_not_spill_in_their_loops():
-    spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
-    ic = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ic)
+    ic = _isa_check()
     rows = {r["name"]: r for r in ic.analyse(ic.compile_asm(), "conv_h2_kernel")}
     for name, limit in ic.HOT:
         hit = [r for n, r in rows.items() if name in n]
@@ -40,9 +50,7 @@ def test_winograd_kernel_fits_fourteen_waves():
     must stay within 128 VGPRs.  No spill inside a period loop (the consumers' K loop, the producers' item loop); the producers' prologue and
     tile-boundary code may hold a few values in scratch (<= 128 bytes: a handful of instructions per TILE, since round 5's chunks carry two
     tiles' offsets), the forward's own instantiations (reflection padding or raw input) at most 64."""
-    spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
-    ic = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ic)
+    ic = _isa_check()
     asm = ic.compile_asm(unit="conv_w1_launch.cpp")
     res = ic.kernel_resources(asm, "conv_w1_kernel")
     assert len(res) >= 8, res
@@ -63,9 +71,7 @@ def test_large_map_flow_kernel_has_no_packed_fp32_arithmetic():
     other wave's MFMAs) returned different and wrong flows from run to run on the MI355X (csrc/flow_persist.hpp, profiles/round4_flow_cfg4.txt);
     the scalar build is exact.  Its translation unit is compiled with -fno-slp-vectorize: this pins the flag, two waves per SIMD (<= 256
     VGPRs) and no scratch."""
-    spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
-    ic = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ic)
+    ic = _isa_check()
     asm = ic.compile_asm(unit="flow_p_launch.cpp")
     res = ic.kernel_resources(asm, "flow_kernel_p")
     assert res, "flow_kernel_p is not in the product library"

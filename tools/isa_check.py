@@ -64,9 +64,26 @@ def analyse(asm_path, pattern=""):
     return rows
 
 
+_ASM = {}
+
+
+def compile_all(units, tools=False):
+    """compile several translation units at once (hipcc is single-threaded per unit: four units in the time of the slowest); compile_asm then returns from the cache"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(len(units)) as ex:
+        list(ex.map(lambda u: compile_asm(tools, u), units))
+
+
 def compile_asm(tools=False, unit="conv_h2_launch.cpp"):
+    if (tools, unit) not in _ASM:
+        _ASM[(tools, unit)] = _compile_asm(tools, unit)
+    return _ASM[(tools, unit)]
+
+
+def _compile_asm(tools, unit):
     tmp = tempfile.mkdtemp(prefix="tsnet_isa_")
-    sys.path.insert(0, ROOT)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
     from wacv23_tsnet_amd import build as B          # the library's own flags: the ISA looked at is the ISA that ships
     cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + B.UNIT_FLAGS.get(unit, []) + ["-save-temps", "-I" + os.path.join(ROOT, "include")]
     if tools:
