@@ -358,6 +358,7 @@ def _rank_main(rank: int, world: int, local_rank: int, args, q=None):
     emulation build of the kernels on tiny shapes (tests/test_bench_ranks.py); the product path is device "cuda" / backend nccl (= RCCL)."""
     cuda = args.device == "cuda"
     if cuda:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (also under torch.distributed.run, before the HIP runtime starts)
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     else:
