@@ -67,7 +67,8 @@ def main():
             r = Hh.bf16_mode_report(eng, cfg, sd, inp, rec, B, "cpu", mode=mode, flows=flows)
             ok = (same and r["src_fea"] < 5e-2 and r["tar_fea"] < 2e-2 and r["sg"] < 8e-2 and r["flow_on_engine_features"] < 1e-4
                   and r["pg_on_engine_features"] < 4e-3 and r["decoder_on_engine_features"] < 3e-2 and bool(rec.isfinite().all()))
-            line = " ".join(f"{k}={r[k]:.2e}" for k in ("src_fea", "tar_fea", "sg", "flow_on_engine_features", "pg_on_engine_features", "decoder_on_engine_features"))
+            line = " ".join(f"{k}={r[k]:.2e}" for k in ("src_fea", "tar_fea", "sg", "flow_on_engine_features", "pg_on_engine_features", "decoder_on_engine_features",
+                                                            "decoder_on_engine_features_mean", "decoder_on_engine_features_p99999"))
         eng.close()
         if not ok:
             bad.append((desc, line, same))
