@@ -180,6 +180,35 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- host side of a step (what one thread pays to enqueue a forward -- the scaling question at 8 GPUs is a host question,
+    # the ranks exchange nothing per step).  After the timed region, from an idle device: the wall time of `nq` step() calls BEFORE any
+    # synchronisation (the HIP queue holds a few thousand packets: five forwards never fill it), beside the time until the device is done.
+    host_probe = None
+    if cuda:
+        nq = 5
+        sync()
+        q0 = time.perf_counter()
+        for _ in range(nq):
+            step()
+        q1 = time.perf_counter()
+        sync()
+        q2 = time.perf_counter()
+        host_probe = {"host_enqueue_ms_per_step": round((q1 - q0) / nq * 1e3, 3), "device_ms_per_step_same_probe": round((q2 - q0) / nq * 1e3, 3),
+                      "host_threads": 1, "steps": nq,
+                      "note": "wall time of the step() calls (Python shell + ctypes + the engine's ~70 hipLaunchKernel) before any synchronisation, one host thread"}
+        host_probe["host_enqueue_frac_of_step"] = round(host_probe["host_enqueue_ms_per_step"] / max(host_probe["device_ms_per_step_same_probe"], 1e-9), 3)
+        # the one collective of a replica's life: the packed weight buffer.  At world size 1 there is no peer; what can be measured here is the
+        # buffer's size and a device-to-device copy of it (the HBM side of a broadcast: read once, written once).
+        try:
+            wb = eng.packed_weights(dev)
+            tmp = torch.empty_like(wb)
+            tmp.copy_(wb); sync()
+            c0 = time.perf_counter(); tmp.copy_(wb); sync(); c1 = time.perf_counter()
+            host_probe["packed_weights_MB"] = round(wb.numel() * wb.element_size() / 1e6, 1)
+            host_probe["packed_weights_d2d_copy_ms"] = round((c1 - c0) * 1e3, 3)
+            del tmp
+        except Exception as e:           # noqa: BLE001  (a probe must never cost the line)
+            host_probe["packed_weights_error"] = "%s: %s" % (type(e).__name__, e)
     if rank != 0:
         return None
     step_ms = sorted(a.elapsed_time(b) for a, b in ev) if ev else None
@@ -219,7 +248,12 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
             flop_per_launch = flop_class / (n_enc + n_dec)
             avg_ms = res_ms / res_launches
             achieved = flop_class * nprobe / (res_ms * 1e-3) / 1e12
-            peak = PEAK_F16_MFMA_TFLOPS if bf16 else PEAK_H2_TFLOPS
+            # The ceiling in ALGORITHMIC flop of the kernel that ran: one MFMA product per bf16 product; three fp16 products per fp32 product
+            # in the direct form (2500 / 3); the Winograd F(2,3)-along-x form issues them on 2/3 of the products, so ITS ceiling is
+            # 2500 / (3 * 2/3) = 1250 TF -- a number the kernel cannot exceed (833 TF was not a ceiling for it).  `frac` is
+            # therefore the fraction of the matrix pipe's dense peak the launches keep busy (= mfma_flops_issued_tflops / 2500); the
+            # direct-form figure of rounds 3 - 5 stays beside it as frac_of_direct_form_ceiling.
+            peak = PEAK_F16_MFMA_TFLOPS if bf16 else (PEAK_H2_TFLOPS * 1.5 if wino else PEAK_H2_TFLOPS)
             kname = "conv_w1_kernel" if wino else "conv_h2_kernel"
             traffic, traffic_src = _pmc_traffic_bytes("conv_w1<" if wino else "conv_h2<%d,%d," % (pr, bn), cf["pmc"]) if cuda else (None, "not a GPU run")
             roofline = {"bound": "mfma",
@@ -230,7 +264,9 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         "traffic": traffic, "traffic_source": traffic_src,
                         "peak_basis": "2500 TF dense bf16 MFMA, one product per bf16 product" if bf16 else
-                                      "2500 TF dense fp16 MFMA / 3 fp16 products per fp32 product (2-way split of the scaled operand, conv_common.hpp)",
+                                      ("2500 TF dense fp16 MFMA / (3 fp16 products per fp32 product x 2/3 of the products in the Winograd F(2,3)-along-x form) = 1250 TF algorithmic" if wino else
+                                       "2500 TF dense fp16 MFMA / 3 fp16 products per fp32 product (2-way split of the scaled operand, conv_common.hpp)"),
+                        "frac_of_direct_form_ceiling": round(achieved / (PEAK_F16_MFMA_TFLOPS if bf16 else PEAK_H2_TFLOPS), 4),
                         # MFMA work actually issued: 3 products per fp32 product, on 2/3 of the products in the Winograd form; 1 in the bf16 mode
                         "mfma_flops_issued_tflops": round(achieved * (1.0 if bf16 else (2.0 if wino else 3.0)), 1),
                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -332,7 +368,7 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
         "ms_per_step_hipevent_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)] if step_ms else None,
         "algorithmic_gflop_per_frame": round(gflop_frame, 3),
         "whole_forward_frac_of_fp32_mfma_peak": round(frames / dt * gflop_frame / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4),
-        "roofline": roofline, "cpu_baseline": cpu_base, "secondary_bf16_cfg2": second,
+        "roofline": roofline, "cpu_baseline": cpu_base, "secondary_bf16_cfg2": second, "host": host_probe,
     }
     if bf16:
         line["parity_bf16"] = parity16

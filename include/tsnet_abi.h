@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TSNET_ABI_VERSION 4      /* 4: tsnet_cfg.operand_mode = 2 (bf16 storage); tsnet_op_conv2d kernel = 3 (Winograd-along-x form); tsnet_op_flow_k, tsnet_flow_plan */
+#define TSNET_ABI_VERSION 5      /* 5: tsnet_op_warp_k (round 6); 4: tsnet_cfg.operand_mode = 2 (bf16 storage); tsnet_op_conv2d kernel = 3 (Winograd-along-x form); tsnet_op_flow_k, tsnet_flow_plan */
 #define TSNET_MAX_SOURCES 8
 
 enum {
@@ -179,6 +179,9 @@ int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64
  *   launches the flow kernel that many times (identical results); ms_out (nullable) receives the average time of launches 2 .. repeat by
  *   HIP events (tools/flow_bench.py), 0 when repeat <= 1.
  * tsnet_op_warp       <- F.grid_sample(bilinear, zeros, align_corners=False) (TSNet.py:366) on NHWC.
+ * tsnet_op_warp_k     <- the same for K sources per driving frame fused with the mean over sources (TSNet.py:366, 392/400), as the forward
+ *   runs it: src_fea / flow hold K*B images (image k*B + b), out (B,h,w,C).  repeat > 1 launches the kernel that many times; ms_out
+ *   (nullable) receives the average time of launches 2 .. repeat by HIP events -- the kernel ALONE (tools/warp_bench.py).
  */
 int tsnet_op_conv2d(const float* x, int N, int H, int W, int Cin,
                     const float* w_oihw, const float* bias, int Cout, int ksize, int stride, int pad, int pad_mode,
@@ -203,6 +206,7 @@ int tsnet_op_flow_k(const float* tar_fea, const float* src_fea, const float* tar
  * arguments.  Host logic only. */
 int tsnet_flow_plan(int B, int h, int w, int C);
 int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, int C, float* out, void* stream);
+int tsnet_op_warp_k(const float* src_fea, const float* flow, int B, int K, int h, int w, int C, float* out, int repeat, float* ms_out, void* stream);
 const char* tsnet_op_last_error(void);
 
 /* ---- demo post-processing (demo/demo_face.py:96-105,180-198 = demo/demo_pose.py:98-107,

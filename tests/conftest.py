@@ -24,7 +24,7 @@ def pytest_configure(config):
 
 def build_emu_lib() -> str:
     csrc = os.path.join(ROOT, "wacv23_tsnet_amd", "csrc")
-    src = [os.path.join(csrc, u) for u in ("engine.cpp", "conv_h2_launch.cpp", "conv_h2r_launch.cpp", "conv_w1_launch.cpp", "flow_p_launch.cpp")] + [os.path.join(ROOT, "tests", "emu", "emu_runtime.cpp")]
+    src = [os.path.join(csrc, u) for u in ("engine.cpp", "conv_h2_launch.cpp", "conv_h2r_launch.cpp", "conv_g64_launch.cpp", "conv_w1_launch.cpp", "flow_p_launch.cpp")] + [os.path.join(ROOT, "tests", "emu", "emu_runtime.cpp")]
     deps = src + sorted(glob.glob(os.path.join(ROOT, "wacv23_tsnet_amd", "csrc", "*.hpp")))
     deps += [os.path.join(ROOT, "include", "tsnet_abi.h"), os.path.join(ROOT, "tests", "emu", "include", "hip", "hip_runtime.h")]
     out_dir = os.path.join(ROOT, "tests", "emu", "_build")

@@ -135,6 +135,8 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }     // the MI355X's 256 CUs: the launch logic under test is the product's
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 #define hipStreamNonBlocking 1
 #define hipEventDisableTiming 2

@@ -407,3 +407,29 @@ def conv_w1_odd_slab_case(lib, dev, N=1, H=4, W=32, Cin=48, Cout=64, seed=0):
     yc = nchw(y.cpu()).double()
     assert torch.isfinite(yc).all(), "non-finite outputs"
     return ((yc - ref).abs().max() / ref.abs().max()).item()
+
+
+def conv_g64_cases(lib, dev, big=False):
+    """conv_g64 (csrc/conv_g64.hpp: the general implicit GEMM in 64-deep K steps) against conv_h2r (16-deep steps) on the layer kinds the
+    forward sends it -- the two kernels run the same chains, so the outputs must be EQUAL BITS -- and against the fp64 reference.  Shapes:
+    1 x 1 (fuse_net.conv / dec.map_conv), 3 x 3 stride 2 with the producer's InstanceNorm + ReLU on load (the 64 -> 128 layer; with bf16
+    operands every stride-2 layer), 3 x 3 stride 1 with reflection on a ragged frame, 192 channels (three steps per tap), both tile heights;
+    the concat formed on load (own channel split per tensor, shared second image).  Returns the worst relative error of the fp16 x 2 cases."""
+    worst = 0.0
+    shapes = [(2, 8, 8, 128, 128, 1, 1, 0, False, False, 3, 64), (1, 16, 16, 64, 128, 3, 2, 1, False, True, 3, 128), (2, 10, 12, 64, 256, 3, 1, 1, True, True, 3, 128),
+              (1, 16, 16, 128, 128, 3, 2, 1, False, True, 1, 128), (1, 9, 7, 192, 128, 3, 2, 1, False, False, 3, 128)]
+    if big:      # the forward's own shapes at the headline batch
+        shapes += [(4, 32, 32, 1024, 512, 1, 1, 0, False, False, 3, 64), (3, 256, 256, 64, 128, 3, 2, 1, False, True, 3, 128), (2, 64, 64, 256, 512, 3, 2, 1, False, True, 1, 128)]
+    for (N, H, W, Cin, Cout, k, st, pad, refl, norm, nprod, ref_tile) in shapes:
+        a = conv_case(lib, dev, N, H, W, Cin, Cout, k, st, pad, refl, norm=norm, nprod=nprod, kernel=1, tile=ref_tile, return_output=True)
+        for tile in (3064, 3128):
+            b = conv_case(lib, dev, N, H, W, Cin, Cout, k, st, pad, refl, norm=norm, nprod=nprod, kernel=1, tile=tile, return_output=True)
+            assert torch.equal(a, b), (N, H, W, Cin, Cout, k, st, nprod, tile, (a - b).abs().max().item())
+        if nprod == 3:
+            worst = max(worst, conv_case(lib, dev, N, H, W, Cin, Cout, k, st, pad, refl, norm=norm, nprod=nprod, kernel=1, tile=3064))
+        c = conv_case(lib, dev, N, H, W, Cin, Cout, k, st, pad, refl, norm=norm, nprod=nprod, kernel=1, tile=0, return_output=True)    # the launcher's own choice
+        assert torch.equal(a, c)
+    worst = max(worst, conv_cat_case(lib, dev, 2, 8, 8, 64, 64, 128), conv_cat_case(lib, dev, 2, 8, 8, 128, 64, 256, shared=True))
+    if big:
+        worst = max(worst, conv_cat_case(lib, dev, 4, 32, 32, 512, 512, 512))
+    return worst

@@ -54,7 +54,7 @@ def test_library_loads_and_reports_version():
     except RuntimeError as e:
         pytest.skip(str(e))
     lib = _lib.load()
-    assert lib.tsnet_abi_version() == 4
+    assert lib.tsnet_abi_version() == 5
     for sym in _lib.ABI_SYMBOLS:
         assert hasattr(lib, sym)
 

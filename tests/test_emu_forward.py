@@ -81,14 +81,22 @@ def test_pose_composite(emu_lib):
     eng.close()
 
 
-def test_conv_epilogue_statistics_path(emu_lib):
+@pytest.mark.parametrize("H,W,B", [(64, 64, 1), (96, 64, 2)])
+def test_conv_epilogue_statistics_path(emu_lib, H, W, B):
     """64x64 input -> 8x8 features: every image is one ragged 128-position tile at the feature resolution, two / eight / 32 whole tiles above
-    it; the in-kernel statistics finalize (at most 32 tiles per image) and the in_finalize2 launch (the 64x64 stem is exactly 32) both run."""
-    cfg, sd, inp = _case(K=1, nb=1, B=1, H=64, W=64, enc_blocks=1)
-    ref = O.tsnet_forward(sd, cfg, *inp)
-    eng = Hh.make_engine(cfg, sd, 64, 64, 1, "cpu", lib=emu_lib)
+    it: the in-kernel statistics finalize (at most 32 tiles per image; the 64x64 stem is exactly 32, four batches of the fold's eight-entry
+    loads).  96x64, two images: the stem and the last up-convolution have 48 tiles per image -- the in_finalize2 launch with a ragged last
+    batch of its 16 groups (test_pose_composite's 256 x 256 frame runs it on 512 / 128 / 64 partials)."""
+    cfg, sd, inp = _case(K=1, nb=1, B=B, H=H, W=W, enc_blocks=1)
+    ref = O.tsnet_forward(sd, cfg, *inp, want_stages=True)
+    eng = Hh.make_engine(cfg, sd, H, W, B, "cpu", lib=emu_lib)
     rec, _ = Hh.run_engine(eng, inp, "cpu", return_flow=False)
     assert (rec - ref["rec_tar_img"]).abs().max().item() < 5e-4
+    rep = Hh.stage_report(eng, ref["stages"], cfg.n_source, B, "cpu")
+    assert max(rep[k] for k in rep if k.startswith("src_fea")) < 1e-4 and rep["tar_fea"] < 1e-4 and rep["sg"] < 1e-4
+    if B > 1:                                   # the second image alone: the same bits (per-image counters, groups and partials)
+        one, _ = Hh.run_engine(eng, [[t[1:2] for t in x] if isinstance(x, list) else x[1:2] for x in inp], "cpu", return_flow=False)
+        assert torch.equal(one, rec[1:2])
     eng.close()
 
 

@@ -29,6 +29,11 @@ def test_conv_general_kernel_tiles_and_shapes(emu_lib):
     assert torch.equal(a, b)
 
 
+def test_conv_g64_equals_conv_h2r_bitwise(emu_lib):
+    """the 64-deep-step form of the general kernel (round 6) on every layer kind the forward sends it: equal bits, and < REL of the reference"""
+    assert oc.conv_g64_cases(emu_lib, "cpu") < REL
+
+
 def test_conv_cat_on_load(emu_lib):
     """dec.map_conv: 1x1 on cat(pg, sg) formed on load from two tensors (TSNet.py:163); also a 3x3 and a shared second tensor"""
     assert oc.conv_cat_case(emu_lib, "cpu", 2, 4, 8, 32, 32, 48) < REL

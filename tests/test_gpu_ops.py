@@ -40,6 +40,12 @@ def test_conv_general_kernel_shapes(lib):
     assert torch.equal(a, b)
 
 
+def test_conv_g64_equals_conv_h2r_bitwise(lib):
+    """the 64-deep-step form of the general kernel (csrc/conv_g64.hpp): equal bits to conv_h2r on the small cases and on the forward's own
+    shapes (1 x 1 at 4096 x 1024 -> 512, the 64 -> 128 stride-2 layer at 256^2, a bf16 stride-2 layer), < REL of the fp64 reference"""
+    assert oc.conv_g64_cases(lib, DEV, big=True) < REL
+
+
 def test_conv_cat_on_load(lib):
     """dec.map_conv at its real shape: 1x1 on cat(pg, sg), 512 + 512 -> 512 channels, formed on load"""
     assert oc.conv_cat_case(lib, DEV, 4, 32, 32, 512, 512, 512) < REL

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "tsnet_forward", "tsnet_set_source_divisors", "tsnet_set_sources", "tsnet_forward_target", "tsnet_train_extras", "tsnet_stage_ptr",
     "tsnet_forward_macs", "tsnet_timing_enable", "tsnet_timing_read",
     "tsnet_op_conv2d", "tsnet_op_conv2d_cat", "tsnet_op_head", "tsnet_op_instnorm_stats", "tsnet_op_norm_act", "tsnet_op_upsample2x",
-    "tsnet_op_flow", "tsnet_op_flow_k", "tsnet_flow_plan", "tsnet_op_warp", "tsnet_op_last_error", "tsnet_frame_stats", "tsnet_demo_postprocess", "tsnet_fit_face_curves", "tsnet_raster_face", "tsnet_vl2ch", "tsnet_fit_pose_curves", "tsnet_raster_pose", "tsnet_label_bbox", "tsnet_resize_pad", "tsnet_resize_label", "tsnet_bench_conv", "tsnet_debug_counters", "tsnet_linspace", "tsnet_coord_table",
+    "tsnet_op_flow", "tsnet_op_flow_k", "tsnet_flow_plan", "tsnet_op_warp", "tsnet_op_warp_k", "tsnet_op_last_error", "tsnet_frame_stats", "tsnet_demo_postprocess", "tsnet_fit_face_curves", "tsnet_raster_face", "tsnet_vl2ch", "tsnet_fit_pose_curves", "tsnet_raster_pose", "tsnet_label_bbox", "tsnet_resize_pad", "tsnet_resize_label", "tsnet_bench_conv", "tsnet_debug_counters", "tsnet_linspace", "tsnet_coord_table",
 )
 
 
@@ -81,6 +81,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.tsnet_op_flow_k.argtypes = [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [_vp, C.c_int, C.c_int, _fp, _vp]
     lib.tsnet_flow_plan.argtypes = [C.c_int] * 4
     lib.tsnet_op_warp.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
+    if hasattr(lib, "tsnet_op_warp_k"):          # absent from an older build opened beside this one (tools/forward_ab.py --lib2)
+        lib.tsnet_op_warp_k.argtypes = [_vp, _vp] + [C.c_int] * 5 + [_vp, C.c_int, _fp, _vp]
     lib.tsnet_op_last_error.restype = C.c_char_p
     lib.tsnet_frame_stats.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp]
     lib.tsnet_demo_postprocess.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _fp, _vp, _vp]
@@ -127,6 +129,6 @@ def load() -> C.CDLL:
         _cached = bind(C.CDLL(LIB_PATH))
     except OSError as e:  # pragma: no cover - depends on the machine
         raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
-    if _cached.tsnet_abi_version() != 4:
+    if _cached.tsnet_abi_version() != 5:
         raise RuntimeError("libtsnet_hip.so ABI version mismatch; rebuild")
     return _cached

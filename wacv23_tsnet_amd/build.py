@@ -16,7 +16,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ("engine.cpp", "conv_h2_launch.cpp", "conv_h2r_launch.cpp", "conv_w1_launch.cpp", "flow_p_launch.cpp")
+UNITS = ("engine.cpp", "conv_h2_launch.cpp", "conv_h2r_launch.cpp", "conv_g64_launch.cpp", "conv_w1_launch.cpp", "flow_p_launch.cpp")
 OUT = os.path.join(HERE, "lib", "libtsnet_hip.so")
 # the same sources with -DTSNET_TOOLS: the product kernels PLUS the ablation / experiment instantiations ("computes garbage" variants)
 # that tools/x3_ablate.py and tools/h2_variants.py time.  Never loaded by the package.
@@ -28,7 +28,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]            # MFMA C/D in VGPRs: no AGPR<->VGPR copies around the K loop
 # per-unit extras.  The patch convolutions fold accumulator registers with plain fp32 adds; the SLP vectoriser pairs them into
 # v_pk_add_f32, which beside MFMAs costs more than the two v_add_f32 it replaces (MI355X_MICROARCH.md, "price of one filler")
-UNIT_FLAGS = {"conv_h2_launch.cpp": ["-fno-slp-vectorize"], "conv_w1_launch.cpp": ["-fno-slp-vectorize"], "flow_p_launch.cpp": ["-fno-slp-vectorize"]}
+UNIT_FLAGS = {"conv_h2_launch.cpp": ["-fno-slp-vectorize"], "conv_g64_launch.cpp": ["-fno-slp-vectorize"], "conv_w1_launch.cpp": ["-fno-slp-vectorize"], "flow_p_launch.cpp": ["-fno-slp-vectorize"]}
 
 
 def _deps():

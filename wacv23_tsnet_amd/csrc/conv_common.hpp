@@ -336,27 +336,50 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
             // on BOTH sides (write-through sc1 stores above, sc1 loads below: never served from a stale L1 / another XCD's L2), every
             // storing wave's stores drained before the workgroup counts itself.  The drain is inline asm on purpose: the compiler may drop
             // a builtin s_waitcnt it can prove redundant.  The workgroup that reads fin_S - 1 sums the partials in a fixed order
-            // (four interleaved groups, then g0+g1+g2+g3): run-to-run deterministic.  (Which of the two finalize paths a layer takes depends on
-            // its tiles per image alone, never on the batch.)
+            // (four interleaved groups, then g0+g1+g2+g3): run-to-run deterministic.
             const int S = a.fin_S;
             const int img = (int)(stat_tile / (size_t)S);
-            int* counter = a.fin_counter + (size_t)img * ((a.Npad + 31) / 32) + n0 / 32;   // 32 = narrowest tile
-            auto finalize = [&]() __attribute__((always_inline)) {
-                if (stid >= 0 && stid < BN && n0 + stid < a.Cout) {
-                    double gs[4] = {0, 0, 0, 0}, gq[4] = {0, 0, 0, 0};
-                    for (int t = 0; t < S; ++t) {
-                        const double* p = a.stat_part + (((size_t)img * S + t) * a.Cout + n0 + stid) * 2;
-                        gs[t & 3] += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        gq[t & 3] += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ntn = (a.Npad + 31) / 32;                                                    // 32 = narrowest tile
+            int* counter = a.fin_counter + (size_t)img * ntn + n0 / 32;
+            const bool mine = stid >= 0 && stid < BN && n0 + stid < a.Cout;
+            // Entries in order t = 0 .. cnt-1 into four interleaved sums (t & 3), then g0 + g1 + g2 + g3.  The loads of EIGHT entries are issued
+            // before the first addition: a loop of one load pair per iteration compiles to a memory round trip per entry (s_waitcnt vmcnt(0)
+            // before every v_add_f64 -- 8 to 32 serial round trips in the last workgroup of every launch up to round 5).  Entries past cnt
+            // re-read the last one and contribute +0.0 (x + 0.0 == x): the association does not depend on the batching.
+            auto fold = [&](const double* p0, int cnt, size_t step, double& sm, double& sq) __attribute__((always_inline)) {
+                double gs[4] = {0, 0, 0, 0}, gq[4] = {0, 0, 0, 0};
+                for (int t0 = 0; t0 < cnt; t0 += 8) {
+                    double v[8], w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double* p = p0 + (size_t)(t0 + u < cnt ? t0 + u : cnt - 1) * step;
+                        v[u] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w[u] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    double sm = gs[0], sq = gq[0];
-                    for (int k = 1; k < 4; ++k) { sm += gs[k]; sq += gq[k]; }
-                    const double mean = sm / hw;
-                    double var = sq / hw - mean * mean;
-                    if (var < 0) var = 0;
-                    const float al = 1.0f / sqrtf((float)var + a.fin_eps);
-                    a.fin_alpha[(size_t)img * a.Cout + n0 + stid] = al;
-                    a.fin_beta[(size_t)img * a.Cout + n0 + stid] = -((float)mean) * al;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool in = t0 + u < cnt;
+                        gs[u & 3] += in ? v[u] : 0.0;
+                        gq[u & 3] += in ? w[u] : 0.0;
+                    }
+                }
+                sm = gs[0]; sq = gq[0];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) { sm += gs[k]; sq += gq[k]; }
+            };
+            auto write_ab = [&](double sm, double sq) __attribute__((always_inline)) {
+                const double mean = sm / hw;
+                double var = sq / hw - mean * mean;
+                if (var < 0) var = 0;
+                const float al = 1.0f / sqrtf((float)var + a.fin_eps);
+                a.fin_alpha[(size_t)img * a.Cout + n0 + stid] = al;
+                a.fin_beta[(size_t)img * a.Cout + n0 + stid] = -((float)mean) * al;
+            };
+            auto finalize = [&]() __attribute__((always_inline)) {                                 // all S tile partials of the image
+                if (mine) {
+                    double sm, sq;
+                    fold(a.stat_part + (((size_t)img * S) * a.Cout + n0 + stid) * 2, S, (size_t)a.Cout * 2, sm, sq);
+                    write_ab(sm, sq);
                 }
                 if (stid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
             };
@@ -365,20 +388,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&tot)[M
                 // last to arrive -- finalises, all in program order and WITHOUT a workgroup barrier; the other waves go straight on to their
                 // output stores.  (On a CU that one workgroup owns -- conv_w1 -- nothing else hides the counter's round trip.)
                 if (stid >= 0 && stid < 64) {
-                    TSNET_DRAIN_VMEM();
-                    float arrived = 0.f;
-                    if (lane == 0) arrived = (float)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    auto arrive = [&](int* c) __attribute__((always_inline)) {
+                        TSNET_DRAIN_VMEM();
+                        float arrived = 0.f;
+                        if (lane == 0) arrived = (float)__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) arrived += __shfl_xor(arrived, off);      // lane 0's value to every lane (the others hold 0)
-                    if ((int)arrived == S - 1) finalize();
+                        for (int off = 32; off > 0; off >>= 1) arrived += __shfl_xor(arrived, off);      // lane 0's value to every lane (the others hold 0)
+                        return (int)arrived;
+                    };
+                    if (arrive(counter) == S - 1) finalize();
                 }
             } else {
                 int* flag = reinterpret_cast<int*>(smem_raw + 8192);
-                TSNET_DRAIN_VMEM();
-                __syncthreads();
-                if (stid == 0) *flag = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                if (*flag == S - 1) finalize();
+                auto arrive = [&](int* c) __attribute__((always_inline)) {                         // every thread of the workgroup calls it
+                    TSNET_DRAIN_VMEM();
+                    __syncthreads();
+                    if (stid == 0) *flag = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    return *flag;
+                };
+                if (arrive(counter) == S - 1) finalize();                                         // workgroup-uniform
             }
         }
     }

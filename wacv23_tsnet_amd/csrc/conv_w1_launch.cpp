@@ -37,10 +37,12 @@ void go_w1(const ConvArgs& a, hipStream_t s) {
         else go_w1_one<NPROD, true, 1>(a, s);
         return;
     }
-    if (!a.in_alpha && !a.in_relu) go_w1_k<NPROD, false, 2>(a, lds, s);
-    else if (!a.in_alpha) go_w1_k<NPROD, false, 0>(a, lds, s);
-    else if (a.reflect) go_w1_k<NPROD, true, 0>(a, lds, s);
-    else go_w1_k<NPROD, true, 1>(a, lds, s);          // zero padding under a fused InstanceNorm: padded pixels re-zeroed after the transform
+    if constexpr (NPROD == 3) {                       // (one plane: chunks of one tile only -- the chunk kernel is not instantiated for it)
+        if (!a.in_alpha && !a.in_relu) go_w1_k<NPROD, false, 2>(a, lds, s);
+        else if (!a.in_alpha) go_w1_k<NPROD, false, 0>(a, lds, s);
+        else if (a.reflect) go_w1_k<NPROD, true, 0>(a, lds, s);
+        else go_w1_k<NPROD, true, 1>(a, lds, s);      // zero padding under a fused InstanceNorm: padded pixels re-zeroed after the transform
+    }
 }
 
 }  // namespace

@@ -15,8 +15,10 @@
 // tile; operands enter the matrix pipe as fp16 x 2 splits (three products) or, with tsnet_cfg.operand_mode = 1, as one bf16 plane.
 // Which kernel a layer runs on (the Winograd-along-x kernel of conv_w1.hpp for the ResnetBlock / FuseNet layers and the first two
 // up-convolutions, the patch kernels of conv_h2.hpp where the output splits into 4 x 32 rectangles, the general implicit GEMM of
-// conv_h2r.hpp elsewhere) and which tile it takes depend on the layer and the frame size only -- never on the batch, never on the
-// environment: a frame's result is the same bits alone (B = 1) and in any batch (tests/test_gpu_forward.py::test_single_frame_forward).
+// conv_g64.hpp / conv_h2r.hpp elsewhere) and which tile it takes depend on the layer and the frame size only -- never on the batch, never
+// on the environment.  Two launch parameters DO follow the batch -- conv_w1's tiles per workgroup and nothing else -- and are bit-neutral by
+// construction (the same chains per output element in every chunk size): a frame's result is the same bits alone (B = 1) and in any batch
+// (tests/test_gpu_forward.py::test_single_frame_forward).
 // InstanceNorm statistics: fp64 partial sums in the producing conv's epilogue, finalised there by the last-arriving workgroup
 // (or by in_finalize2 when an image has many tiles).
 #include <hip/hip_runtime.h>
@@ -69,6 +71,17 @@ struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; 
 struct WeightError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// CUs of the current device (MI355X: 256 in 8 XCDs -- the XCD count is part of the kernels' block -> tile maps, conv_common.hpp; the CU count
+// only enters launch heuristics: how many tiles fill the chip in whole rounds).  Asked once; a device that reports nothing counts as 256.
+inline int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
+        cus = v;
+    }
+    return cus;
+}
 inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 inline int next_pow2(int x) { int p = 4; while (p < x) p <<= 1; return p; }
 
@@ -172,6 +185,9 @@ struct DevBufs {
 };
 
 constexpr size_t kFinCounterInts = 65536;   // size of the arrival-counter arrays of the in-kernel statistics finalize
+constexpr int kFinGroup = 32;               // most tiles per image the last-arriving workgroup folds itself (conv_epilogue); above: in_finalize2
+// doubles a convolution's statistics scratch must hold: (sum, sum of squares) per (tile, channel)
+inline size_t stat_part_doubles(size_t N, size_t tpi, size_t Cout) { return N * tpi * Cout * 2; }
 constexpr int KPAD_ALIGN = 32;   // packed weights are K-padded to an even number of 16-deep chunks (fragment prefetch runs up to two past the end)
 
 inline int conv_kpad(int ks, int cin_pad) { return round_up(ks * ks * cin_pad, KPAD_ALIGN); }
@@ -213,7 +229,7 @@ inline int h2_scale_log2(float bound) {
 }
 
 // Kernel class of a layer at a frame size.  The patch kernels sum K slab-major, the general one tap-major: the class must depend on the
-// layer and the geometry alone, never on the batch (a sample's result is the same bits in any batch of >= 2 frames; B = 1: see run_conv).
+// layer and the geometry alone, never on the batch (a sample's result is the same bits in any batch, B = 1 included).
 enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3, K_W1 = 4 };
 // a layer packed in the Winograd-along-x form runs conv_w1 and nothing else: 3 x 3 / stride 1 / pad 1 on frames of whole 4 x 32 tiles
 inline size_t w1_lds_bytes_host(int Cin, int tables) {       // conv_w1.hpp w1_lds_bytes for the two-plane stages
@@ -284,9 +300,12 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         g.tpi = (hw + rows_per_tile_m - 1) / rows_per_tile_m;
         g.tiles_m = c.N * g.tpi; g.tiles_n = (g.Cout + bn - 1) / bn;
         g.fin_S = g.tpi;
-        // few tiles per image: the last workgroup of each (image, channel tile) finalises the statistics (conv_epilogue); many tiles per
-        // image (the 128^2 / 256^2 layers): a serial tail of hundreds of partials would cost more than the in_finalize2 launch it saves
-        g.fin_counter = (c.stat_part && c.fin_counter && g.tpi <= 32 && (size_t)g.N * ((g.Npad + 31) / 32) <= kFinCounterInts) ? c.fin_counter : nullptr;
+        // few tiles per image: the last workgroup of each (image, channel tile) finalises the statistics (conv_epilogue).  Many tiles per
+        // image (the 64^2 .. 256^2 layers): the in_finalize2 launch spreads the fold over C / 16 x N workgroups.  Round 6 measured the
+        // alternative -- a two-level in-kernel finalize, groups of 32 tiles then groups -- against it in one process: 5.062 vs 5.035 ms
+        // per forward for the launch (profiles/round6_ab_twolevel.txt): the last group's serial tail (6 memory round trips + 2 hand-offs
+        // on the stem) costs more than a kernel boundary + a 4 us kernel, once that kernel's loads are batched.
+        g.fin_counter = (c.stat_part && c.fin_counter && g.tpi <= kFinGroup && (size_t)g.N * ((g.Npad + 31) / 32) <= kFinCounterInts) ? c.fin_counter : nullptr;
     };
     // 256 CUs each run ceil(tiles / 256) tiles (co-resident workgroups share the MFMA pipe): minimise that count x tile area / efficiency
     auto wide_pays = [&](long tm, double gain) {
@@ -309,19 +328,22 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
             // but a chunk's first disappears under its predecessor's last two periods.  Every XCD owns whole rows of the tile matrix (or its
             // cell of the XCD grid) and the chunk size must divide their count.  A chunk that crosses into the next image needs the second
             // transform table in LDS (it fits up to 512 input channels; a raw input has no table); without it chunks stay inside an image.
-            // Three periods per tile at least (the fetch stream runs one item past the next tile's V(1)).  Chosen where the chunks fill the
-            // 256 CUs in whole rounds; c.tile = 1, 2, 3 forces a size (op tests, tools).
+            // Chosen where the chunks fill the CUs in whole rounds -- so the chunk size DOES depend on the batch; what keeps a frame's bits
+            // independent of its batch is that every chunk size runs the same chains per output element (bit-identical, tested at the
+            // forward's shapes and under random ones).  c.tile = 1, 2, 3 forces a size (op tests, tools).
             {
                 const int n = g.tiles_m * g.tiles_n, npp = ((g.Cin >> 4) + 1) / 2;
                 const int rows = gn ? g.tiles_m / (8 / gn) : (g.tiles_m % 8 ? 0 : g.tiles_m / 8);
                 const bool tab2 = !c.alpha || w1_lds_bytes_host(g.Cin, 2) + 256 <= 160 * 1024;
-                auto fits = [&](int cc) { return cc == 1 || (c.nprod != 1 && npp >= 3 && rows > 0 && rows % cc == 0 && (tab2 || g.tpi % cc == 0)); };
+                // (four periods at least: the fetch stream reads the next tile's periods 0..2 without the last period's tail mask -- with three
+                // periods and an odd slab count, period 2 would stage another pixel's channels past Cin)
+                auto fits = [&](int cc) { return cc == 1 || (c.nprod != 1 && npp >= 4 && rows > 0 && rows % cc == 0 && (tab2 || g.tpi % cc == 0)); };
                 int cc = 1;
                 if (c.tile >= 1 && c.tile <= 3) {
                     if (!fits(c.tile)) throw ArgError("conv(w1): this chunk size does not fit the layer");
                     cc = c.tile;
                 } else {
-                    for (int t : {3, 2}) if (fits(t) && n % (256 * t) == 0) { cc = t; break; }
+                    for (int t : {3, 2}) if (fits(t) && n % (device_cus() * t) == 0) { cc = t; break; }
                 }
 #ifdef TSNET_TOOLS
                 if (!c.tile && cc > g_tools_knob[0]) cc = 1;          // tools/forward_ab.py: the same forward with and without chunks, one process
@@ -395,11 +417,30 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         } else {
             if (c.abl || c.opt) throw ArgError("conv: experiment variants exist for the 3x3 / stride-1 patch kernel only");
             const long tm = (long)c.N * ((hw + 127) / 128);
+            // 64-deep K steps (conv_g64.hpp: the same bits, a quarter of the barriers and address computations, whole cache lines per
+            // load) wherever the layer allows: 1 x 1 / 3 x 3, input channels (and the concat split) multiples of 64, 128-wide output.  In the
+            // forward: the two 1 x 1 convolutions, the 64 -> 128 stride-2 layer and, with bf16 operands, every stride-2 layer.  Tile codes
+            // 3064 / 3128 (with kernel = general) request it with 64 / 128 rows; 64 / 128 request conv_h2r with that width.
+            const bool g64_ok = (L.ks == 1 || L.ks == 3) && (g.Cin & 63) == 0 && (!c.x2 || (g.Csplit & 63) == 0) && g.Npad % 128 == 0 && g.Cout > 64 &&
+                                (c.nprod == 1 || c.nprod == 3);
+            if (c.tile == 3064 || c.tile == 3128 || (!c.tile && g64_ok)) {
+                if (!g64_ok) throw ArgError("conv(g64): needs a 1 x 1 / 3 x 3 layer, input channels in multiples of 64 and more than 64 output channels");
+                // rows per tile: 64 in every batch (with statistics the tile decides the partial sums' grouping, so it may never depend on the
+                // batch: a frame's bits do not)
+                // (measured, tools/g64_variants.py: the 128-row tile -- eight waves at 140 VGPRs: one workgroup per CU -- loses everywhere with
+                // fp16 x 2 operands, 208 vs 156 us on the 64 -> 128 stride-2 layer, and ties with bf16 operands)
+                const int bm = c.tile ? c.tile - 3000 : 64;
+                set_tiles(bm, 128);
+                launch_conv_g64(g, L.ks, bm, c.nprod, ctx.stream);
+                ++g_launch_counters[1];
+            } else {
             int bn = c.tile ? c.tile : ((L.ks == 3 && L.cin_pad >= 16 && wide_pays(tm, 1.15)) ? 128 : 64);
+            if (bn != 64 && bn != 128) throw ArgError("conv(h2r): the tile width must be 64 or 128");
             if (g.Npad % bn) throw ArgError("conv(h2r): the tile width must divide the padded output width");
             set_tiles(128, bn);
             launch_conv_h2r(g, L.ks, bn, c.nprod, ctx.stream);
             ++g_launch_counters[1];
+            }
         }
     } catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
     check_launch("conv");
@@ -447,6 +488,8 @@ void run_add_stats(Ctx& ctx, const float* x, const float* add, int add_nmod, flo
     AddStatsArgs sa{x, add, y, part, HW, C, S, rps, add_nmod > 0 ? add_nmod : 1};
     hipLaunchKernelGGL(add_stats_partial_kernel, dim3(S, N, (cq + 255) / 256), dim3(256), 0, ctx.stream, sa);
     check_launch("add_stats_partial");
+    // (its finalize stays a launch: 64 splits x 1024 channels per image are a megabyte of partials -- one last-arriving workgroup per image
+    // would read them at a single block's rate, in_finalize2 spreads them over 64 x N)
     launch_finalize(part, alpha, beta, N, C, S, HW, ctx.stream);
 }
 
@@ -640,13 +683,13 @@ struct tsnet_engine {
     float* flow_part = nullptr;        // its partial softmax states (large maps only)
     hipStream_t side_stream = nullptr; // target-label chain of a full forward runs here, concurrently with the source encoder
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_done = nullptr;      // recorded behind the last launch of a forward on the caller's stream
     float* train_ws = nullptr;         // workspace of tsnet_train_extras, allocated on first use
 
     // clip-mode cache
     int cached_B = 0;
     float* bbox_copy = nullptr;     // (K, Bmax, H, W) device copies of the source bboxes
     int last_B = 0;
-    hipStream_t last_stream = nullptr;    // the caller's stream of the last forward (tsnet_stage_ptr orders its widening pass behind it)
     int cur_B = 0;                        // batch of the forward being enqueued
     float src_div[TSNET_MAX_SOURCES];  // per-source image divisor (255; 1 for use_prev sources), tsnet_set_source_divisors
 
@@ -880,7 +923,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     size_t part_doubles = NB * 64 * 2 * C * 2;
     for (int l = 0; l <= cfg.n_downsampling; ++l) {
         const size_t hw = (size_t)(H >> l) * (W >> l), tpi = (hw + 63) / 64;
-        part_doubles = std::max(part_doubles, NB * tpi * (size_t)std::max(cfg.ngf << l, 2 * C) * 2);
+        part_doubles = std::max(part_doubles, stat_part_doubles(NB, tpi, (size_t)std::max(cfg.ngf << l, 2 * C)));
     }
     float *part_f = nullptr, *part_side_f = nullptr;
     want(&part_f, 2 * part_doubles); want(&part_side_f, 2 * part_doubles);
@@ -906,6 +949,7 @@ void tsnet_engine::alloc_all(hipStream_t s) {
     HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
 }
 
 void tsnet_engine::resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float stream_bound, const unsigned* stream_amax,
@@ -1085,7 +1129,8 @@ void tsnet_engine::forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb,
         for (int c = 0; c < 3; ++c) ha.bg[c] = (-cfg.pose_mean[c]) / 255.0f;             // TSNet_pose.py:276
         launch_head(ha, hh, ww, B, ctx.stream);
     }
-    last_B = B; last_stream = ctx.stream;
+    last_B = B;
+    HIP_TRY(hipEventRecord(ev_done, ctx.stream));       // what tsnet_stage_ptr orders its widening pass behind
 }
 
 // ================================================================================================
@@ -1191,6 +1236,7 @@ void tsnet_destroy(tsnet_handle h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     (void)hipFree(h->wpack); (void)hipFree(h->arena); (void)hipFree(h->d_coords); (void)hipFree(h->d_gx); (void)hipFree(h->d_gy);
     delete h;
 }
@@ -1332,11 +1378,13 @@ int tsnet_stage_ptr(tsnet_handle h, const char* name, const float** dev_ptr, siz
         const int i = n[6] - '0';        // raw output of the i-th decoder up-convolution (before its InstanceNorm)
         p = h->R[i]; c = B * ((size_t)(h->h << (i + 1)) * (h->w << (i + 1)) * (h->C >> (i + 1)));
         if (h->st16) {                   // stored as bf16: widened into the (now idle, twice as large) upsampled-input buffer of the same level
-            // on the stream of the last forward: ordered behind it, and ahead of a forward started next on that stream -- the engine's
-            // streams are non-blocking, the NULL stream orders nothing against them
-            hipLaunchKernelGGL(bf16_widen_kernel, dim3(ew_grid(c)), dim3(256), 0, h->last_stream, reinterpret_cast<const unsigned short*>(h->R[i]), h->U[i], c);
+            // ordered behind the last forward -- the engine's streams are non-blocking, the NULL stream orders nothing against them
+            // ... and not on the caller's stream handle either, which may be gone by now: the forward leaves an event behind its last
+            // launch; the engine's own side stream waits for it, widens and is drained before this call returns
+            HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_done, 0));
+            hipLaunchKernelGGL(bf16_widen_kernel, dim3(ew_grid(c)), dim3(256), 0, h->side_stream, reinterpret_cast<const unsigned short*>(h->R[i]), h->U[i], c);
             check_launch("bf16_widen");
-            HIP_TRY(hipStreamSynchronize(h->last_stream));
+            HIP_TRY(hipStreamSynchronize(h->side_stream));
             p = h->U[i];
         }
     }
@@ -1589,6 +1637,29 @@ int tsnet_op_warp(const float* src_fea, const float* flow, int B, int h, int w, 
     OP_END
 }
 
+int tsnet_op_warp_k(const float* src_fea, const float* flow, int B, int K, int h, int w, int C, float* out, int repeat, float* ms_out, void* stream) {
+    OP_BEGIN
+    if (!src_fea || !flow || !out) throw ArgError("null tensor");
+    if (C & 3) throw ArgError("warp op: C must be a multiple of 4");
+    if (B < 1 || K < 1 || K > TSNET_MAX_SOURCES || h < 1 || w < 1) throw ArgError("warp op: bad shape");
+    Ctx ctx; ctx.stream = (hipStream_t)stream;
+    if (ms_out) *ms_out = 0.f;
+    run_warp(ctx, src_fea, flow, out, B, K, h, w, C);
+    if (repeat > 1) {                    // launches 2 .. repeat between two events: the kernel ALONE (tools/warp_bench.py)
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, ctx.stream));
+        for (int i = 1; i < repeat; ++i) run_warp(ctx, src_fea, flow, out, B, K, h, w, C);
+        HIP_TRY(hipEventRecord(e1, ctx.stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (ms_out) *ms_out = t / (float)(repeat - 1);
+    }
+    OP_END
+}
+
 int tsnet_frame_stats(const float* x, int B, int C, int HW, float div, float* mean, float* std_unbiased, void* stream) {
     OP_BEGIN
     if (!x || !mean || !std_unbiased) throw ArgError("frame_stats: null tensor");
@@ -1785,7 +1856,7 @@ int tsnet_bench_conv(int N, int H, int W, int Cin, int Cout, int ksize, int stri
         if (norm & 1) { c.alpha = al; c.beta = be; c.relu = 1; }
         if (norm & 2) {                                              // with the InstanceNorm statistics of the output, as the forward's layers run
             const size_t tpi = ((size_t)Ho * Wo + 63) / 64;
-            c.stat_part = mem.alloc<double>((size_t)N * tpi * Cout * 2 * sizeof(double));
+            c.stat_part = mem.alloc<double>(stat_part_doubles(N, tpi, Cout) * sizeof(double));
             c.fin_alpha = mem.alloc<float>((size_t)N * Cout * 4); c.fin_beta = mem.alloc<float>((size_t)N * Cout * 4);
             c.fin_counter = mem.alloc<int>(kFinCounterInts * sizeof(int));
             HIP_TRY(hipMemset(c.fin_counter, 0, kFinCounterInts * sizeof(int)));

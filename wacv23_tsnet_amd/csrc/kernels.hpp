@@ -1,5 +1,5 @@
 // kernels.hpp -- launchers of the convolution kernels and the large-map flow kernel.  Each kernel family lives in its own translation unit
-// (conv_h2_launch.cpp, conv_h2r_launch.cpp, conv_w1_launch.cpp, flow_p_launch.cpp) so that the library builds in parallel and the MFMA
+// (conv_h2_launch.cpp, conv_h2r_launch.cpp, conv_g64_launch.cpp, conv_w1_launch.cpp, flow_p_launch.cpp) so that the library builds in parallel and the MFMA
 // kernels build without the SLP vectorizer; engine.cpp holds the host logic and the small kernels.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -22,6 +22,9 @@ void launch_conv_h2d(const ConvArgs& a, int pr, int bn, int nprod, hipStream_t s
 void launch_conv_w1(const ConvArgs& a, int nprod, int abl, hipStream_t s);      // abl: tools build only
 // conv_h2r.hpp -- general implicit GEMM: ks in {1, 3, 7}, bn = 64 (any) or 128 (ks = 3, Cin >= 16); Cin = 8 or a power of two >= 16
 void launch_conv_h2r(const ConvArgs& a, int ks, int bn, int nprod, hipStream_t s);
+// conv_g64.hpp -- the same GEMM in 64-deep K steps (Cin, and the concat split, multiples of 64; Npad a multiple of 128): ks in {1, 3},
+// bm = 64 (four waves) or 128 (eight waves) rows x 128 channels; the same bits as conv_h2r
+void launch_conv_g64(const ConvArgs& a, int ks, int bm, int nprod, hipStream_t s);
 
 // flow_persist.hpp -- flow_kernel_p: a.K, a.G (flowp_plan), a.part, a.cnt set by the caller; variant: tools build only
 void launch_flow_p(const FlowArgs& a, int variant, hipStream_t s);
