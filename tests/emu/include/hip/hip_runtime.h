@@ -103,6 +103,7 @@ static inline void emu_split_pair(float a, float b, unsigned& hw, unsigned& lw) 
 }
 #define TSNET_SPLIT_PAIR(a, b, hw, lw) emu_split_pair((a), (b), (hw), (lw))
 #define TSNET_SPLIT_2PAIRS(a0, b0, a1, b1, h0, l0, h1, l1) do { emu_split_pair((a0), (b0), (h0), (l0)); emu_split_pair((a1), (b1), (h1), (l1)); } while (0)
+#define TSNET_SPLIT_2PAIRS_SCALED(a0, b0, a1, b1, s, h0, l0, h1, l1) do { emu_split_pair((a0) * (s), (b0) * (s), (h0), (l0)); emu_split_pair((a1) * (s), (b1) * (s), (h1), (l1)); } while (0)
 static inline unsigned emu_bf16_rne(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16; }
 #define TSNET_CVT_PK_BF16(a, b) ((emu_bf16_rne(a) & 0xFFFFu) | (emu_bf16_rne(b) << 16))
 #define TSNET_SETPRIO(n) ((void)0)

@@ -73,6 +73,24 @@ typedef __bf16 tsnet_bf16x8 __attribute__((ext_vector_type(8)));
         : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)                                                              \
         : "v"(a0), "v"(b0), "v"(a1), "v"(b1))
 #endif
+// The same split of (a0, b0, a1, b1) * s for a power-of-two s held in a register: v_fma_mix evaluates a * s (exact) and rounds once to fp16,
+// so hi = rne16(a s) costs one instruction per VALUE where multiply + v_cvt_pk_f16_f32 cost three per pair -- eight instructions for two
+// pairs instead of ten -- and lo = rne16(a s - hi) as before (the difference is exact in fp32).  Same bits as TSNET_SPLIT_2PAIRS on the
+// products (tests: the emulator evaluates the C form; the GPU op tests compare against it through the fp64 reference and across kernels).
+// Every mixhi stands at least one instruction behind the mixlo of its register (partial-write forwarding hazard, as above).
+#ifndef TSNET_SPLIT_2PAIRS_SCALED
+#define TSNET_SPLIT_2PAIRS_SCALED(a0, b0, a1, b1, s, h0, l0, h1, l1)                                              \
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]\n\t"                                       \
+        "v_fma_mixlo_f16 %1, %6, %8, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]\n\t"                                       \
+        "v_fma_mixhi_f16 %0, %5, %8, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]\n\t"                                       \
+        "v_fma_mixhi_f16 %1, %7, %8, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]\n\t"                                       \
+        "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"                                     \
+        "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"                                     \
+        "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"                                     \
+        "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"                                          \
+        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)                                                               \
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(s))
+#endif
 #ifndef TSNET_FAST_EXP
 #define TSNET_FAST_EXP(x) __expf(x)
 #endif

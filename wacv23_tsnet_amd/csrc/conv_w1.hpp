@@ -79,6 +79,101 @@ static __device__ unsigned long long g_w1_prof[kW1ProfTiles * kW1Waves * kW1Prof
 #define TSNET_W1_PUT(slot, v) do { } while (0)
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------
+// THE ARITHMETIC of the kernel, written once: the chunk path below and the one-tile path (conv_w1_one.hpp) differ in how a workgroup is
+// scheduled -- prologue, tiles per workgroup, where the next fetch comes from -- and share these three pieces, so a change to the
+// transform, the split, the product order or the output transform is made in one place (the two kernels used to carry a copy each).
+//
+// (1) Producer: four input pixels x four channels of one column pair -> the four Winograd positions, split, one ds_write_b64 per plane.
+//     b[q] = pixel q of the pair as fetched (zeros for a padded pixel); pad[q] = that pixel lies in the ZERO padding of an InstanceNorm-ed
+//     input (re-zeroed after the affine transform: a padded pixel is zero, not beta); ta = the image's table at the item's first channel
+//     (alpha * s, then beta * s at + cp32); scale = the operand scale s of a raw input.
+//     A raw input WITHOUT ReLU (the residual stream, the upsampled maps: NO_RELU) is transformed unscaled and scaled inside the split --
+//     s is a power of two, (d0 - d2) s == d0 s - d2 s exactly, and v_fma_mix takes the factor as an operand (TSNET_SPLIT_2PAIRS_SCALED):
+//     16 multiplies fewer per item in the waves whose instruction count bounds the K loop (60 -> 52 VALU per item).
+template <int NPROD, bool AFFINE, bool ZPAD_KEEP, bool NO_RELU, int POSB, int PLANE_V>
+__device__ __forceinline__ void w1_put_item(const F4 (&b)[4], const bool (&pad)[4], const float* ta, const int cp32, const float scale,
+                                            const float relu_floor, unsigned char* dst) {
+    struct alignas(8) U2 { unsigned x, y; };
+    constexpr bool LATE_SCALE = !AFFINE && NO_RELU && NPROD != 1;
+    F4 d[4];
+    if (AFFINE) {
+        const F4 al = *reinterpret_cast<const F4*>(ta), be = *reinterpret_cast<const F4*>(ta + cp32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = __builtin_fmaxf(__builtin_fmaf(b[q].v[e], al.v[e], be.v[e]), relu_floor);
+                d[q].v[e] = (ZPAD_KEEP && pad[q]) ? 0.f : v;
+            }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[q].v[e] = LATE_SCALE ? b[q].v[e] : (NO_RELU ? b[q].v[e] * scale : __builtin_fmaxf(b[q].v[e] * scale, relu_floor));
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d0 = d[0].v[e], d1 = d[1].v[e], d2 = d[2].v[e], d3 = d[3].v[e];
+            v[e] = p == 0 ? d0 - d2 : (p == 1 ? d1 + d2 : (p == 2 ? d2 - d1 : d1 - d3));
+        }
+        if (NPROD == 1) {
+            U2 h;
+            h.x = TSNET_CVT_PK_BF16(v[0], v[1]);
+            h.y = TSNET_CVT_PK_BF16(v[2], v[3]);
+            *reinterpret_cast<U2*>(dst + p * POSB) = h;
+        } else {
+            U2 h, l;
+            if (LATE_SCALE) TSNET_SPLIT_2PAIRS_SCALED(v[0], v[1], v[2], v[3], scale, h.x, l.x, h.y, l.y);
+            else TSNET_SPLIT_2PAIRS(v[0], v[1], v[2], v[3], h.x, l.x, h.y, l.y);
+            *reinterpret_cast<U2*>(dst + p * POSB) = h;
+            *reinterpret_cast<U2*>(dst + p * POSB + PLANE_V) = l;
+        }
+    }
+}
+
+// (2) Consumer: the MFMA products of one step (tap row, slab) on the wave's two 32-pair halves: lo * hi, hi * lo, hi * hi in this order into
+//     the period's chain (`fresh`: the chain starts here), or the single bf16 product.  a0 / a1: the A fragments of the two halves, [plane].
+template <int NPROD, int NPL>
+__device__ __forceinline__ void w1_step_products(f32x16 (&acc)[2], const F4 (&a0)[NPL], const F4 (&a1)[NPL], const F4 (&bw)[NPL], const bool fresh) {
+    auto product = [&](int pa, int pb, bool fr) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x16 c = acc[i];
+            if (fr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+            }
+            const F4& A = i ? a1[pa] : a0[pa];
+            if (NPROD == 1) acc[i] = TSNET_MFMA_BF16(A, bw[pb], c);
+            else acc[i] = TSNET_MFMA_F16(A, bw[pb], c);
+        }
+    };
+    if (NPROD == 1) {
+        product(0, 0, fresh);
+    } else {
+        product(NPL - 1, 0, fresh);          // lo * hi
+        product(0, NPL - 1, false);          // hi * lo
+        product(0, 0, false);                // hi * hi
+    }
+}
+
+// (3) Output transform: the four positions M0..M3 of the column pairs of one output row half (m: the pair-major exchange region at this lane's
+//     first pair and channel, pstride floats between positions) -> the lane's 16 accumulator rows = 8 pairs x (even pixel, odd pixel).
+__device__ __forceinline__ void w1_output_transform(const float* m, const int pstride, const int lh, f32x16& out) {
+#pragma unroll
+    for (int r2 = 0; r2 < 8; ++r2) {                                 // accumulator rows 2 r2, 2 r2 + 1 = pixels (x, x + 1) of one pair
+        const int x = ((2 * r2) & 3) + 8 * ((2 * r2) >> 2) + 4 * lh;
+        const float* q = m + (size_t)(x >> 1) * 64;
+        const float m0 = q[0], m1 = q[pstride], m2 = q[2 * pstride], m3 = q[3 * pstride];
+        out[2 * r2] = (m0 + m1) + m2;
+        out[2 * r2 + 1] = (m1 - m2) - m3;
+    }
+}
+
 // A workgroup runs a CHUNK of a.w1_chunk consecutive tiles (1, 2 or 3: run_conv picks it so that the chunks fill the chip in whole rounds).
 // Measured on the one-tile form (tools/w1_timeline.py, ResnetBlock layer at the headline batch): of a tile's 44 - 45 us, 35 are the K loop;
 // 3.2 - 3.8 us pass before its first MFMA (the table, then V(0) and V(1): the consumers wait at the prologue barrier), 4.5 - 5 us after its
@@ -209,16 +304,7 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         f32x16 out[1][1];
         unsigned char* const ebase = two_pass ? smem_raw + st_free : smem_raw;
         float* const ex = reinterpret_cast<float*>(ebase);           // one pass: [position][pair 64][channel 64]; two: [position][pair 32][channel 64]
-        auto transform = [&](const float* m, const int pstride) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r2 = 0; r2 < 8; ++r2) {                         // accumulator rows 2 r2, 2 r2 + 1 = pixels (x, x + 1) of one pair
-                const int x = ((2 * r2) & 3) + 8 * ((2 * r2) >> 2) + 4 * lh;
-                const float* q = m + (size_t)(x >> 1) * 64;
-                const float m0 = q[0], m1 = q[pstride], m2 = q[2 * pstride], m3 = q[3 * pstride];
-                out[0][0][2 * r2] = (m0 + m1) + m2;
-                out[0][0][2 * r2 + 1] = (m1 - m2) - m3;
-            }
-        };
+        auto transform = [&](const float* m, const int pstride) __attribute__((always_inline)) { w1_output_transform(m, pstride, lh, out[0][0]); };
         if (!two_pass) {
             if (consumer) {
 #pragma unroll
@@ -318,7 +404,6 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         const float* tab_nxt = tab0;
         const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();
         F4 sx[2][4];                                                 // two items in turn: four pixels x four channels each
-        struct alignas(8) U2 { unsigned x, y; };
         // Which tile an item belongs to is decided where the loop is written, not per load: the period loop below is split at the tile
         // boundary (every select, compare and branch in here is an issue slot taken from the MFMA waves of the same SIMD; the first form
         // spent 71 scalar instructions and 27 s_nop per two items).  SRC: 0 = the current tile, 1 = its last period, 2 = the next tile.
@@ -334,45 +419,11 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         auto v_put = [&](auto SRC, int pe, int it, int st, const F4 (&b)[4]) __attribute__((always_inline)) {   // transform + split + store of a fetched item into the stage at st
             constexpr bool nx = decltype(SRC)::value == 2;
             const int c0 = pe * 32 + quad * 4;
-            const float scale = nx ? Tn.in_scale : T.in_scale;
-            F4 d[4];
-            if (AFFINE) {
-                const float* ta = (nx ? tab_nxt : tab_cur) + c0;
-                const F4 al = *reinterpret_cast<const F4*>(ta), be = *reinterpret_cast<const F4*>(ta + cp32);
+            bool pad[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = __builtin_fmaxf(__builtin_fmaf(b[q].v[e], al.v[e], be.v[e]), relu_floor);
-                        d[q].v[e] = (ZPAD_KEEP && (nx ? nxt.vP[it][q] : cur.vP[it][q]) == kOOB) ? 0.f : v;     // a padded pixel is zero, not beta
-                    }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) d[q].v[e] = NO_RELU ? b[q].v[e] * scale : __builtin_fmaxf(b[q].v[e] * scale, relu_floor);
-            }
-            unsigned char* dst = smem_raw + st + ldst[it];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d0 = d[0].v[e], d1 = d[1].v[e], d2 = d[2].v[e], d3 = d[3].v[e];
-                    v[e] = p == 0 ? d0 - d2 : (p == 1 ? d1 + d2 : (p == 2 ? d2 - d1 : d1 - d3));
-                }
-                if (NPROD == 1) {
-                    U2 h;
-                    h.x = TSNET_CVT_PK_BF16(v[0], v[1]);
-                    h.y = TSNET_CVT_PK_BF16(v[2], v[3]);
-                    *reinterpret_cast<U2*>(dst + p * POSB) = h;
-                } else {
-                    U2 h, l;
-                    TSNET_SPLIT_2PAIRS(v[0], v[1], v[2], v[3], h.x, l.x, h.y, l.y);
-                    *reinterpret_cast<U2*>(dst + p * POSB) = h;
-                    *reinterpret_cast<U2*>(dst + p * POSB + PLANE_V) = l;
-                }
-            }
+            for (int q = 0; q < 4; ++q) pad[q] = ZPAD_KEEP && (nx ? nxt.vP[it][q] : cur.vP[it][q]) == kOOB;
+            w1_put_item<NPROD, AFFINE, ZPAD_KEEP, NO_RELU, POSB, PLANE_V>(b, pad, (nx ? tab_nxt : tab_cur) + c0, cp32, nx ? Tn.in_scale : T.in_scale, relu_floor,
+                                                                        smem_raw + st + ldst[it]);
         };
         // an item by its period pq counted from the current tile (pq >= npp: the next tile's), the source picked by branches: the prologue
         // and tiles of fewer than five periods (the hot layers have 16 and 32)
@@ -487,18 +538,6 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        auto product = [&](int sl, int ky, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f32x16 c = acc[i];
-                if (fresh) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
-                }
-                if (NPROD == 1) acc[i] = TSNET_MFMA_BF16(af[sl][ky + 2 * i][pa], bf[sb][pb], c);
-                else acc[i] = TSNET_MFMA_F16(af[sl][ky + 2 * i][pa], bf[sb][pb], c);
-            }
-        };
         // One period = two slabs = six steps (t: slab t / 3, tap row t % 3) between two barriers = one accumulation chain.  st_cur is read
         // now, st_nxt = the next period (complete before this period's barrier: its first fragments are fetched at the last step).  Step
         // (sl, ky) uses fragments ky and ky + 2 of slab sl; weights BD - 1 steps ahead.
@@ -526,13 +565,7 @@ __device__ __forceinline__ void w1_chunk(const ConvArgs& a, unsigned char* smem_
                     if (t == 5) { load_f(0, 0, st_nxt); load_f(0, 2, st_nxt); }
                 }
                 const bool fresh = (!ONE_LEVEL && t == 0) || (ONE_LEVEL && t == 0 && first);
-                if (NPROD == 1) {
-                    product(sl, ky, t % BD, 0, 0, fresh);
-                } else {
-                    product(sl, ky, t % BD, 1, 0, fresh);            // lo * hi
-                    product(sl, ky, t % BD, 0, 1, false);            // hi * lo
-                    product(sl, ky, t % BD, 0, 0, false);            // hi * hi
-                }
+                w1_step_products<NPROD, NPL>(acc, af[sl][ky], af[sl][ky + 2], bf[t % BD], fresh);
                 __builtin_amdgcn_sched_barrier(0);                   // loads stay ahead of their use (conv_h2.hpp)
             }
             if (!ONE_LEVEL) {

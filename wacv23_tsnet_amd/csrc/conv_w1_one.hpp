@@ -79,7 +79,6 @@ __device__ __forceinline__ void w1_tile_one(const ConvArgs& a, unsigned char* sm
         const int pw = wave - 8, quad = lane & 7;
         const int psl = quad >> 2, poct = (quad >> 1) & 1, psub = quad & 1;
         unsigned vP[NIT][4];
-        float vM[NIT][4];
         int ldst[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -103,13 +102,11 @@ __device__ __forceinline__ void w1_tile_one(const ConvArgs& a, unsigned char* sm
                     ok = ok && ix >= 0 && ix < a.W;
                 }
                 vP[it][q] = ok ? (unsigned)(((img * a.H * a.W + iy * a.W + ix) * a.Cin + quad * 4) * 4) : kOOB;
-                vM[it][q] = ok ? 1.f : 0.f;
             }
             ldst[it] = psl * SLABB + poct * REG + (prow * 16 + ppair) * 16 + psub * 8;
         }
         const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();
         F4 sx[2][4];                                                 // two items in turn: four pixels x four channels each
-        struct alignas(8) U2 { unsigned x, y; };
         auto v_load = [&](int pq, int it, int buf) __attribute__((always_inline)) {   // period pq; channels past Cin (the second slab of an odd count) read zeros, like the weights of that slab
             const bool cok = pq * 32 + quad * 4 < a.Cin;
 #pragma unroll
@@ -117,44 +114,11 @@ __device__ __forceinline__ void w1_tile_one(const ConvArgs& a, unsigned char* sm
         };
         auto v_item = [&](int pq, int it, int st, int buf) __attribute__((always_inline)) {   // transform + split + store of a fetched item into the stage at st
             const int c0 = pq * 32 + quad * 4;
-            F4 d[4];
-            if (AFFINE) {
-                const float* ta = tab + (c0 < cp32 ? c0 : 0);                // (periods past the tile: never read)
-                const F4 al = *reinterpret_cast<const F4*>(ta), be = *reinterpret_cast<const F4*>(ta + cp32);
+            bool pad[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = __builtin_fmaxf(__builtin_fmaf(sx[buf][q].v[e], al.v[e], be.v[e]), relu_floor);
-                        d[q].v[e] = ZPAD_KEEP ? v * vM[it][q] : v;
-                    }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) d[q].v[e] = NO_RELU ? sx[buf][q].v[e] * in_scale : __builtin_fmaxf(sx[buf][q].v[e] * in_scale, relu_floor);
-            }
-            unsigned char* dst = smem_raw + st + ldst[it];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d0 = d[0].v[e], d1 = d[1].v[e], d2 = d[2].v[e], d3 = d[3].v[e];
-                    v[e] = p == 0 ? d0 - d2 : (p == 1 ? d1 + d2 : (p == 2 ? d2 - d1 : d1 - d3));
-                }
-                if (NPROD == 1) {
-                    U2 h;
-                    h.x = TSNET_CVT_PK_BF16(v[0], v[1]);
-                    h.y = TSNET_CVT_PK_BF16(v[2], v[3]);
-                    *reinterpret_cast<U2*>(dst + p * POSB) = h;
-                } else {
-                    U2 h, l;
-                    TSNET_SPLIT_2PAIRS(v[0], v[1], v[2], v[3], h.x, l.x, h.y, l.y);
-                    *reinterpret_cast<U2*>(dst + p * POSB) = h;
-                    *reinterpret_cast<U2*>(dst + p * POSB + PLANE_V) = l;
-                }
-            }
+            for (int q = 0; q < 4; ++q) pad[q] = ZPAD_KEEP && vP[it][q] == kOOB;
+            w1_put_item<NPROD, AFFINE, ZPAD_KEEP, NO_RELU, POSB, PLANE_V>(sx[buf], pad, tab + (c0 < cp32 ? c0 : 0) /* (periods past the tile: never read) */, cp32, in_scale,
+                                                                        relu_floor, smem_raw + st + ldst[it]);
         };
         // the item stream (period, item): each item is fetched while its predecessor is transformed; two buffers in turn
         v_load(0, 0, 0);
@@ -197,18 +161,6 @@ __device__ __forceinline__ void w1_tile_one(const ConvArgs& a, unsigned char* sm
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        auto product = [&](int sl, int ky, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f32x16 c = acc[i];
-                if (fresh) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
-                }
-                if (NPROD == 1) acc[i] = TSNET_MFMA_BF16(af[sl][ky + 2 * i][pa], bf[sb][pb], c);
-                else acc[i] = TSNET_MFMA_F16(af[sl][ky + 2 * i][pa], bf[sb][pb], c);
-            }
-        };
         // One period = two slabs = six steps (t: slab t / 3, tap row t % 3) between two barriers = one accumulation chain.  st_cur is read
         // now, st_nxt = period pp + 1 (complete before this period's barrier: its first fragments are fetched at the last step).  Step
         // (sl, ky) uses fragments ky and ky + 2 of slab sl; weights BD - 1 steps ahead.
@@ -225,13 +177,7 @@ __device__ __forceinline__ void w1_tile_one(const ConvArgs& a, unsigned char* sm
                     if (t == 5) { load_f(0, 0, st_nxt); load_f(0, 2, st_nxt); }
                 }
                 const bool fresh = !ONE_LEVEL && t == 0;
-                if (NPROD == 1) {
-                    product(sl, ky, t % BD, 0, 0, fresh);
-                } else {
-                    product(sl, ky, t % BD, 1, 0, fresh);            // lo * hi
-                    product(sl, ky, t % BD, 0, 1, false);            // hi * lo
-                    product(sl, ky, t % BD, 0, 0, false);            // hi * hi
-                }
+                w1_step_products<NPROD, NPL>(acc, af[sl][ky], af[sl][ky + 2], bf[t % BD], fresh);
                 __builtin_amdgcn_sched_barrier(0);                   // loads stay ahead of their use (conv_h2.hpp)
             }
             if (!ONE_LEVEL) {
@@ -278,14 +224,7 @@ __device__ __forceinline__ void w1_tile_one(const ConvArgs& a, unsigned char* sm
     __syncthreads();
     const int mq = consumer ? wave >> 1 : 0;                         // epilogue role: output row mq of the tile, channel half nt
     f32x16 out[1][1];
-#pragma unroll
-    for (int r2 = 0; r2 < 8; ++r2) {                                 // accumulator rows 2 r2, 2 r2 + 1 = pixels (x, x + 1) of one pair
-        const int x = ((2 * r2) & 3) + 8 * ((2 * r2) >> 2) + 4 * lh;
-        const float* m = ex + (size_t)(mq * 16 + (x >> 1)) * 64 + wn0 + li;
-        const float m0 = m[0], m1 = m[64 * 64], m2 = m[2 * 64 * 64], m3 = m[3 * 64 * 64];
-        out[0][0][2 * r2] = (m0 + m1) + m2;
-        out[0][0][2 * r2 + 1] = (m1 - m2) - m3;
-    }
+    w1_output_transform(ex + (size_t)(mq * 16) * 64 + wn0 + li, 64 * 64, lh, out[0][0]);
     __syncthreads();                                                 // the shared epilogue reuses the region for its reductions
     const int m_img = img * a.Ho * a.Wo;
     conv_epilogue<64, 4, 2, 1, 1>(a, out, smem_raw, tid, consumer ? wave : nt, n0, (size_t)img * tper + tin,
