@@ -433,3 +433,20 @@ def conv_g64_cases(lib, dev, big=False):
     if big:
         worst = max(worst, conv_cat_case(lib, dev, 4, 32, 32, 512, 512, 512))
     return worst
+
+
+def conv_h2s32_cases(lib, dev, big=False):
+    """The pose model's 7 x 7 stems (32 padded input channels) on their patch kernel (csrc/conv_h2s32.hpp; kernel = 0: the layer's own) against
+    the general kernel (kernel = 1, conv_h2r) -- same K order and chains: EQUAL BITS -- and against the fp64 reference: one tile, several tiles
+    and images with reflection at all four borders, a narrow net (8 output channels), three channel tiles with a ragged last one, bf16 operands."""
+    worst = 0.0
+    shapes = [(1, 4, 32, 64, 3, True, 0), (2, 8, 64, 64, 3, False, 3), (1, 12, 32, 8, 3, True, 5), (1, 4, 64, 130, 3, True, 7), (1, 8, 32, 64, 1, True, 9)]
+    if big:
+        shapes += [(2, 256, 256, 64, 3, True, 11)]
+    for (N, H, W, Cout, nprod, bias, seed) in shapes:
+        a = conv_case(lib, dev, N, H, W, 32, Cout, 7, 1, 3, True, nprod=nprod, bias=bias, seed=seed, kernel=1, tile=64, return_output=True)
+        b = conv_case(lib, dev, N, H, W, 32, Cout, 7, 1, 3, True, nprod=nprod, bias=bias, seed=seed, kernel=0, return_output=True)
+        assert torch.equal(a, b), (N, H, W, Cout, nprod, (a - b).abs().max().item())
+        if nprod == 3:
+            worst = max(worst, conv_case(lib, dev, N, H, W, 32, Cout, 7, 1, 3, True, nprod=nprod, bias=bias, seed=seed, kernel=2))
+    return worst

@@ -34,6 +34,11 @@ def test_conv_g64_equals_conv_h2r_bitwise(emu_lib):
     assert oc.conv_g64_cases(emu_lib, "cpu") < REL
 
 
+def test_conv_h2s32_pose_stem_equals_conv_h2r_bitwise(emu_lib):
+    """the pose model's 32-channel 7 x 7 stems on their own patch kernel (round 6): equal bits to the general kernel, < REL of the reference"""
+    assert oc.conv_h2s32_cases(emu_lib, "cpu") < REL
+
+
 def test_conv_cat_on_load(emu_lib):
     """dec.map_conv: 1x1 on cat(pg, sg) formed on load from two tensors (TSNet.py:163); also a 3x3 and a shared second tensor"""
     assert oc.conv_cat_case(emu_lib, "cpu", 2, 4, 8, 32, 32, 48) < REL

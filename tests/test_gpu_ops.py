@@ -46,6 +46,11 @@ def test_conv_g64_equals_conv_h2r_bitwise(lib):
     assert oc.conv_g64_cases(lib, DEV, big=True) < REL
 
 
+def test_conv_h2s32_pose_stem_equals_conv_h2r_bitwise(lib):
+    """the pose model's 32-channel 7 x 7 stems on their own patch kernel (csrc/conv_h2s32.hpp): equal bits to conv_h2r, also at 256 x 256"""
+    assert oc.conv_h2s32_cases(lib, DEV, big=True) < REL
+
+
 def test_conv_cat_on_load(lib):
     """dec.map_conv at its real shape: 1x1 on cat(pg, sg), 512 + 512 -> 512 channels, formed on load"""
     assert oc.conv_cat_case(lib, DEV, 4, 32, 32, 512, 512, 512) < REL

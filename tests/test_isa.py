@@ -36,7 +36,8 @@ def test_hot_kernels_do_not_spill_in_their_loops():
     # the encoder front end and the general kernel's layers of the headline forward (DESIGN.md section 1's "no spill in a hot loop" now
     # covers them; the one tolerated case is written down in tools/isa_check.py)
     for unit, pat, hot in (("conv_h2_launch.cpp", "conv_h2d_kernel", ic.HOT_FRONT[:2]), ("conv_h2_launch.cpp", "conv_h2s_kernel", ic.HOT_FRONT[2:]),
-                           ("conv_h2r_launch.cpp", "conv_h2r_kernel", ic.HOT_GENERAL), ("conv_g64_launch.cpp", "conv_g64_kernel", ic.HOT_G64)):
+                           ("conv_h2r_launch.cpp", "conv_h2r_kernel", ic.HOT_GENERAL), ("conv_g64_launch.cpp", "conv_g64_kernel", ic.HOT_G64),
+                           ("conv_g64_launch.cpp", "conv_h2s32_kernel", ic.HOT_S32)):
         rows = {r["name"]: r for r in ic.analyse(ic.compile_asm(unit=unit), pat)}
         for name, limit in hot:
             hit = [r for n, r in rows.items() if name in n]

@@ -12,6 +12,8 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 GEN, BF = 1 << 12, 1 << 13
 # name, (N, H, W, Cin, Cout, k, stride, pad, reflect), norm modes (1 = IN + ReLU on load, 2 = statistics of the output), variants
 CASES = [
+    ("pose stem 7x7 32->64, 12 images 256^2 (conv_h2s32 = the layer's own kernel)", (12, 256, 256, 32, 64, 7, 1, 3, 1), (2,), [("h2r 128x64", GEN | 64), ("h2s32 (own)", 0)]),
+    ("pose stem, 4 images (target lane)", (4, 256, 256, 32, 64, 7, 1, 3, 1), (2,), [("h2r 128x64", GEN | 64), ("h2s32 (own)", 0)]),
     ("fuse_net.conv / dec.map_conv 1x1 1024->512, B=4", (4, 32, 32, 1024, 512, 1, 1, 0, 0), (0,), [("h2r 128x64", GEN | 64), ("g64 64x128", GEN | 3064), ("g64 128x128", GEN | 3128)]),
     ("same, one frame", (1, 32, 32, 1024, 512, 1, 1, 0, 0), (0,), [("h2r 128x64", GEN | 64), ("g64 64x128", GEN | 3064)]),
     ("down1 64->128 s2, 12 images 256^2", (12, 256, 256, 64, 128, 3, 2, 1, 0), (3,), [("h2r 128x128", GEN | 128), ("g64 64x128", GEN | 3064), ("g64 128x128", GEN | 3128)]),

@@ -20,6 +20,7 @@ HOT_GENERAL = [("conv_h2r_kernel<3, 128, 2, 2, 3, true, false>", 0), ("conv_h2r_
 # ... and of its 64-deep-step form (conv_g64_launch.cpp, round 6), which now carries those layers in the forward: the 64-row tile, 1 x 1 on a raw input,
 # 3 x 3 stride 2 under a fused InstanceNorm + ReLU (fp16 x 2 operands: no spill; bf16 operands hold 4 spill operations per step at 119 - 123 VGPRs)
 HOT_G64 = [("conv_g64_kernel<1, 64, 3, false>", 0), ("conv_g64_kernel<3, 64, 3, true>", 0), ("conv_g64_kernel<3, 64, 1, true>", 4)]
+HOT_S32 = [("conv_h2s32_kernel<3>", 0), ("conv_h2s32_kernel<1>", 0)]      # the pose model's stems (same unit)
 
 
 def loops_of(body):

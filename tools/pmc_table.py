@@ -23,7 +23,7 @@ def load(dbdir):
     return agg
 
 def short(n):
-    m = re.search(r"(conv_h2[a-z]?|conv_w1)_kernel(?:<([^>]*)>)?", n)
+    m = re.search(r"(conv_h2[a-z]?|conv_g64|conv_w1_one|conv_w1)_kernel(?:<([^>]*)>)?", n)
     if m: return m.group(1) + ("<" + m.group(2).replace(" ", "").replace("false", "f").replace("true", "t") + ">" if m.group(2) else "")
     return re.sub(r"\(.*", "", n).split("::")[-1][:34]
 

@@ -4,7 +4,7 @@ import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 rows = cur.execute("select name, start, end, duration, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count from kernels order by start").fetchall()
 def short(n):
-    m = re.search(r"(conv_h2[a-z]?|conv_w1)_kernel<([^>]*)>", n)
+    m = re.search(r"(conv_h2[a-z]?|conv_g64|conv_w1_one|conv_w1)_kernel<([^>]*)>", n)
     if m: return "%s<%s>" % (m.group(1), m.group(2).replace(" ", "").replace("false", "f").replace("true", "t"))
     n = re.sub(r"\(.*", "", n); return n.split("::")[-1][:40]
 agg = {}

@@ -1,7 +1,9 @@
-// conv_g64_launch.cpp -- instantiations and launcher of the general implicit GEMM with 64-deep K steps (conv_g64.hpp).
+// conv_g64_launch.cpp -- instantiations and launchers of the general implicit GEMM with 64-deep K steps (conv_g64.hpp) and of the 32-channel
+// stem patch kernel (conv_h2s32.hpp): the two kernels that took over conv_h2r's hot layers in round 6.
 #include <stdexcept>
 
 #include "conv_g64.hpp"
+#include "conv_h2s32.hpp"
 #include "kernels.hpp"
 
 namespace tsnet {
@@ -34,6 +36,19 @@ void launch_conv_g64(const ConvArgs& a, int ks, int bm, int nprod, hipStream_t s
     if (nprod == 3) go_np<3>(a, ks, bm, s);
     else if (nprod == 1) go_np<1>(a, ks, bm, s);
     else throw std::invalid_argument("conv(g64): 1 (bf16 operands) or 3 products");
+}
+
+void launch_conv_h2s32(const ConvArgs& a, int nprod, hipStream_t s) {
+    if (a.Cin != 32 || a.taps != 49 || a.stride != 1 || a.pad != 3 || !a.reflect || a.in_alpha) throw std::invalid_argument("conv(h2s32): a 7 x 7 / reflection-pad-3 stem on 32 raw input channels");
+    if (nprod == 3) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2s32_kernel<3>), (size_t)h2s32_lds_bytes(2));
+        hipLaunchKernelGGL((conv_h2s32_kernel<3>), dim3(a.tiles_m * a.tiles_n), dim3(256), (size_t)h2s32_lds_bytes(2), s, a);
+    } else if (nprod == 1) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2s32_kernel<1>), (size_t)h2s32_lds_bytes(1));
+        hipLaunchKernelGGL((conv_h2s32_kernel<1>), dim3(a.tiles_m * a.tiles_n), dim3(256), (size_t)h2s32_lds_bytes(1), s, a);
+    } else {
+        throw std::invalid_argument("conv(h2s32): 1 (bf16 operands) or 3 products");
+    }
 }
 
 }  // namespace tsnet

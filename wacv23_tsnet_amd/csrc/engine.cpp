@@ -230,7 +230,7 @@ inline int h2_scale_log2(float bound) {
 
 // Kernel class of a layer at a frame size.  The patch kernels sum K slab-major, the general one tap-major: the class must depend on the
 // layer and the geometry alone, never on the batch (a sample's result is the same bits in any batch, B = 1 included).
-enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3, K_W1 = 4 };
+enum { K_GENERAL = 0, K_H2 = 1, K_H2S = 2, K_H2D = 3, K_W1 = 4, K_H2S32 = 5 };
 // a layer packed in the Winograd-along-x form runs conv_w1 and nothing else: 3 x 3 / stride 1 / pad 1 on frames of whole 4 x 32 tiles
 inline size_t w1_lds_bytes_host(int Cin, int tables) {       // conv_w1.hpp w1_lds_bytes for the two-plane stages
     return 3 * (size_t)(2 * (4 * 2 * 2 * (96 * 16 + 64) + 32)) + (size_t)tables * 2 * ((Cin + 31) / 32 * 32) * 4;
@@ -253,6 +253,8 @@ inline int conv_class(const ConvLayer& L, int H, int W, bool two_sources, bool t
     if (Ho % kPatchRows) return K_GENERAL;
     if (s1) return K_H2;
     if (L.ks == 7 && L.stride == 1 && L.pad == 3 && L.reflect && L.cin_pad == 8 && !transform && H >= 4 && W >= 4) return K_H2S;
+    // the pose model's stems (31 / 28 channels padded to 32): their own patch kernel since round 6 (653 + 231 us on the general kernel at configs[3])
+    if (L.ks == 7 && L.stride == 1 && L.pad == 3 && L.reflect && L.cin_pad == 32 && !transform && H >= 4 && W >= 4) return K_H2S32;
     // stride 2: the patch kernel from 128 input channels on (117 / 125 us on the 128 -> 256 / 256 -> 512 layers against 132 / 142 us for the
     // general kernel); with 64 channels the K loop is four slabs long and the general kernel's smaller per-tile prologue wins (147 vs 157 us)
     // bf16 operands: a third of the MFMA work per staged byte -- the patch tiles' five-round staging binds (459 / 378 us on 128 -> 256 /
@@ -396,6 +398,10 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
         } else if (cls == K_H2S) {
             set_tiles(128, 64);
             launch_conv_h2s(g, c.nprod, ctx.stream);
+            ++g_launch_counters[0];
+        } else if (cls == K_H2S32) {
+            set_tiles(128, 64);
+            launch_conv_h2s32(g, c.nprod, ctx.stream);
             ++g_launch_counters[0];
         } else if (cls == K_H2D) {
             // two rows x 128 columns (four waves, 44 KiB of LDS: three workgroups per CU) wherever the layer is 128 channels wide: 125 -> 99 us

@@ -25,6 +25,8 @@ void launch_conv_h2r(const ConvArgs& a, int ks, int bn, int nprod, hipStream_t s
 // conv_g64.hpp -- the same GEMM in 64-deep K steps (Cin, and the concat split, multiples of 64; Npad a multiple of 128): ks in {1, 3},
 // bm = 64 (four waves) or 128 (eight waves) rows x 128 channels; the same bits as conv_h2r
 void launch_conv_g64(const ConvArgs& a, int ks, int bm, int nprod, hipStream_t s);
+// conv_h2s32.hpp -- 7 x 7 stems at 32 raw input channels (the pose model) as a patch kernel: 4 x 32 pixels x 64 channels; the same bits as conv_h2r
+void launch_conv_h2s32(const ConvArgs& a, int nprod, hipStream_t s);
 
 // flow_persist.hpp -- flow_kernel_p: a.K, a.G (flowp_plan), a.part, a.cnt set by the caller; variant: tools build only
 void launch_flow_p(const FlowArgs& a, int variant, hipStream_t s);
