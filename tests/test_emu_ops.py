@@ -129,6 +129,8 @@ def test_instnorm_large_mean(emu_lib):
 @pytest.mark.parametrize("norm", [False, True])
 def test_upsample(emu_lib, norm):
     assert oc.upsample_case(emu_lib, "cpu", 2, 5, 7, 16, norm) < TOL
+    for (h, w) in ((1, 3), (3, 1), (1, 1), (2, 2)):          # one-row / one-column maps: every clamp of the 3 x 3 window (round 6: a thread per 2 x 2 output block)
+        assert oc.upsample_case(emu_lib, "cpu", 1, h, w, 8, norm, seed=h * 10 + w) < TOL
 
 
 @pytest.mark.parametrize("mask_mode", ["bernoulli", "ones", "zeros", "soft"])

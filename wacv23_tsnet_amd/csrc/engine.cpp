@@ -740,7 +740,7 @@ struct tsnet_engine {
     // else its bound is measured: max |first value| published by the producer + amax_add (decoder: the stream starts at a raw conv output)
     void resblock(Ctx& ctx, const ConvLayer& c1, const ConvLayer& c2, float* Xs, float stream_bound, const unsigned* stream_amax, float amax_add,
                   float* y1, float* y2, int N, int hh, int ww);
-    void set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B);
+    void set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B, hipStream_t bbox_stream = nullptr);
     void target_chain(Ctx& ctx, const float* tar_lbl, int B);
     void forward_rest(Ctx& ctx, const float* tar_bbox, float* out_rgb, float* out_flow, int B);
     void forward_target(Ctx& ctx, const float* tar_lbl, const float* tar_bbox, float* out_rgb, float* out_flow, int B) {
@@ -999,7 +999,10 @@ void tsnet_engine::encode(Ctx& ctx, std::vector<ConvLayer>& L, const float* xin,
         resblock(ctx, L[cfg.n_downsampling + 1 + 2 * i], L[cfg.n_downsampling + 2 + 2 * i], out_fea, bound, nullptr, 0.f, Y1, Y2, N, hh, ww);
 }
 
-void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B) {
+// bbox_stream: where the K bounding-box copies of the clip cache are enqueued.  Their only reader is the flow kernel; the one-shot forward
+// passes its side stream (the flow kernel's own lane: the copies are ordered ahead of it there and cost the caller's lane nothing --
+// three 4.7 us copy kernels + their boundaries sat in front of the stem until round 5); null = the caller's stream (clip mode).
+void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const float* const* src_lbl, const float* const* src_bbox, int B, hipStream_t bbox_stream) {
     cur_B = B;
     const int H = cfg.height, W = cfg.width;
     {
@@ -1013,7 +1016,8 @@ void tsnet_engine::set_sources(Ctx& ctx, const float* const* src_img, const floa
         hipLaunchKernelGGL(pack_input_kernel, dim3(pack_grid(H * W), K * B), dim3(256), 0, ctx.stream, p);
         check_launch("pack_input(img)");
         for (int s = 0; s < K; ++s)
-            HIP_TRY(hipMemcpyAsync(bbox_copy + (size_t)s * Bmax * H * W, src_bbox[s], (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, ctx.stream));
+            HIP_TRY(hipMemcpyAsync(bbox_copy + (size_t)s * Bmax * H * W, src_bbox[s], (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice,
+                                   bbox_stream ? bbox_stream : ctx.stream));
     }
     encode(ctx, img_enc, x_img, amax_src(), K * B, raw_img, X, cfg.enc_blocks);
     run_l2norm_split(ctx, X, reinterpret_cast<unsigned short*>(shat), K * B, P, C);
@@ -1311,12 +1315,15 @@ int tsnet_forward(tsnet_handle h, const float* const* src_img, const float* cons
         // from here on the side lane has work in flight: whatever happens below (an exception included), the caller's stream waits
         // for it before this call returns -- the side lane must not outlive the call
         SideJoin join{h->side_stream, main, h->ev_join};
+        if (!src_img || !src_lbl || !src_bbox) throw ArgError("null source list");
+        for (int s = 0; s < h->K; ++s)
+            if (!src_img[s] || !src_lbl[s] || !src_bbox[s]) throw ArgError("null source tensor (need n_source entries)");
         h->target_chain(cs, tar_lbl, B);
+        Ctx cm; cm.stream = main;
+        h->set_sources(cm, src_img, src_lbl, src_bbox, B, h->side_stream);      // (the bounding-box copies ride the side lane, ahead of the flow kernel)
         HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
-        const int rc = tsnet_set_sources(h, src_img, src_lbl, src_bbox, B, stream);
         HIP_TRY(hipStreamWaitEvent(main, h->ev_join, 0));
         join.done = true;
-        if (rc != TSNET_OK) return rc;
         Ctx ctx; ctx.stream = main;
         h->forward_rest(ctx, tar_bbox, out_rgb, out_flow, B);
         API_END(h)

@@ -380,30 +380,40 @@ struct PackArgs {
     unsigned* amax_out;    // null, or amax_out[image] <- max |packed value| of that image (float bits; operand scale of the fp16 x 2 stem)
 };
 
-// grid = (blocks per image, S * B images)
+// grid = (blocks per image, S * B images).  Eight channels at a time: their eight loads are issued TOGETHER -- each from a wave-uniform plane
+// pointer picked by selects, a dummy address for a padding channel -- and the /255 follows in a second pass.  (Written as one branch per
+// channel kind and element, the round-5 kernel compiled to eight dependent load -> branch -> load links per pixel: 39 us for the 12 source
+// images of the headline forward, 1 TB/s.)
 __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
     const size_t HW = (size_t)a.H * a.W;
     const int creal = a.nimg + a.L + (a.coords ? 3 : 0);
     const int n = blockIdx.y;
     const int s = n / a.B, b = n - s * a.B;
+    const float* const img_b = a.nimg ? a.img[s] + (size_t)b * a.nimg * HW : a.lbl[s];
+    const float* const lbl_b = a.lbl[s] + (size_t)b * a.L * HW;
+    const float* const dummy = a.lbl[s];                         // any readable address: the value is discarded
+    const float div = a.img_div[s];
     float vmax = 0.f;
     for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < HW; pix += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = (size_t)n * HW + pix;
-        float* o = a.out + i * a.Cp;
-        for (int c0 = 0; c0 < a.Cp; c0 += 4) {
-            float v[4];
+        float* o = a.out + ((size_t)n * HW + pix) * a.Cp;
+        for (int c0 = 0; c0 < a.Cp; c0 += 8) {
+            float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 8; ++e) {                        // every pointer / stride below is wave-uniform
                 const int c = c0 + e;
-                float t = 0.f;
-                if (c < a.nimg) t = a.img[s][((size_t)b * a.nimg + c) * HW + pix] / a.img_div[s];
-                else if (c < a.nimg + a.L) t = a.lbl[s][((size_t)b * a.L + (c - a.nimg)) * HW + pix];
-                else if (c < creal) t = a.coords[pix * 3 + (c - a.nimg - a.L)];
-                v[e] = t;
-                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(t));
+                const bool is_img = c < a.nimg, is_lbl = !is_img && c < a.nimg + a.L, is_crd = !is_img && !is_lbl && c < creal;
+                const float* p = is_img ? img_b + (size_t)c * HW : (is_lbl ? lbl_b + (size_t)(c - a.nimg) * HW : (is_crd ? a.coords + (c - a.nimg - a.L) : dummy));
+                const size_t idx = is_crd ? pix * 3 : ((is_img || is_lbl) ? pix : 0);
+                const float t = p[idx];
+                v[e] = (is_img || is_lbl || is_crd) ? t : 0.f;
             }
-            const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(o + c0) = v4;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (c0 + e < a.nimg) v[e] = v[e] / div;          // set_test_input's /255 (TSNet.py:286): IEEE division, as torch divides
+                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v[e]));
+            }
+            *reinterpret_cast<float4*>(o + c0) = make_float4(v[0], v[1], v[2], v[3]);          // Cp = 8 or a multiple of 16 (conv_cin_pad)
+            *reinterpret_cast<float4*>(o + c0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
     }
     if (a.amax_out) tsnet_publish_amax(a.amax_out + n, vmax);      // per image; block-uniform branch: every thread of the workgroup arrives
