@@ -86,6 +86,10 @@ if SEL == "w1":         # Winograd F(2,3) along x (conv_w1.hpp) against the dire
     run("dec_up1 (256->128 @128^2)", (4, 128, 128, 256, 128, 3, 1, 1, 1), [("the layer's own", code(0)), W1], norms=(0,))
     run("dec_up2 (128->64 @256^2)", (4, 256, 256, 128, 64, 3, 1, 1, 1), [("the layer's own", code(0)), W1], norms=(0,))
     sys.exit(0)
+if SEL == "w1abl":      # conv_w1 on the ResnetBlock layer (raw input), sustained loop: the product and the ablations (garbage): 1 no producer work, 2 weights once, 3 both
+    W1 = ("w1 (product)", code(w1=True))
+    run("res w1 ablations", RES, [W1] + [(f"w1 abl{m}", code(w1=True, abl=m)) for m in (1, 2, 3)], norms=(0,), iters=24)
+    sys.exit(0)
 if SEL == "w1c":        # conv_w1: tiles per workgroup (tile code 1, 2, 3; 0 = the launcher's choice), with the output statistics (norm bit 1) as in the forward
     for nm, shp in (("res (B=4: 12 images)", RES), ("res (B=8: 24 images)", (24, 32, 32, 512, 512, 3, 1, 1, 1)), ("fuse_c2 (1024->1024)", (12, 32, 32, 1024, 1024, 3, 1, 1, 1)),
                     ("fuse_c1_src (512->1024)", (12, 32, 32, 512, 1024, 3, 1, 1, 1)), ("fuse_c1_tar (4 images)", (4, 32, 32, 512, 1024, 3, 1, 1, 1)),
