@@ -89,6 +89,14 @@ template <class T> static inline T emu_buf_load16(const tsnet_rsrc_t& r, unsigne
     return v;
 }
 #define TSNET_BUF_LOAD16(rsrc, voff, soff) emu_buf_load16<F4>((rsrc), (voff), (soff))
+struct alignas(8) F2 { float v[2]; };
+static inline F2 emu_buf_load8(const tsnet_rsrc_t& r, unsigned voff, unsigned soff) {
+    F2 v;
+    const bool oob = soff > r.bytes || (unsigned long long)voff + 8 > (unsigned long long)(r.bytes - soff);
+    if (oob) memset(&v, 0, 8); else memcpy(&v, r.base + (size_t)voff + soff, 8);
+    return v;
+}
+#define TSNET_BUF_LOAD8(rsrc, voff, soff) emu_buf_load8((rsrc), (voff), (soff))
 // hook of conv_x3.hpp: v_mfma_f32_32x32x16_bf16 on raw 16-byte operands (8 bf16 per lane)
 #define TSNET_MFMA_BF16(a, b, c) emu::mfma_bf16_32x32x16(&(a), &(b), (c))
 // hook of conv_h2.hpp: v_mfma_f32_32x32x16_f16 on raw 16-byte operands (8 fp16 per lane)

@@ -30,6 +30,11 @@ __device__ __forceinline__ tsnet_brsrc_t tsnet_make_brsrc(const void* p, unsigne
 // 16-byte buffer load: lanes whose offset lies outside the descriptor read zeros (zero padding and ragged tiles cost no branch)
 #define TSNET_BUF_LOAD16(rsrc, voff, soff) __builtin_bit_cast(F4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (int)(voff), (int)(soff), 0))
 #endif
+#ifndef TSNET_BUF_LOAD8
+struct alignas(8) F2 { float v[2]; };
+// 8-byte buffer load (four bf16 of a channel quad in the bf16-storage mode), same out-of-range rule
+#define TSNET_BUF_LOAD8(rsrc, voff, soff) __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64((rsrc), (int)(voff), (int)(soff), 0))
+#endif
 #ifndef TSNET_UNIFORM
 #define TSNET_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif

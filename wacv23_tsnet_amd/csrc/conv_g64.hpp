@@ -113,16 +113,12 @@ void conv_g64_kernel(ConvArgs a) {
             if (second) {
                 const unsigned v = ok ? (unsigned)(((pix2 + iy * a.W + ix) * C2 + (cb - a.Csplit) + q8 * 4) * 4) : kOOB;
                 ar[s][0] = TSNET_BUF_LOAD16(rsx2, v, 0u); ar[s][1] = TSNET_BUF_LOAD16(rsx2, v, 128u);
-            } else if (xb16) {                                       // bf16 storage: the quad is 8 bytes; two quads of a half per 16-byte load would cross lanes -- load 8 B twice via the 16-byte path of the pair lane
+            } else if (xb16) {                                       // bf16 storage: the quad is 8 bytes, the two 32-channel halves 64 bytes apart; widened exactly
                 const unsigned v = ok ? (unsigned)(((pix0 + iy * a.W + ix) * a.Csplit + cb + q8 * 4) * 2) : kOOB;
-                // 16-byte loads only (the emulator hook): read the aligned 16 bytes that hold this quad and pick its half
-                const unsigned va = v == kOOB ? kOOB : (v & ~15u);
-                const F4 p0 = TSNET_BUF_LOAD16(rsx, va, 0u), p1 = TSNET_BUF_LOAD16(rsx, va, 64u);
-                const int hsel = (q8 & 1) * 2;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const F4& p = h ? p1 : p0;
-                    const unsigned w0 = __builtin_bit_cast(unsigned, p.v[hsel]), w1 = __builtin_bit_cast(unsigned, p.v[hsel + 1]);
+                    const F2 p = TSNET_BUF_LOAD8(rsx, v, (unsigned)(h * 64));
+                    const unsigned w0 = __builtin_bit_cast(unsigned, p.v[0]), w1 = __builtin_bit_cast(unsigned, p.v[1]);
                     ar[s][h].v[0] = __builtin_bit_cast(float, w0 << 16); ar[s][h].v[1] = __builtin_bit_cast(float, w0 & 0xFFFF0000u);
                     ar[s][h].v[2] = __builtin_bit_cast(float, w1 << 16); ar[s][h].v[3] = __builtin_bit_cast(float, w1 & 0xFFFF0000u);
                 }
