@@ -2,6 +2,7 @@
 the C ABI and compared with PyTorch CPU ops.  This checks indexing / padding / MFMA fragment layout /
 reduction logic; numerics on real hardware are the GPU tier's job."""
 import pytest
+import torch
 
 import op_cases as oc
 
@@ -113,6 +114,18 @@ def test_bf16_operand_convs(emu_lib):
     assert oc.conv_case(emu_lib, "cpu", 1, 8, 64, 16, 128, 3, 2, 1, False, norm=True, nprod=1) < 2e-2
     assert oc.conv_case(emu_lib, "cpu", 1, 4, 32, 8, 64, 7, 1, 3, True, nprod=1) < 2e-2
     assert oc.conv_case(emu_lib, "cpu", 1, 5, 7, 16, 24, 1, 1, 0, False, nprod=1) < 2e-2
+
+
+def test_bf16_wide_tile_side_by_side_waves(emu_lib):
+    """the bf16 4 x 128 patch tile with its four waves side by side (tile code 3128; the bf16 layer's own tile since round 6): the A rows
+    double-buffered by tap column, every weight fragment loaded once -- same K order and chains, so THE SAME BITS as the 2 x 2 wave grid (128)
+    and as the 64-wide tile; reflection and zero padding, one and several tiles, two slab counts, with and without the fused transform"""
+    for (N, H, W, Ci, Co, refl, norm) in ((1, 4, 32, 32, 128, True, True), (2, 8, 64, 48, 256, False, True), (1, 8, 32, 16, 128, True, False)):
+        ys = [oc.conv_h2_case(emu_lib, "cpu", N, H, W, Ci, Co, refl, norm=norm, nprod=1, tile_n=t, return_output=True) for t in (64, 128, 3128, 0)]
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2]) and torch.equal(ys[2], ys[3])
+        assert oc.conv_h2_case(emu_lib, "cpu", N, H, W, Ci, Co, refl, norm=norm, nprod=1, tile_n=3128) < 2e-2
+    with pytest.raises(AssertionError, match="bf16 4 x 128"):
+        oc.conv_h2_case(emu_lib, "cpu", 1, 4, 32, 32, 128, True, nprod=3, tile_n=3128)
 
 
 @pytest.mark.parametrize("C,H,W", [(8, 6, 5), (64, 16, 16), (24, 9, 3), (1024, 2, 2)])

@@ -201,6 +201,15 @@ def test_bf16_operand_convs(lib):
     assert oc.conv_case(lib, DEV, 2, 32, 32, 1024, 512, 1, 1, 0, False, nprod=1) < 2e-2
 
 
+def test_bf16_wide_tile_side_by_side_waves(lib):
+    """bf16 4 x 128 patch tile, four waves side by side (3128: the bf16 layers' own tile) against the 2 x 2 wave grid (128) and the 64-wide
+    tile: the same bits, at the ResnetBlock and first up-convolution shapes"""
+    for (N, H, W, Ci, Co, refl) in ((4, 32, 32, 512, 512, True), (2, 128, 128, 256, 128, True), (3, 32, 32, 1024, 1024, False)):
+        ys = [oc.conv_h2_case(lib, DEV, N, H, W, Ci, Co, refl, norm=True, nprod=1, tile_n=t, return_output=True) for t in (64, 128, 3128, 0)]
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2]) and torch.equal(ys[2], ys[3])
+        assert oc.conv_h2_case(lib, DEV, N, H, W, Ci, Co, refl, norm=True, nprod=1, tile_n=3128) < 2e-2
+
+
 def test_conv_split_worst_case_dynamic_range(lib):
     """The fp16 x 2 split under an adversarial dynamic range inside ONE image at the ResnetBlock shape (512 -> 512, 32 x 32): 1 % of the
     activations at amax, the bulk at amax * 2^-12 / 2^-18 / 2^-24, weights likewise.  Absolute error within 3 x the exact-fp32 chain's

@@ -32,7 +32,7 @@ def test_hot_kernels_do_not_spill_in_their_loops():
         assert hit, f"{name} is not in the product library"
         r = hit[0]
         assert r["scratch"] <= limit, f"{name}: {r['scratch']} scratch operations in the main loop (limit {limit}), {r['vgpr']} VGPRs"
-        assert r["vgpr"] <= (256 if ("4, 128" in name or ", 24>" in name) else 168), (name, r["vgpr"])
+        assert r["vgpr"] <= (256 if ("4, 128, 2, 2" in name or ", 24>" in name) else 168), (name, r["vgpr"])
     # the encoder front end and the general kernel's layers of the headline forward (DESIGN.md section 1's "no spill in a hot loop" now
     # covers them; the one tolerated case is written down in tools/isa_check.py)
     for unit, pat, hot in (("conv_h2_launch.cpp", "conv_h2d_kernel", ic.HOT_FRONT[:2]), ("conv_h2_launch.cpp", "conv_h2s_kernel", ic.HOT_FRONT[2:]),

@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOT = [("conv_h2_kernel<4, 64, 2, 2, 3, true, 0, 0>", 0), ("conv_h2_kernel<4, 64, 2, 2, 3, false, 0, 0>", 0),
        ("conv_h2_kernel<4, 128, 2, 2, 3, false, 0, 0>", 0), ("conv_h2_kernel<4, 128, 2, 2, 3, true, 0, 0>", 4),
        ("conv_h2_kernel<4, 64, 2, 2, 1, true, 0, 0>", 0), ("conv_h2_kernel<4, 64, 2, 2, 1, false, 0, 0>", 0),
-       ("conv_h2_kernel<4, 64, 2, 2, 3, true, 0, 24>", 0), ("conv_h2_kernel<4, 32, 4, 1, 3, true, 0, 24>", 0)]
+       ("conv_h2_kernel<4, 64, 2, 2, 3, true, 0, 24>", 0), ("conv_h2_kernel<4, 32, 4, 1, 3, true, 0, 24>", 0),
+       # the bf16 modes' 4 x 128 tile, four waves side by side (round 6): 168 VGPRs = the three workgroups per CU it is scheduled for
+       ("conv_h2_kernel<4, 128, 1, 4, 1, true, 0, 0>", 0), ("conv_h2_kernel<4, 128, 1, 4, 1, false, 0, 0>", 0)]
 # the encoder front end of the headline forward: the stride-2 patch kernel from 128 channels on, the 7 x 7 stem.  The IN + ReLU form of the
 # stride-2 tile holds 2 spill operations per slab pair at its 168 VGPRs (three workgroups per CU): measured, tolerated, pinned so that it cannot grow unseen.
 HOT_FRONT = [("conv_h2d_kernel<128, 4, 3, true, 2>", 2), ("conv_h2d_kernel<128, 4, 3, false, 2>", 0), ("conv_h2s_kernel<3>", 0)]

@@ -155,7 +155,12 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     // the MT + 2 patch rows ar[0 .. MT+1], row i + ky for output row i -- every row fragment is read ONCE per tap column and serves up to
     // three taps (12 instead of 18 LDS reads per plane and slab on a two-row wave tile, in the registers of the two alternating sets it replaces).
     const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
-    F4 ar[NRW][NPL], bf[BD][NPL][NTL];                               // [patch row][plane], [register set][plane][tile]
+    // A wave tile of more than two rows (MT = 4: the four waves side by side over the channels, every weight fragment loaded once per workgroup)
+    // cannot roll its rows through one ring -- rows 2 .. MT-1 of a column are still read at its last tap row -- so the row fragments are
+    // double-buffered by tap column instead: the whole next column is fetched, two rows per step, while the current one is used.
+    constexpr bool DB = MT > 2;
+    static_assert(!DB || NRW == 6, "the double-buffered form fetches two rows of the next tap column per step");
+    F4 ar[DB ? 2 : 1][NRW][NPL], bf[BD][NPL][NTL];                   // [tap-column parity][patch row][plane], [register set][plane][tile]
     auto tap_of = [](int s) __attribute__((always_inline)) { return (s % 3) * 3 + s / 3; };
     // Weight fragment of (tap, slab): byte offset ((tap * ncc + slab) * Npad + n0 + 32 j) * 32 = tap * wT + slab * wB + n0 * 32 + 1024 j.  The K
     // loop keeps the running offset of its current slab (`wsl`, + KG slabs per iteration) and adds compile-time multiples of wT / wB per
@@ -174,7 +179,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     auto load_row = [&](int r, int par, int kx) __attribute__((always_inline)) {
         const unsigned char* pbase = abase + par * PATCH_BYTES;
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) ar[r][p] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + (r * PC + kx) * 16);
+        for (int p = 0; p < NPL; ++p) ar[DB ? (kx & 1) : 0][r][p] = *reinterpret_cast<const F4*>(pbase + p * PLANE_P + (r * PC + kx) * 16);
     };
 
     f32x16 acc[MT][NTL], tot[MT][NTL];
@@ -185,7 +190,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
-    auto product = [&](int ky, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
+    auto product = [&](int kx, int ky, int sb, int pa, int pb, bool fresh) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -195,8 +200,8 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c[r] = 0.f;
                 }
-                if (NPROD == 1) acc[i][j] = TSNET_MFMA_BF16(ar[i + ky][pa], bf[sb][pb][j], c);
-                else acc[i][j] = TSNET_MFMA_F16(ar[i + ky][pa], bf[sb][pb][j], c);
+                if (NPROD == 1) acc[i][j] = TSNET_MFMA_BF16(ar[DB ? (kx & 1) : 0][i + ky][pa], bf[sb][pb][j], c);
+                else acc[i][j] = TSNET_MFMA_F16(ar[DB ? (kx & 1) : 0][i + ky][pa], bf[sb][pb][j], c);
             }
     };
     // step s of local slab cc (stage par): B(cc, s) sits in set s % BD, the rows of its tap column in ar; issues first B of BD - 1 steps ahead
@@ -208,12 +213,16 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
         const int s2 = (s + BD - 1) % 9;
         if (!(HABL & 2)) load_b((par * 9 + s + BD - 1) % BD, s + BD - 1 >= 9 ? 1 : 0, s2);
         if (!(HABL & 4)) {
-            if (ky < 2) load_row(ky + MT, par, kx);
-            if (kx < 2 && ky == 1) {
+            if (DB) {
+                if (kx < 2) { load_row(2 * ky, par, kx + 1); load_row(2 * ky + 1, par, kx + 1); }     // the next tap column, into the other buffer
+            } else {
+                if (ky < 2) load_row(ky + MT, par, kx);
+                if (kx < 2 && ky == 1) {
 #pragma unroll
-                for (int r = 0; r + 1 < MT; ++r) load_row(r, par, kx + 1);
+                    for (int r = 0; r + 1 < MT; ++r) load_row(r, par, kx + 1);
+                }
+                if (kx < 2 && ky == 2) load_row(MT - 1, par, kx + 1);
             }
-            if (kx < 2 && ky == 2) load_row(MT - 1, par, kx + 1);
         }
         // staging of slab cc+1: round 0 fetched at step 0 and written at step 2, round 1 fetched at step 3 and written at step 5 (DEEP: fetched
         // at steps 0 and 1, written at steps 5 and 7).  Past the last slab the loads run into the next pixel's channels or return zeros:
@@ -222,12 +231,12 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
         if (s == (DEEP ? 1 : 3) && !(HABL & 1)) stage_load_x(cc + 1, 1);
         const int SB = (par * 9 + s) % BD;
         if (NPROD == 1) {
-            product(ky, SB, 0, 0, fresh);                            // bf16 * bf16
+            product(kx, ky, SB, 0, 0, fresh);                        // bf16 * bf16
         } else {
-            if (NPROD == 4) product(ky, SB, NPL - 1, NPL - 1, fresh);        // lo * lo
-            product(ky, SB, NPL - 1, 0, fresh && NPROD == 3);        // lo * hi
-            product(ky, SB, 0, NPL - 1, false);                      // hi * lo
-            product(ky, SB, 0, 0, false);                            // hi * hi
+            if (NPROD == 4) product(kx, ky, SB, NPL - 1, NPL - 1, fresh);    // lo * lo
+            product(kx, ky, SB, NPL - 1, 0, fresh && NPROD == 3);    // lo * hi
+            product(kx, ky, SB, 0, NPL - 1, false);                  // hi * lo
+            product(kx, ky, SB, 0, 0, false);                        // hi * hi
         }
         if (s == (DEEP ? 5 : 2) && !(HABL & 1)) stage_store(cc + 1, par ^ 1, 0);
         if (s == (DEEP ? 7 : 5) && !(HABL & 1)) stage_store(cc + 1, par ^ 1, 1);
@@ -249,7 +258,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
         if (!(HABL & 16)) __syncthreads();                           // patch(cc) complete and visible; slab cc-1 fully read
         if (!(HABL & 4) || cc == 0) {
 #pragma unroll
-            for (int r = 0; r < MT; ++r) load_row(r, par, 0);
+            for (int r = 0; r < (DB ? NRW : MT); ++r) load_row(r, par, 0);
         }
 #pragma unroll
         for (int s = 0; s < 9; ++s) step(cc, par, s, open && s == 0, close && s == 8);

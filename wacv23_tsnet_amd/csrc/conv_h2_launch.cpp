@@ -50,6 +50,10 @@ void go_h2_shape(const ConvArgs& a, int pr, int bn, hipStream_t s) {
     else if (pr == 4 && bn == 64) go_h2<4, 64, 2, 2, NPROD>(a, s);
     else if (pr == 4 && bn == 128) go_h2<4, 128, 2, 2, NPROD>(a, s);
     else if (pr == 2 && bn == 128) go_h2<2, 128, 1, 4, NPROD>(a, s);
+    else if (pr == 5 && bn == 128) {                 // 4 rows x 128 channels with the four waves side by side (1 x 4, wave tile 128 x 32): every weight fragment is loaded once per workgroup
+        if constexpr (NPROD == 1) go_h2<4, 128, 1, 4, 1>(a, s);
+        else throw std::invalid_argument("conv(h2): the 1 x 4 wave grid of the 4 x 128 tile is built for bf16 operands");
+    }
     else throw std::invalid_argument("conv(h2): tile must be 4x32, 4x64, 4x128 or 2x128");
 }
 

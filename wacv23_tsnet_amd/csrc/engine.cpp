@@ -379,6 +379,14 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
                 // at B = 4), and the forward no longer takes it: a frame's bits do not depend on its batch, B = 1 included.  The tile codes
                 // 20032 / 20064 stay available to tsnet_op_conv2d.)
             }
+            // bf16 operands, the 4 x 128 tile: the four waves SIDE BY SIDE (1 x 4, wave tile 128 x 32) instead of 2 x 2 (64 x 64) -- every weight
+            // fragment is loaded once per workgroup instead of twice (the tile was bound by its weight loads: 72 of 80 vector loads per slab),
+            // the A rows double-buffered by tap column: 120.5 -> 107.0 us on the 512 -> 512 layer, 96.1 -> 86.3 us on the decoder's first
+            // up-convolution (profiles/round6_h2_1x4.txt).  Same K order and chains: the same bits as the 2 x 2 form (tests).  Tile code 3128
+            // forces it, 128 (or 4128) the 2 x 2 form.
+            const bool side_by_side = pr == 3 || (!c.tile && bf16 && pr == 4 && bn == 128);
+            if (pr == 3) pr = 4;
+            if (side_by_side && (!bf16 || bn != 128)) throw ArgError("conv(h2): the 1 x 4 wave grid is the bf16 4 x 128 tile's");
             if ((pr != 2 && pr != 4) || g.Ho % pr) throw ArgError("conv(h2): the output height must be a multiple of the tile's rows (2 or 4)");
             if (g.Npad % bn) throw ArgError("conv(h2): the tile width must divide the padded output width");
             set_tiles(pr * kPatchCols, bn);
@@ -392,9 +400,9 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
                 }
                 g.xcd_gn = gn;
             }
-            launch_conv_h2(g, pr, bn, c.nprod, c.abl, opt, ctx.stream);
+            launch_conv_h2(g, side_by_side ? 5 : pr, bn, c.nprod, c.abl, opt, ctx.stream);
             ++g_launch_counters[0];
-            if (c.tclass == TSNET_T_CONV_RES) g_launch_counters[3] = pr * 1000 + bn + ((opt & 16) ? 20000 : 0);
+            if (c.tclass == TSNET_T_CONV_RES) g_launch_counters[3] = (side_by_side ? 3 : pr) * 1000 + bn + ((opt & 16) ? 20000 : 0);
         } else if (cls == K_H2S) {
             set_tiles(128, 64);
             launch_conv_h2s(g, c.nprod, ctx.stream);
