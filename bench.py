@@ -243,6 +243,8 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
             code = int(cnt[3]) % 10000               # + 20000: the two-K-group tiles of single-frame forwards
             wino = int(cnt[3]) // 10000 == 3         # + 30000: the Winograd-along-x form (conv_w1.hpp)
             pr, bn = code // 1000, code % 1000
+            side = pr == 3                           # 3128: the bf16 modes' 4 x 128 tile with its four waves side by side (conv_h2<4,128,1,4,...>)
+            pr = 4 if side else pr
             n_enc, n_dec = 2 * int(kw.get("enc_blocks", 9)), 2 * int(kw["n_blocks"])
             flop_class = 2.0 * P * C * (9 * C) * (n_enc * K * batch + n_dec * batch)       # per forward
             flop_per_launch = flop_class / (n_enc + n_dec)
@@ -259,7 +261,7 @@ def run_rank(*, rank: int, world: int, device, steps: int, warmup: int, lib=None
             roofline = {"bound": "mfma",
                         "kernel": "%s<%d rows, %d channels, ...> (3x3 ResnetBlock convolution%s%s, %d launches per forward = %.0f %% of the forward)"
                                   % (kname, pr, bn, ", Winograd F(2,3) along x: 2/3 of the direct form's MFMA products" if wino else "",
-                                     ", bf16 operands: one MFMA product" if bf16 else "",
+                                     (", bf16 operands: one MFMA product" + (", four waves side by side" if side else "")) if bf16 else "",
                                      res_launches // nprobe, 100.0 * res_ms / nprobe / (dt * 1e3 / steps)),
                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         "traffic": traffic, "traffic_source": traffic_src,
