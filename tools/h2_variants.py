@@ -61,7 +61,7 @@ if SEL == "bf16":       # the bf16-operand kernels against the fp16 x 2 ones, la
             vs += [("bf16 w1 (winograd-x)", code(w1=True, bf16=True)), ("bf16 4x64", code(64, bf16=True)), ("bf16 2x128", code(2128, bf16=True))]
             if shp[4] % 128 == 0:
                 vs += [("bf16 4x128 (2x2 waves)", code(128, bf16=True)), ("bf16 4x128 (1x4 waves)", code(3128, bf16=True))]
-                vs += [(f"bf16 4x128 1x4 abl{m}", code(3128, bf16=True, abl=m)) for m in (1, 2, 4, 3, 7, 8, 16)]
+                vs += [(f"bf16 4x128 1x4 abl{m}", code(3128, bf16=True, abl=m)) for m in (1, 2, 4, 8, 3, 7, 16)]
                 vs += [(f"bf16 4x128 abl{m}", code(128, bf16=True, abl=m)) for m in (1, 2, 4, 3, 7, 16)]
         if shp[6] == 2 and shp[3] >= 128:
             vs += [("bf16 h2d 4 waves x 64", code(64, patch=True, bf16=True)), ("bf16 h2d 8 waves x 128", code(128, patch=True, bf16=True)), ("bf16 general 128", code(128, general=True, bf16=True))]

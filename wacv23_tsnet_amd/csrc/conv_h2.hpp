@@ -256,7 +256,7 @@ __device__ __forceinline__ void h2_tile(const ConvArgs& a, unsigned char* smem_r
     // a slab: nine steps between two barriers; open / close: the slab is the first / last of its accumulation chain
     auto slab = [&](int cc, int par, bool open, bool close) __attribute__((always_inline)) {
         if (!(HABL & 16)) __syncthreads();                           // patch(cc) complete and visible; slab cc-1 fully read
-        if (!(HABL & 4) || cc == 0) {
+        if ((!(HABL & 4) || cc == 0) && !(DB && (HABL & 8) && cc > 0)) {        // (HABL 8 on the double-buffered form: without the exposed fetch of a slab's first tap column)
 #pragma unroll
             for (int r = 0; r < (DB ? NRW : MT); ++r) load_row(r, par, 0);
         }

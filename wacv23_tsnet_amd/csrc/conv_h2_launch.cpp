@@ -86,6 +86,9 @@ void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int o
 #define TSNET_H2_VAR1(A_) if (pr == 4 && bn == 128 && abl == A_ && opt == 0) { go_h2<4, 128, 2, 2, 1, A_, 0>(a, s); return; }
             TSNET_H2_VAR1(1) TSNET_H2_VAR1(2) TSNET_H2_VAR1(4) TSNET_H2_VAR1(3) TSNET_H2_VAR1(7) TSNET_H2_VAR1(16)
 #undef TSNET_H2_VAR1
+#define TSNET_H2_VAR1S(A_) if (pr == 5 && bn == 128 && abl == A_ && opt == 0) { go_h2<4, 128, 1, 4, 1, A_, 0>(a, s); return; }       // ... and of its side-by-side form
+            TSNET_H2_VAR1S(1) TSNET_H2_VAR1S(2) TSNET_H2_VAR1S(4) TSNET_H2_VAR1S(3) TSNET_H2_VAR1S(7) TSNET_H2_VAR1S(16) TSNET_H2_VAR1S(8)
+#undef TSNET_H2_VAR1S
             throw std::invalid_argument("conv(h2): this bf16 experiment variant is not instantiated");
         }
         if (nprod != 3) throw std::invalid_argument("conv(h2): experiment variants are built for one or three products");
