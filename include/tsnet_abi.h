@@ -155,9 +155,11 @@ int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64
  *   4 x 32 rectangles: 3x3 / stride 1, 3x3 / stride 2 / zero pad, 7x7 stem with 8 input channels; the general implicit GEMM of conv_h2r.hpp
  *   elsewhere), 1 = the general kernel, 2 = the patch kernel (error if the layer has none), 3 = the Winograd F(2,3)-along-x form of a
  *   3x3 / stride-1 / pad-1 layer on frames of whole 4 x 32 tiles (conv_w1.hpp: the kernel the forward runs its ResnetBlock / FuseNet / first
- *   up-convolution layers on; the op packs the transformed filters itself; `tile` is ignored).
- *   tile: 0 = the launcher's choice; patch 3x3 / stride 1: 32, 64, 128 (4-row tiles), 2128 (2 rows x 128), 20032 / 20064 (the two-K-group
- *   tiles a single-frame forward runs); patch 3x3 / stride 2: 64, 128 (4 rows) or 2128 (2 rows x 128: the forward's shape); others: 64 or 128.
+ *   up-convolution layers on; the op packs the transformed filters itself; `tile` = tiles per workgroup, 1, 2 or 3, 0 = the launcher's choice).
+ *   tile: 0 = the launcher's choice; patch 3x3 / stride 1: 32, 64, 128 (4-row tiles), 2128 (2 rows x 128), 3128 (nprod = 1 only: 4 rows x 128
+ *   with the four waves side by side, the bf16 modes' own tile), 20032 / 20064 (two-K-group tiles); patch 3x3 / stride 2: 64, 128 (4 rows)
+ *   or 2128 (2 rows x 128: the forward's shape); general kernel: 64 or 128 (16-deep steps, conv_h2r.hpp), 3064 / 3128 (64-deep steps,
+ *   conv_g64.hpp, 64 / 128 rows: where the layer allows, the forward's choice).
  *   All one-group tiles of one kernel produce identical bits, and so do the two two-group tiles among themselves (tested); the two-group
  *   tiles, and patch vs general kernels, sum K in another association / order: agreement to fp32 rounding.
  * tsnet_op_conv2d_cat <- the same on torch.cat((x, x2), channel axis) formed on load (dec.map_conv on cat(pg, sg), TSNet.py:163):

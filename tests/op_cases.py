@@ -68,7 +68,7 @@ def conv_case(lib, dev, N, H, W, Cin, Cout, k, stride, pad, reflect, norm=False,
 
 
 def conv_h2_case(lib, dev, N, H, W, Cin, Cout, reflect, norm=False, bias=True, nprod=3, tile_n=0, seed=0, scale=1.0, return_output=False):
-    """3x3 / stride 1 / pad 1 on the PATCH kernel (conv_h2.hpp h2_tile); tile_n: 0, 32, 64, 128 (4-row tiles), 2128 (2 rows x 128), 20032 / 20064 (two K groups, 4 x 32 / 4 x 64)."""
+    """3x3 / stride 1 / pad 1 on the PATCH kernel (conv_h2.hpp h2_tile); tile_n: 0, 32, 64, 128 (4-row tiles), 2128 (2 rows x 128), 3128 (bf16 operands: 4 x 128, four waves side by side), 20032 / 20064 (two K groups, 4 x 32 / 4 x 64)."""
     return conv_case(lib, dev, N, H, W, Cin, Cout, 3, 1, 1, reflect, norm=norm, bias=bias, seed=seed, nprod=nprod, kernel=2, tile=tile_n,
                      scale=scale, return_output=return_output)
 
