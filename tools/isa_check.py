@@ -20,8 +20,9 @@ HOT_FRONT = [("conv_h2d_kernel<128, 4, 3, true, 2>", 2), ("conv_h2d_kernel<128, 
 # ... and of the general kernel's unit (conv_h2r_launch.cpp): the 64 -> 128 stride-2 layer and the two 1 x 1 convolutions
 HOT_GENERAL = [("conv_h2r_kernel<3, 128, 2, 2, 3, true, false>", 0), ("conv_h2r_kernel<1, 64, 2, 2, 3, false, false>", 0)]
 # ... and of its 64-deep-step form (conv_g64_launch.cpp, round 6), which now carries those layers in the forward: the 64-row tile, 1 x 1 on a raw input,
-# 3 x 3 stride 2 under a fused InstanceNorm + ReLU (fp16 x 2 operands: no spill; bf16 operands hold 4 spill operations per step at 119 - 123 VGPRs)
-HOT_G64 = [("conv_g64_kernel<1, 64, 3, false>", 0), ("conv_g64_kernel<3, 64, 3, true>", 0), ("conv_g64_kernel<3, 64, 1, true>", 4)]
+# 3 x 3 stride 2 under a fused InstanceNorm + ReLU (no spill with either operand form: the bf16 loop held 4 spill operations per step until its
+# bf16-storage input path was rewritten to read 8-byte quads)
+HOT_G64 = [("conv_g64_kernel<1, 64, 3, false>", 0), ("conv_g64_kernel<3, 64, 3, true>", 0), ("conv_g64_kernel<3, 64, 1, true>", 0), ("conv_g64_kernel<1, 64, 1, false>", 0)]
 HOT_S32 = [("conv_h2s32_kernel<3>", 0), ("conv_h2s32_kernel<1>", 0)]      # the pose model's stems (same unit)
 
 
