@@ -166,7 +166,8 @@ int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64
  *   x (N,H,W,C1), x2 (x2_nmod,H,W,C2) read at image n % x2_nmod; C1 a multiple of 16.  No input transform.
  * tsnet_op_head <- the decoder's RGB head: ReflectionPad2d(3) + Conv2d(C -> 3, 7x7) + bias + Tanh (TSNet.py:151-152) on relu(alpha*x+beta),
  *   with the pose model's fixed-background composite (TSNet_pose.py:416-417: columns outside [64,192) <- bg) when composite != 0.
- *   x (N,H,W,C) NHWC, w (3,C,7,7), bias (3), bg 3 host floats or NULL; y (N,3,H,W) NCHW.
+ *   x (N,H,W,C) NHWC, w (3,C,7,7), bias (3), bg 3 host floats or NULL; y (N,3,H,W) NCHW.  composite: bit 0 = the composite; bits 8.. = tile
+ *   rows of the kernel to force (8, 16, 32; 0 = the launcher's choice by the number of workgroups: every choice gives the same bits).
  * tsnet_op_instnorm_stats <- nn.InstanceNorm2d statistics (TSNet.py:53; eps 1e-5, biased variance):
  *   alpha = 1/sqrt(var+eps), beta = -mean*alpha, each (N*C).
  * tsnet_op_norm_act   : y = alpha*x+beta (relu optional) ; if resid != NULL y += resid  (ResnetBlock tail, TSNet.py:48)

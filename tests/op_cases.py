@@ -105,9 +105,10 @@ def conv_cat_case(lib, dev, N, H, W, C1, C2, Cout, k=1, seed=0, shared=False):
     return ((nchw(y.cpu()).double() - ref).abs().max() / ref.abs().max()).item()
 
 
-def head_case(lib, dev, N, H, W, C, norm=True, composite=False, seed=0):
+def head_case(lib, dev, N, H, W, C, norm=True, composite=False, seed=0, rows=0, return_output=False):
     """the decoder's RGB head: ReflectionPad2d(3) + Conv2d(C -> 3, 7x7) + bias + Tanh on relu(IN(x)) (TSNet.py:151-152), optional pose
-    composite (TSNet_pose.py:416-417) vs tsnet_op_head.  Returns max|d|."""
+    composite (TSNet_pose.py:416-417) vs tsnet_op_head.  rows: tile rows of head_conv3 to force (8, 16, 32; 0 = the launcher's choice).
+    Returns max|d| (or the output)."""
     x = _rand(seed, "x", (N, C, H, W))
     w = _rand(seed, "w", (3, C, 7, 7)) * (2.0 / (C * 49) ** 0.5)
     b = _rand(seed, "b", (3,))
@@ -127,10 +128,12 @@ def head_case(lib, dev, N, H, W, C, norm=True, composite=False, seed=0):
     xd, wd, bd = nhwc(x).to(dev), w.to(dev), b.to(dev)
     ald = al.contiguous().to(dev) if norm else None
     bed = be.contiguous().to(dev) if norm else None
-    rc = lib.tsnet_op_head(xd.data_ptr(), N, H, W, C, _p(ald), _p(bed), wd.data_ptr(), bd.data_ptr(), int(composite), (ctypes.c_float * 3)(*bg),
+    rc = lib.tsnet_op_head(xd.data_ptr(), N, H, W, C, _p(ald), _p(bed), wd.data_ptr(), bd.data_ptr(), int(composite) | (rows << 8), (ctypes.c_float * 3)(*bg),
                            y.data_ptr(), None)
     assert rc == 0, lib.tsnet_op_last_error().decode()
     _sync(dev)
+    if return_output:
+        return y.cpu()
     return (y.cpu() - ref).abs().max().item()
 
 

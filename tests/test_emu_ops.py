@@ -54,6 +54,16 @@ def test_head(emu_lib, C):
         assert oc.head_case(emu_lib, "cpu", 1, 8, 256, C, norm=False, composite=True) < TOL
 
 
+def test_head_tile_rows_give_the_same_bits(emu_lib):
+    """head_conv3 with 8-, 16- and 32-row tiles (the launcher picks by the number of workgroups: 8 rows for one frame, 32 from B = 4 on):
+    a pixel's sums do not depend on its tile -- torch.equal; a ragged frame (40 rows: tiles hanging over the edge in every form), the
+    fused InstanceNorm + ReLU, the composite"""
+    for (N, H, W, C, norm, comp) in ((1, 40, 36, 16, True, False), (2, 32, 256, 16, False, True)):
+        ys = [oc.head_case(emu_lib, "cpu", N, H, W, C, norm=norm, composite=comp, rows=r, return_output=True) for r in (8, 16, 32, 0)]
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2]) and torch.equal(ys[2], ys[3])
+        assert oc.head_case(emu_lib, "cpu", N, H, W, C, norm=norm, composite=comp, rows=32) < TOL
+
+
 @pytest.mark.parametrize("norm", [False, True])
 @pytest.mark.parametrize("reflect", [True, False])
 def test_conv_h2(emu_lib, norm, reflect):
@@ -97,6 +107,14 @@ def test_conv_h2d_stride2_patch_kernel(emu_lib):
     c = oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, 32, 256, 3, norm=True, kernel=2, tile=2128, return_output=True)       # two rows x 128, four waves
     assert torch.equal(a, b) and torch.equal(a, c)
     assert oc.conv_h2r_case(emu_lib, "cpu", 2, 12, 64, 48, 128, 3, norm=True, kernel=2, tile=2128) < REL     # six output rows: three 2-row tiles per image
+    # the deep schedule of the 2 x 128 tile (12128: weights eight steps ahead, the three staging rounds in flight together -- what a launch of
+    # at most two workgroups per CU runs, so every emulator-sized launch when the choice is the launcher's): the same bits, odd and even slab
+    # counts, with and without the fused transform
+    d = oc.conv_h2r_case(emu_lib, "cpu", 1, 8, 64, 32, 256, 3, norm=True, kernel=2, tile=12128, return_output=True)
+    assert torch.equal(a, d)
+    for (cin, norm) in ((16, True), (48, False), (64, True)):
+        ys = [oc.conv_h2r_case(emu_lib, "cpu", 2, 16, 64, cin, 128, 3, norm=norm, kernel=2, tile=t, seed=cin, return_output=True) for t in (2128, 12128, 0)]
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2])
 
 
 def test_conv_h2s_stem_patch_kernel(emu_lib):

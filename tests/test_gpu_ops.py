@@ -62,6 +62,15 @@ def test_head(lib, C, H, W, composite):
     assert oc.head_case(lib, DEV, 2, H, W, C, composite=composite) < TOL
 
 
+def test_head_tile_rows_give_the_same_bits(lib):
+    """head_conv3 with 8-, 16- and 32-row tiles at the forward's shape (one frame runs 8 rows, two 16, four and more 32) and on a ragged
+    frame: torch.equal"""
+    for (N, H, W, C, comp) in ((1, 256, 256, 64, True), (2, 40, 72, 64, False), (4, 256, 256, 64, False)):
+        ys = [oc.head_case(lib, DEV, N, H, W, C, composite=comp, rows=r, return_output=True) for r in (8, 16, 32, 0)]
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2]) and torch.equal(ys[2], ys[3])
+        assert oc.head_case(lib, DEV, N, H, W, C, composite=comp, rows=8) < TOL
+
+
 @pytest.mark.parametrize("C,H,W", [(8, 6, 5), (64, 64, 64), (24, 9, 3), (512, 32, 32), (1024, 8, 8)])
 @pytest.mark.parametrize("relu,resid", [(True, False), (False, True)])
 def test_instnorm(lib, C, H, W, relu, resid):
@@ -180,6 +189,10 @@ def test_conv_h2d_downsampling_layers(lib):
     c = oc.conv_h2r_case(lib, DEV, 2, 64, 64, 256, 512, 3, norm=True, kernel=2, tile=2128, return_output=True)      # two rows x 128: the forward's shape
     d = oc.conv_h2r_case(lib, DEV, 2, 64, 64, 256, 512, 3, norm=True, kernel=2, return_output=True)                 # the launcher's own choice
     assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    # the deep schedule (12128: a single frame's launches) against the plain one, at the one-frame and the batch shapes of both layers
+    for (n, hw_, ci, co) in ((1, 64, 256, 512), (3, 128, 128, 256), (4, 64, 256, 512)):
+        ys = [oc.conv_h2r_case(lib, DEV, n, hw_, hw_, ci, co, 3, norm=True, kernel=2, tile=t, return_output=True) for t in (2128, 12128, 0)]
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2])
     assert oc.conv_h2r_case(lib, DEV, 4, 128, 128, 128, 256, 3, norm=True, kernel=2, tile=2128) < REL
     g = oc.conv_h2r_case(lib, DEV, 2, 64, 64, 256, 512, 3, norm=True, kernel=1, return_output=True)
     assert not torch.equal(a, g) and (a - g).abs().max().item() < 1e-4 * a.abs().max().item()

@@ -529,7 +529,13 @@ void conv_h2s_kernel(ConvArgs a) {
 // SIMD -- their MFMA pipe is 0.20 busy.  PR = 2 (NW = 4, BN = 128): a 2 x 32 output rectangle, waves 1 (M) x 4 (N), patch 5 x 65: 44 KiB and
 // 168 VGPRs -> THREE workgroups per CU (twelve waves), three staging rounds; 11 % more patch pixels per output than the 4-row tile.
 // K order, chains and fold points are h2_tile's in every shape: bit-identical results.
-template <int BN, int NWV, int NPROD, bool AFFINE, int PR = kPatchRows>
+// DEEP (two-row tile only; round 6): the schedule of a launch that cannot fill the chip -- a single frame's 64 .. 384 workgroups, one or two per
+// CU.  With weight fragments two steps ahead and each staging round fetched two steps before it is written, a lone workgroup pays one memory round
+// trip per STEP (72 us for 16 slabs on 64 CUs: ~1000 cycles per step of 6 MFMAs); three co-resident workgroups hide that for each other, one does
+// not.  DEEP keeps the weight fragments of eight steps in flight (nine register sets: the tap index is the set index) and fetches all three
+// staging rounds of the next slab in its first three steps, writing them in its last three: ~230 VGPRs, two workgroups per CU.  Same
+// arithmetic, same bits.
+template <int BN, int NWV, int NPROD, bool AFFINE, int PR = kPatchRows, bool DEEP = false>
 __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_raw, const int tile_m, const int n0) {
     constexpr int BM = PR * kPatchCols;
     constexpr int WARPS_M = PR / 2, WARPS_N = NWV / WARPS_M;
@@ -549,6 +555,8 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     constexpr int NBLK = (PP + 31) / 32;                             // 19 (11) blocks of 32 pixels
     constexpr int NR = (NBLK + NWV - 1) / NWV;                       // staging rounds: 5 (four waves, four rows) or 3 (eight waves; two rows)
     static_assert(NR == 5 || NR == 3, "staging schedules exist for five and three rounds");
+    static_assert(!DEEP || NR == 3, "the deep schedule is the two-row tile's");
+    constexpr int BD = DEEP ? 9 : 3;                                 // weight register sets: fragments are fetched BD - 1 steps ahead
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -599,18 +607,19 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
         __syncthreads();
     }
     const float relu_floor = a.in_relu ? 0.f : -__builtin_inff();
-    F4 sx[2];                                                        // staging registers: one round of x in flight
+    F4 sx[DEEP ? NR : 1][2];                                         // staging registers: one round of x in flight (DEEP: all three)
     auto stage_load_x = [&](int cn, int r) __attribute__((always_inline)) {
-        if (NPROD == 1) load_x_octet(rsx, xb16, vP[r], (unsigned)(cn * 64), sx);
+        F4 (&sxr)[2] = sx[DEEP ? r : 0];
+        if (NPROD == 1) load_x_octet(rsx, xb16, vP[r], (unsigned)(cn * 64), sxr);
         else {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) sx[q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(cn * 64 + q * 16));
+            for (int q = 0; q < 2; ++q) sxr[q] = TSNET_BUF_LOAD16(rsx, vP[r], (unsigned)(cn * 64 + q * 16));
         }
     };
     auto stage_store = [&](int cn, int r) __attribute__((always_inline)) {
         F4 t[2];
         const float* ta = tab + (cn < ncc ? cn * 16 : 0) + oct * 8;
-        transform_octet<AFFINE>(sx, ta, a.Cin, in_scale, relu_floor, vM[r], t);
+        transform_octet<AFFINE>(sx[DEEP ? r : 0], ta, a.Cin, in_scale, relu_floor, vM[r], t);
         const int so = slot_of(r);
         const bool real = so >= 0;
         unsigned char* dst = smem_raw + (real ? (cn & 1) * PATCH_BYTES + oct * REGION + so : OFF_SINK + (lane & 63) * 16);
@@ -627,7 +636,7 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
 
     // ---- fragments
     const unsigned vB = (unsigned)((wn0 + li) * 32 + (lh ^ ((li >> 3) & 1)) * 16);
-    F4 af[2][NPL][MT], bf[3][NPL][NTL];
+    F4 af[2][NPL][MT], bf[BD][NPL][NTL];
     const int wB = a.Npad * 32, wT = ncc * wB;                       // (the running weight offset of h2_tile: one add per step instead of a re-derivation)
     int wsl = n0 * 32;
     auto load_b = [&](int set, int dslab, int t) __attribute__((always_inline)) {
@@ -674,10 +683,12 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     //   (a store precedes the next load issued in its tap)
     auto step = [&](int cc, int t, int SA) __attribute__((always_inline)) {
         const bool fresh = t == 0 || t == 4;
-        const int t2 = (t + 2) % 9;
-        load_b(t2 % 3, t + 2 >= 9 ? 1 : 0, t2);
+        const int t2 = (t + BD - 1) % 9;
+        load_b(t2 % BD, t + BD - 1 >= 9 ? 1 : 0, t2);
         if (t < 8) load_a(SA ^ 1, cc, t + 1);
-        if (NR == 5) {
+        if (DEEP) {
+            if (t < 3) stage_load_x(cc + 1, t);
+        } else if (NR == 5) {
             if (t == 1) stage_store(cc + 1, 0);
             if (t == 3) stage_store(cc + 1, 1);
             if (t == 4) stage_store(cc + 1, 2);
@@ -692,7 +703,7 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
             if (t == 3) stage_load_x(cc + 1, 1);
             if (t == 6) stage_load_x(cc + 1, 2);
         }
-        const int SB = t % 3;
+        const int SB = t % BD;
         if (NPROD == 1) {
             product(SA, SB, 0, 0, fresh);
         } else {
@@ -700,7 +711,9 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
             product(SA, SB, 0, NPL - 1, false);                      // hi * lo
             product(SA, SB, 0, 0, false);                            // hi * hi
         }
-        if (NR == 5) {
+        if (DEEP) {
+            if (t >= 6) stage_store(cc + 1, t - 6);
+        } else if (NR == 5) {
             if (t == 8) stage_store(cc + 1, 4);
         } else {
             if (t == 2) stage_store(cc + 1, 0);
@@ -726,8 +739,8 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
     // prologue: patch of slab 0, weight fragments of steps (0,0) and (0,1)
 #pragma unroll
     for (int r = 0; r < NR; ++r) { stage_load_x(0, r); stage_store(0, r); }
-    load_b(0, 0, 0);
-    load_b(1, 0, 1);
+#pragma unroll
+    for (int i = 0; i < BD - 1; ++i) load_b(i, 0, i);
     int cc = 0;
     for (; cc + 2 <= ncc; cc += 2) { slab(cc, 0); slab(cc + 1, 1); }
     if (cc < ncc) slab(cc, 0);
@@ -748,13 +761,13 @@ __device__ __forceinline__ void h2d_tile(const ConvArgs& a, unsigned char* smem_
 // two stages x two planes x two octet regions + sink (+ 2 Cin floats x 2 of the table, added by the launcher)
 constexpr int h2d_lds_bytes(int PR) { return 2 * 2 * 2 * (2 * PR + 1) * 68 * 16 + 2048; }
 
-template <int BN, int NWV, int NPROD, bool AFFINE, int PR = kPatchRows>
-__global__ __launch_bounds__(64 * NWV, (NWV == 8 || PR == 2) ? 3 : 2)  // waves per SIMD: eight waves = 1.5 workgroups' worth; two rows: three workgroups of four
+template <int BN, int NWV, int NPROD, bool AFFINE, int PR = kPatchRows, bool DEEP = false>
+__global__ __launch_bounds__(64 * NWV, DEEP ? 2 : ((NWV == 8 || PR == 2) ? 3 : 2))  // waves per SIMD: eight waves = 1.5 workgroups' worth; two rows: three workgroups of four (DEEP: two)
 void conv_h2d_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     const int bid = xcd_item(blockIdx.x, a.tiles_m * a.tiles_n);
     const int tile_m = bid / a.tiles_n;
-    h2d_tile<BN, NWV, NPROD, AFFINE, PR>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
+    h2d_tile<BN, NWV, NPROD, AFFINE, PR, DEEP>(a, smem_raw, tile_m, (bid - tile_m * a.tiles_n) * BN);
 }
 
 }  // namespace tsnet

@@ -57,15 +57,15 @@ void go_h2_shape(const ConvArgs& a, int pr, int bn, hipStream_t s) {
     else throw std::invalid_argument("conv(h2): tile must be 4x32, 4x64, 4x128 or 2x128");
 }
 
-template <int BN, int NWV, int NPROD, int PR = kPatchRows>
+template <int BN, int NWV, int NPROD, int PR = kPatchRows, bool DEEP = false>
 void go_h2d(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)h2d_lds_bytes(PR) + (size_t)2 * a.Cin * 4;
     if (a.in_alpha) {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NWV, NPROD, true, PR>), lds);
-        hipLaunchKernelGGL((conv_h2d_kernel<BN, NWV, NPROD, true, PR>), dim3(a.tiles_m * a.tiles_n), dim3(64 * NWV), lds, s, a);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NWV, NPROD, true, PR, DEEP>), lds);
+        hipLaunchKernelGGL((conv_h2d_kernel<BN, NWV, NPROD, true, PR, DEEP>), dim3(a.tiles_m * a.tiles_n), dim3(64 * NWV), lds, s, a);
     } else {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NWV, NPROD, false, PR>), lds);
-        hipLaunchKernelGGL((conv_h2d_kernel<BN, NWV, NPROD, false, PR>), dim3(a.tiles_m * a.tiles_n), dim3(64 * NWV), lds, s, a);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(conv_h2d_kernel<BN, NWV, NPROD, false, PR, DEEP>), lds);
+        hipLaunchKernelGGL((conv_h2d_kernel<BN, NWV, NPROD, false, PR, DEEP>), dim3(a.tiles_m * a.tiles_n), dim3(64 * NWV), lds, s, a);
     }
 }
 
@@ -120,8 +120,13 @@ void launch_conv_h2s(const ConvArgs& a, int nprod, hipStream_t s) {
     else throw std::invalid_argument("conv(h2s): 1 (bf16 operands) or 3 products");
 }
 
-void launch_conv_h2d(const ConvArgs& a, int pr, int bn, int nprod, hipStream_t s) {
+void launch_conv_h2d(const ConvArgs& a, int pr, int bn, int nprod, bool deep, hipStream_t s) {
     if (nprod != 1 && nprod != 3) throw std::invalid_argument("conv(h2d): 1 (bf16 operands) or 3 products");
+    if (deep) {                        // launches that cannot fill the chip: weights eight steps ahead, the three staging rounds in flight together (conv_h2.hpp)
+        if (pr != 2 || bn != 128 || nprod != 3) throw std::invalid_argument("conv(h2d): the deep schedule is the 2 x 128 tile's, fp16 x 2 operands");
+        go_h2d<128, 4, 3, 2, true>(a, s);
+        return;
+    }
     if (pr == 4 && bn == 64) { if (nprod == 3) go_h2d<64, 4, 3>(a, s); else go_h2d<64, 4, 1>(a, s); }
     else if (pr == 4 && bn == 128) { if (nprod == 3) go_h2d<128, 8, 3>(a, s); else go_h2d<128, 8, 1>(a, s); }
     else if (pr == 2 && bn == 128) { if (nprod == 3) go_h2d<128, 4, 3, 2>(a, s); else go_h2d<128, 4, 1, 2>(a, s); }

@@ -415,7 +415,7 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
             // two rows x 128 columns (four waves, 44 KiB of LDS: three workgroups per CU) wherever the layer is 128 channels wide: 125 -> 99 us
             // on 256 -> 512, 117 -> 109 us on 128 -> 256 at batch 4, equal or better down to one frame (profiles/round3_conv_variants.txt);
             // the four-row shapes hold 80 KiB and run one workgroup per CU
-            if (c.tile / 10000) throw ArgError("conv(h2d): the stride-2 tiles have no two-K-group / deep-prefetch form");
+            if (c.tile / 10000 > 1) throw ArgError("conv(h2d): the stride-2 tiles have no two-K-group form (1xxxx: the deep schedule of the 2 x 128 tile)");
             const int tc = c.tile % 10000;
             int pr = tc >= 1000 ? tc / 1000 : 4, bn = tc % 1000;          // a code without a width (0, 2000, 4000) leaves the width to the heuristic
             if (bn == 0) {
@@ -426,7 +426,11 @@ void run_conv(Ctx& ctx, const ConvLayer& L, const ConvCall& c) {
             if (g.Npad % bn) throw ArgError("conv(h2d): the tile width must divide the padded output width");
             if (g.Ho % pr) throw ArgError("conv(h2d): the output height must be a multiple of the tile's rows");
             set_tiles(pr * kPatchCols, bn);
-            launch_conv_h2d(g, pr, bn, c.nprod, ctx.stream);
+            // A launch of at most two workgroups per CU (a single frame's: 64 .. 384 tiles) runs the deep schedule -- nothing else hides a lone
+            // workgroup's memory round trips (72 -> us on the 64-tile launch).  Same bits: the choice may follow the batch.  Tile code 12128 forces
+            // it, 2128 the plain schedule.
+            const bool deep = c.tile ? c.tile / 10000 == 1 : (pr == 2 && bn == 128 && c.nprod == 3 && (long)g.tiles_m * g.tiles_n <= 2L * device_cus());
+            launch_conv_h2d(g, pr, bn, c.nprod, deep, ctx.stream);
             ++g_launch_counters[0];
         } else {
             if (c.abl || c.opt) throw ArgError("conv: experiment variants exist for the 3x3 / stride-1 patch kernel only");
@@ -531,15 +535,26 @@ void run_upsample(Ctx& ctx, const float* x, const float* alpha, const float* bet
 
 // RGB head (head_conv.hpp): head_conv3_kernel for widths that are multiples of 16 (every reference caller: ngf = 64), the
 // one-pixel-per-thread form for narrower nets.  The choice depends on the width alone.
-void launch_head(const HeadArgs& ha, int hh, int ww, int B, hipStream_t s) {
+void launch_head(const HeadArgs& ha, int hh, int ww, int B, hipStream_t s, int force_rows = 0) {
     if (ha.C % (2 * kHead3Ch) != 0) {
         const int tiles = ((ww + kHeadT - 1) / kHeadT) * ((hh + kHeadT - 1) / kHeadT);
         hipLaunchKernelGGL(head_conv_kernel, dim3(tiles, B), dim3(256), 0, s, ha);
     } else {
-        const int tiles = ((ww + kHead3T - 1) / kHead3T) * ((hh + kHead3T - 1) / kHead3T);
-        const size_t lds = (size_t)(2 * (kHead3PatchF4 + kHead3WtsF4) + ha.C / 2) * sizeof(float4);
-        ensure_dynamic_lds(reinterpret_cast<const void*>(head_conv3_kernel), lds);
-        hipLaunchKernelGGL(head_conv3_kernel, dim3(tiles, B), dim3(512), lds, s, ha);
+        // Tile rows by the number of workgroups (head_conv.hpp): the tallest tile that still gives every CU one -- 32 rows from B = 4 on
+        // at 256^2, 16 at B = 2, 8 for one frame (84 -> 3x us there: eight waves on 64 CUs queue at the LDS pipe).  Same bits for every choice.
+        const int tiles_x = (ww + kHead3T - 1) / kHead3T;
+        auto go = [&](auto tr) {
+            constexpr int TR = decltype(tr)::value;
+            const size_t lds = (size_t)(2 * (head3_patch_f4(TR) + kHead3WtsF4) + ha.C / 2) * sizeof(float4);
+            ensure_dynamic_lds(reinterpret_cast<const void*>(head_conv3_kernel<TR>), lds);
+            hipLaunchKernelGGL(head_conv3_kernel<TR>, dim3(tiles_x * ((hh + TR - 1) / TR), B), dim3(TR * 16), lds, s, ha);
+        };
+        const long cus = device_cus();
+        if (force_rows && force_rows != 8 && force_rows != 16 && force_rows != 32) throw ArgError("head: tile rows 8, 16 or 32");
+        const int rows = force_rows ? force_rows : ((long)B * tiles_x * ((hh + 31) / 32) >= cus ? 32 : ((long)B * tiles_x * ((hh + 15) / 16) >= cus ? 16 : 8));
+        if (rows == 32) go(std::integral_constant<int, 32>{});
+        else if (rows == 16) go(std::integral_constant<int, 16>{});
+        else go(std::integral_constant<int, 8>{});
     }
     check_launch("head_conv");
     ++g_launch_counters[2];
@@ -1554,9 +1569,9 @@ int tsnet_op_head(const float* x, int N, int H, int W, int C, const float* in_al
     HeadArgs ha{};
     ha.x = x; ha.alpha = in_alpha; ha.beta = in_alpha ? in_beta : nullptr; ha.w = tab; ha.bias = bd; ha.y = y;
     ha.N = N; ha.H = H; ha.W = W; ha.C = C;
-    ha.composite = composite; ha.fore_x0 = 64; ha.fore_x1 = 192;
+    ha.composite = composite & 1; ha.fore_x0 = 64; ha.fore_x1 = 192;
     for (int c = 0; c < 3; ++c) ha.bg[c] = bg ? bg[c] : 0.f;
-    launch_head(ha, H, W, N, s);
+    launch_head(ha, H, W, N, s, composite >> 8);               // (bits 8..: tile rows to force -- operator tests; the forward passes 0 / 1)
     HIP_TRY(hipStreamSynchronize(s));
     OP_END
 }

@@ -113,6 +113,12 @@ __global__ __launch_bounds__(256) void head_conv_kernel(HeadArgs a) {
 //   * 32 x 32 output tile, 8 channels per stage and half (48.6 KB patch + 4.7 KB weights each), 1.41x halo over-fetch.
 // Two fmaf chains per output and 8-channel stage (even / odd channels, 196 products each: tap row, quad, tap column), added and folded
 // into the running total.
+// TR = rows of the tile (32, 16 or 8; 32 columns always; TR x 8 threads per half).  The kernel is bound by the CU's LDS pipe (every wave reads
+// 434 x 1 KiB per stage: eight waves keep the pipe busy 3 x as long as their own FMAs take), and a head of few frames is few waves: at B = 1
+// the 512 waves sat eight to a CU on 64 of the 256 CUs.  Shorter tiles spread the same waves over more CUs -- four (TR = 16) or two (TR = 8)
+// per CU, where the LDS pipe no longer binds -- for a larger halo (1.63x / 2.07x staged bytes).  A pixel's arithmetic does not depend on the
+// tile it sits in (same stages, same chains, same half-0 + half-1 sum): the same bits for every TR (tested), so the launcher may choose by
+// the batch (engine.cpp launch_head).
 #ifdef TSNET_UNIFORM
 #define HEAD_UNIFORM(x) TSNET_UNIFORM(x)
 #else
@@ -121,25 +127,30 @@ __global__ __launch_bounds__(256) void head_conv_kernel(HeadArgs a) {
 typedef float head_f2 __attribute__((ext_vector_type(2)));
 typedef float head_f4 __attribute__((ext_vector_type(4)));
 constexpr int kHead3T = 32, kHead3P = kHead3T + 6, kHead3Slots = 10, kHead3Ch = 8;
-constexpr int kHead3PatchF4 = (kHead3Ch / 4) * kHead3P * 4 * kHead3Slots;       // float4 entries of the patch
+constexpr int head3_patch_f4(int TR) { return (kHead3Ch / 4) * (TR + 6) * 4 * kHead3Slots; }       // float4 entries of the patch of a TR-row tile
 constexpr int kHead3WtsF4 = 49 * (kHead3Ch / 4) * 3;
 
-__global__ __launch_bounds__(512, 1) void head_conv3_kernel(HeadArgs a) {
+template <int TR>
+__global__ __launch_bounds__(TR * 16, 1) void head_conv3_kernel(HeadArgs a) {
+    static_assert(TR == 32 || TR == 16 || TR == 8, "tile rows");
+    constexpr int TH = TR * 8;                                          // threads of a half: one per four horizontally adjacent pixels
+    constexpr int PRW = TR + 6, PPX = PRW * kHead3P;                    // patch rows, patch pixels (38 columns)
+    constexpr int kHead3PatchF4 = head3_patch_f4(TR);
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, smem_raw)
     // 512 threads = two halves of four waves.  Both halves own the same 32 x 32 pixels; half h takes the channel stages h, h + 2, ... through
     // its own patch / weight region and the two partial sums are added at the end (half 0 + half 1, a fixed order).  At B = 4 the head is
     // only 256 tiles: splitting the channels is what puts two waves on every SIMD, and it halves the number of barrier-separated stages.
-    const int half = HEAD_UNIFORM((int)(threadIdx.x >> 8));           // wave-uniform: region bases stay scalar
+    const int half = HEAD_UNIFORM((int)(threadIdx.x / TH));           // wave-uniform: region bases stay scalar
     float4* tile = reinterpret_cast<float4*>(smem_raw) + half * (kHead3PatchF4 + kHead3WtsF4);      // [quad][38 rows][4 column phases][10 slots]
     float4* wts = tile + kHead3PatchF4;                                 // [49 taps][quad][r, g, b] x 4 channels
     float4* abt = reinterpret_cast<float4*>(smem_raw) + 2 * (kHead3PatchF4 + kHead3WtsF4);          // (alpha, beta) of the image: [C/4] alpha quads, [C/4] beta quads
-    const int tid = threadIdx.x & 255;
+    const int tid = threadIdx.x & (TH - 1);
     const int tx = tid & 7, ty = tid >> 3;
     const int tiles_x = (a.W + kHead3T - 1) / kHead3T;
     const int n = blockIdx.y;
-    const int bx = (blockIdx.x % tiles_x) * kHead3T, by = (blockIdx.x / tiles_x) * kHead3T;
+    const int bx = (blockIdx.x % tiles_x) * kHead3T, by = (blockIdx.x / tiles_x) * TR;
     if (a.alpha) {                                                      // once per workgroup: a global load per stage would sit on the critical path
-        for (int i = threadIdx.x; i < a.C / 2; i += 512)
+        for (int i = threadIdx.x; i < a.C / 2; i += 2 * TH)
             abt[i] = *reinterpret_cast<const float4*>((i < a.C / 4 ? a.alpha : a.beta - a.C) + (size_t)n * a.C + i * 4);
         __syncthreads();
     }
@@ -148,14 +159,14 @@ __global__ __launch_bounds__(512, 1) void head_conv3_kernel(HeadArgs a) {
     for (int p = 0; p < 4; ++p) { tot[p][0] = 0.f; tot[p][1] = 0.f; tot[p][2] = 0.f; }
     // Staging geometry, fixed over the channel stages: this thread's (up to 12) patch entries and (up to 2) weight entries.  The loads of
     // stage s + 1 are issued before the FMAs of stage s and held in registers (one wave per SIMD: nothing else would cover their latency).
-    constexpr int NPE = ((kHead3Ch / 4) * kHead3P * kHead3P + 255) / 256;       // 12
-    constexpr int NWE = (kHead3WtsF4 + 255) / 256;                               // 2
+    constexpr int NPE = ((kHead3Ch / 4) * PPX + TH - 1) / TH;                   // 12 (TR = 32), 14, 17
+    constexpr int NWE = (kHead3WtsF4 + TH - 1) / TH;                             // 2, 3, 5
     unsigned src_off[NPE];
 #pragma unroll
     for (int e = 0; e < NPE; ++e) {
-        const int i = tid + e * 256;
-        const bool ok = i < (kHead3Ch / 4) * kHead3P * kHead3P;
-        const int q = ok ? i / (kHead3P * kHead3P) : 0, p = ok ? i - q * (kHead3P * kHead3P) : 0;
+        const int i = tid + e * TH;
+        const bool ok = i < (kHead3Ch / 4) * PPX;
+        const int q = ok ? i / PPX : 0, p = ok ? i - q * PPX : 0;
         const int py = p / kHead3P, px = p - py * kHead3P;
         int iy = by + py - 3, ix = bx + px - 3;
         iy = iy < 0 ? -iy : iy; iy = iy >= a.H ? 2 * (a.H - 1) - iy : iy;
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void head_conv3_kernel(HeadArgs a) {
     unsigned wsrc[NWE];
 #pragma unroll
     for (int e = 0; e < NWE; ++e) {
-        const int i = tid + e * 256;
+        const int i = tid + e * TH;
         const int ii = i < kHead3WtsF4 ? i : 0;
         const int col = ii % 3, tq = ii / 3, q = tq % (kHead3Ch / 4), tap = tq / (kHead3Ch / 4);
         wsrc[e] = (unsigned)((tap * a.C + q * 4) * 4 + col);    // [tap][cin][4]: component `col` of four channels (+ c0 * 4 per stage)
@@ -187,23 +198,23 @@ __global__ __launch_bounds__(512, 1) void head_conv3_kernel(HeadArgs a) {
         for (int e = 0; e < NPE; ++e) {
             float4 v = sreg[e];
             if (a.alpha) {
-                const int c = c0 + (e * 256 + tid >= kHead3P * kHead3P ? 4 : 0);         // entries are quad-major: quad 1 starts at 38 * 38
+                const int c = c0 + (e * TH + tid >= PPX ? 4 : 0);                        // entries are quad-major: quad 1 starts at PPX
                 const float4 al = abt[c >> 2], be = abt[(a.C + c) >> 2];
                 v.x = __builtin_fmaf(v.x, al.x, be.x); v.y = __builtin_fmaf(v.y, al.y, be.y);
                 v.z = __builtin_fmaf(v.z, al.z, be.z); v.w = __builtin_fmaf(v.w, al.w, be.w);
                 v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                 v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
             }
-            const int i = tid + e * 256;                            // recomputed, not kept: registers are the scarce resource here
-            if (i < (kHead3Ch / 4) * kHead3P * kHead3P) {
-                const int q = i / (kHead3P * kHead3P), p = i - q * (kHead3P * kHead3P);
+            const int i = tid + e * TH;                             // recomputed, not kept: registers are the scarce resource here
+            if (i < (kHead3Ch / 4) * PPX) {
+                const int q = i / PPX, p = i - q * PPX;
                 const int py = p / kHead3P, px = p - py * kHead3P;
-                tile[((q * kHead3P + py) * 4 + (px & 3)) * kHead3Slots + (px >> 2)] = v;
+                tile[((q * PRW + py) * 4 + (px & 3)) * kHead3Slots + (px >> 2)] = v;
             }
         }
 #pragma unroll
         for (int e = 0; e < NWE; ++e)
-            if (tid + e * 256 < kHead3WtsF4) wts[tid + e * 256] = wreg[e];
+            if (tid + e * TH < kHead3WtsF4) wts[tid + e * TH] = wreg[e];
     };
     static_assert(kHead3Ch / 4 == 2, "stage_store: two channel quads per stage");
     const int nst = a.C / kHead3Ch;                                     // stages: an even number (C % 16 == 0, checked by the launcher)
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(512, 1) void head_conv3_kernel(HeadArgs a) {
         // ahead are requested before the current step's FMAs (register double / triple buffers, scheduling fences keep the order).
         head_f4 pxb[2][10], wb[3][3];
         auto load_px = [&](int buf, int it) __attribute__((always_inline)) {
-            const head_f4* row = reinterpret_cast<const head_f4*>(tile + (((it & 1) * kHead3P + ty + (it >> 1)) * 4) * kHead3Slots + tx);
+            const head_f4* row = reinterpret_cast<const head_f4*>(tile + (((it & 1) * PRW + ty + (it >> 1)) * 4) * kHead3Slots + tx);
 #pragma unroll
             for (int j = 0; j < 10; ++j) pxb[buf][j] = row[(j & 3) * kHead3Slots + (j >> 2)];      // patch column 4 tx + j
         };
@@ -268,14 +279,14 @@ __global__ __launch_bounds__(512, 1) void head_conv3_kernel(HeadArgs a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int o = 0; o < 3; ++o) xch[(p * 3 + o) * 256 + tid] = tot[p][o];
+            for (int o = 0; o < 3; ++o) xch[(p * 3 + o) * TH + tid] = tot[p][o];
     }
     __syncthreads();
     if (half == 1) return;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int o = 0; o < 3; ++o) tot[p][o] += xch[(p * 3 + o) * 256 + tid];
+        for (int o = 0; o < 3; ++o) tot[p][o] += xch[(p * 3 + o) * TH + tid];
     const size_t hw = (size_t)a.H * a.W;
     const int oy = by + ty;
 #pragma unroll

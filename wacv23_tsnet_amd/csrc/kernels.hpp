@@ -16,7 +16,7 @@ namespace tsnet {
 //   h2d (3x3 / stride 2): bn = 64 (four waves) or 128 (eight waves)
 void launch_conv_h2(const ConvArgs& a, int pr, int bn, int nprod, int abl, int opt, hipStream_t s);
 void launch_conv_h2s(const ConvArgs& a, int nprod, hipStream_t s);
-void launch_conv_h2d(const ConvArgs& a, int pr, int bn, int nprod, hipStream_t s);
+void launch_conv_h2d(const ConvArgs& a, int pr, int bn, int nprod, bool deep, hipStream_t s);
 // conv_w1.hpp -- 3x3 / stride 1 / pad 1 as Winograd F(2,3) along x: 4 x 32 pixels x 64 channels per tile (eight waves); the layer's
 // weights are the TRANSFORMED filters (12 "taps": tap row ky x position p, pack_weights_kernel with kh = 3, kw = 4)
 void launch_conv_w1(const ConvArgs& a, int nprod, int abl, hipStream_t s);      // abl: tools build only
