@@ -35,7 +35,7 @@ def test_hot_kernels_do_not_spill_in_their_loops():
         assert r["vgpr"] <= (256 if ("4, 128, 2, 2" in name or ", 24>" in name) else 168), (name, r["vgpr"])
     # the encoder front end and the general kernel's layers of the headline forward (DESIGN.md section 1's "no spill in a hot loop" now
     # covers them; the one tolerated case is written down in tools/isa_check.py)
-    for unit, pat, hot in (("conv_h2_launch.cpp", "conv_h2d_kernel", ic.HOT_FRONT[:2]), ("conv_h2_launch.cpp", "conv_h2s_kernel", ic.HOT_FRONT[2:]),
+    for unit, pat, hot in (("conv_h2_launch.cpp", "conv_h2d_kernel", ic.HOT_FRONT[:2]), ("conv_h2_launch.cpp", "conv_h2s_kernel", ic.HOT_FRONT[2:]), ("conv_h2_launch.cpp", "conv_h2d_kernel", ic.HOT_FRONT_DEEP),
                            ("conv_h2r_launch.cpp", "conv_h2r_kernel", ic.HOT_GENERAL), ("conv_g64_launch.cpp", "conv_g64_kernel", ic.HOT_G64),
                            ("conv_g64_launch.cpp", "conv_h2s32_kernel", ic.HOT_S32)):
         rows = {r["name"]: r for r in ic.analyse(ic.compile_asm(unit=unit), pat)}

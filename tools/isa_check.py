@@ -16,7 +16,9 @@ HOT = [("conv_h2_kernel<4, 64, 2, 2, 3, true, 0, 0>", 0), ("conv_h2_kernel<4, 64
        ("conv_h2_kernel<4, 128, 1, 4, 1, true, 0, 0>", 0), ("conv_h2_kernel<4, 128, 1, 4, 1, false, 0, 0>", 0)]
 # the encoder front end of the headline forward: the stride-2 patch kernel from 128 channels on, the 7 x 7 stem.  The IN + ReLU form of the
 # stride-2 tile holds 2 spill operations per slab pair at its 168 VGPRs (three workgroups per CU): measured, tolerated, pinned so that it cannot grow unseen.
-HOT_FRONT = [("conv_h2d_kernel<128, 4, 3, true, 2>", 2), ("conv_h2d_kernel<128, 4, 3, false, 2>", 0), ("conv_h2s_kernel<3>", 0)]
+HOT_FRONT = [("conv_h2d_kernel<128, 4, 3, true, 2, false>", 2), ("conv_h2d_kernel<128, 4, 3, false, 2, false>", 0), ("conv_h2s_kernel<3>", 0)]
+# the deep schedule of single-frame launches (round 6): 250 - 253 VGPRs, two workgroups per CU, no spill
+HOT_FRONT_DEEP = [("conv_h2d_kernel<128, 4, 3, true, 2, true>", 0), ("conv_h2d_kernel<128, 4, 3, false, 2, true>", 0)]
 # ... and of the general kernel's unit (conv_h2r_launch.cpp): the 64 -> 128 stride-2 layer and the two 1 x 1 convolutions
 HOT_GENERAL = [("conv_h2r_kernel<3, 128, 2, 2, 3, true, false>", 0), ("conv_h2r_kernel<1, 64, 2, 2, 3, false, false>", 0)]
 # ... and of its 64-deep-step form (conv_g64_launch.cpp, round 6), which now carries those layers in the forward: the 64-row tile, 1 x 1 on a raw input,
