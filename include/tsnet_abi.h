@@ -158,7 +158,7 @@ int tsnet_timing_read(tsnet_handle h, double ms_out[TSNET_TIMING_CLASSES], int64
  *   up-convolution layers on; the op packs the transformed filters itself; `tile` = tiles per workgroup, 1, 2 or 3, 0 = the launcher's choice).
  *   tile: 0 = the launcher's choice; patch 3x3 / stride 1: 32, 64, 128 (4-row tiles), 2128 (2 rows x 128), 3128 (nprod = 1 only: 4 rows x 128
  *   with the four waves side by side, the bf16 modes' own tile), 20032 / 20064 (two-K-group tiles); patch 3x3 / stride 2: 64, 128 (4 rows)
- *   or 2128 (2 rows x 128: the forward's shape); general kernel: 64 or 128 (16-deep steps, conv_h2r.hpp), 3064 / 3128 (64-deep steps,
+ *   or 2128 (2 rows x 128: the forward's shape; 12128: its deep schedule, what a launch of at most two workgroups per CU runs); general kernel: 64 or 128 (16-deep steps, conv_h2r.hpp), 3064 / 3128 (64-deep steps,
  *   conv_g64.hpp, 64 / 128 rows: where the layer allows, the forward's choice).
  *   All one-group tiles of one kernel produce identical bits, and so do the two two-group tiles among themselves (tested); the two-group
  *   tiles, and patch vs general kernels, sum K in another association / order: agreement to fp32 rounding.
